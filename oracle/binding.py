@@ -1,0 +1,173 @@
+"""ctypes binding of the CPU restatement (oracle/libcactus_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by cactus_amd/.  Arrays are numpy; halves
+travel as uint16 bit patterns (use .view(np.float16) to look at them).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcactus_oracle.so")
+
+
+def build():
+    """Compile the restatement with gcc (oracle/Makefile)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    sz, vp = C.c_size_t, C.c_void_p
+    lib.oracle_h2f.restype = C.c_float
+    lib.oracle_h2f.argtypes = [C.c_uint16]
+    lib.oracle_f2h.restype = C.c_uint16
+    lib.oracle_f2h.argtypes = [C.c_float]
+    lib.oracle_set_fma.argtypes = [C.c_int]
+    lib.oracle_set_threads.argtypes = [C.c_int]
+    lib.oracle_matmul_int8.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, vp]
+    lib.oracle_matmul_int4.argtypes = [vp, vp, vp, vp, vp, sz, sz, sz, sz, vp]
+    lib.oracle_matmul_f16.argtypes = [vp, vp, vp, sz, sz, sz]
+    lib.oracle_fp16_max_abs.restype = C.c_float
+    lib.oracle_fp16_max_abs.argtypes = [vp, sz]
+    lib.oracle_fp16_to_int8.argtypes = [vp, vp, sz, C.c_float]
+    lib.oracle_quantize_activations.argtypes = [vp, vp, vp, sz, sz]
+    lib.oracle_quantize_kv_fp16_to_int8.argtypes = [vp, vp, vp, sz, sz, sz, sz]
+    lib.oracle_unpack_int4_to_int8.argtypes = [vp, vp, sz]
+    lib.oracle_attention_f16.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz, sz, sz, C.c_float,
+                                         vp, sz, sz, C.c_int]
+    lib.oracle_attention_hybrid_int8_fp16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp,
+                                                      sz, sz, sz, sz, sz, sz, sz, C.c_float,
+                                                      sz, C.c_int, sz]
+    return lib
+
+
+lib = _load()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.float16 and dt == np.uint16:
+        a = a.view(np.uint16)
+    assert a.dtype == dt, (a.dtype, dt)
+    return a
+
+
+def set_fma(fused):
+    lib.oracle_set_fma(int(bool(fused)))
+
+
+def set_threads(n):
+    lib.oracle_set_threads(int(n))
+
+
+def h2f(bits):
+    return lib.oracle_h2f(int(bits))
+
+
+def f2h(x):
+    return lib.oracle_f2h(float(x))
+
+
+def matmul_int8(A, A_scales, B, B_scales, group_size, want_group_sums=False):
+    A = _c(A, np.int8); B = _c(B, np.int8)
+    As = _c(A_scales, np.float32); Bs = _c(B_scales, np.uint16)
+    M, K = A.shape; N = B.shape[0]
+    Cout = np.zeros((M, N), np.uint16)
+    gs = np.zeros((M, N, K // group_size), np.int32) if want_group_sums else None
+    lib.oracle_matmul_int8(_p(A), _p(As), _p(B), _p(Bs), _p(Cout), M, K, N, group_size, _p(gs))
+    return (Cout, gs) if want_group_sums else Cout
+
+
+def matmul_int4(A, A_scales, B_packed, B_scales, group_size, want_group_sums=False):
+    A = _c(A, np.int8); Bp = _c(B_packed, np.uint8)
+    As = _c(A_scales, np.float32); Bs = _c(B_scales, np.uint16)
+    M, K = A.shape; N = Bp.shape[0]
+    assert Bp.shape[1] * 2 == K
+    Cout = np.zeros((M, N), np.uint16)
+    gs = np.zeros((M, N, K // group_size), np.int32) if want_group_sums else None
+    lib.oracle_matmul_int4(_p(A), _p(As), _p(Bp), _p(Bs), _p(Cout), M, K, N, group_size, _p(gs))
+    return (Cout, gs) if want_group_sums else Cout
+
+
+def matmul_f16(a, bT):
+    a = _c(a, np.uint16); bT = _c(bT, np.uint16)
+    M, K = a.shape; N = bT.shape[0]
+    c = np.zeros((M, N), np.uint16)
+    lib.oracle_matmul_f16(_p(a), _p(bT), _p(c), M, K, N)
+    return c
+
+
+def fp16_max_abs(src):
+    src = _c(src, np.uint16)
+    return lib.oracle_fp16_max_abs(_p(src), src.size)
+
+
+def fp16_to_int8(src, scale):
+    src = _c(src, np.uint16)
+    dst = np.zeros(src.shape, np.int8)
+    lib.oracle_fp16_to_int8(_p(src), _p(dst), src.size, float(scale))
+    return dst
+
+
+def quantize_activations(src):
+    src = _c(src, np.uint16)
+    M, K = src.shape
+    dst = np.zeros((M, K), np.int8)
+    scales = np.zeros(M, np.float32)
+    lib.oracle_quantize_activations(_p(src), _p(dst), _p(scales), M, K)
+    return dst, scales
+
+
+def quantize_kv(src, group_size=128):
+    src = _c(src, np.uint16)
+    S, H, D = src.shape
+    G = (D + group_size - 1) // group_size
+    dst = np.zeros((S, H, D), np.int8)
+    scales = np.zeros((S, H, G), np.float32)
+    lib.oracle_quantize_kv_fp16_to_int8(_p(src), _p(dst), _p(scales), S, H, D, group_size)
+    return dst, scales
+
+
+def unpack_int4(packed, count):
+    packed = _c(packed, np.uint8)
+    out = np.zeros(count, np.int8)
+    lib.oracle_unpack_int4_to_int8(_p(packed), _p(out), count)
+    return out
+
+
+def attention_f16(q, k, v, scale, mask=None, position_offset=0, window_size=0, is_causal=True):
+    q = _c(q, np.uint16); k = _c(k, np.uint16); v = _c(v, np.uint16)
+    B, S, Hq, D = q.shape
+    KV, Hkv = k.shape[1], k.shape[2]
+    m = None if mask is None else _c(mask, np.uint16)
+    out = np.zeros(q.shape, np.uint16)
+    lib.oracle_attention_f16(_p(q), _p(k), _p(v), _p(out), B, S, KV, Hq, Hkv, D, float(scale),
+                             _p(m), position_offset, window_size, int(bool(is_causal)))
+    return out
+
+
+def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale,
+                     position_offset=0, is_causal=True, group_size=128, cache_len=None):
+    q = _c(q, np.uint16); kn = _c(k_new, np.uint16); vn = _c(v_new, np.uint16)
+    kc = _c(k_cached, np.int8); vc = _c(v_cached, np.int8)
+    ks = _c(k_scales, np.float32); vs = _c(v_scales, np.float32)
+    B, S, Hq, D = q.shape
+    new_len, Hkv = kn.shape[1], kn.shape[2]
+    if cache_len is None:
+        cache_len = kc.shape[-3]
+    out = np.zeros(q.shape, np.uint16)
+    lib.oracle_attention_hybrid_int8_fp16(_p(q), _p(kc), _p(vc), _p(ks), _p(vs), _p(kn), _p(vn),
+                                          _p(out), B, S, cache_len, new_len, Hq, Hkv, D,
+                                          float(scale), position_offset, int(bool(is_causal)),
+                                          group_size)
+    return out

@@ -1,0 +1,564 @@
+/*
+ * cactus_oracle.c -- CPU restatement of the Cactus quantized hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see cactus_oracle.h): the checker the HIP kernels
+ * are compared with, and the CPU baseline bench.py times.  Plain scalar C; the
+ * reference's NEON lane structure is restated with explicit per-lane scalars
+ * wherever it decides a floating-point summation order.
+ *
+ * Citations are to /root/reference (cactus v1.5.0), path:line.
+ *
+ * Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp (oracle/Makefile).
+ * -ffp-contract=off matters: every fused multiply-add below is an explicit
+ * fmaf()/fma() so that g_fused alone decides where one rounding is used.
+ */
+#include "cactus_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int g_fused = 1;
+static int g_threads = 1;
+
+void oracle_set_fma(int fused) { g_fused = fused ? 1 : 0; }
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+
+/* a*b + c the way the reference's compiler evaluates `c += a * b` / vfmaq_f32:
+ * vfmaq_* is always fused; plain C++ statements are fused only under the
+ * default -ffp-contract=on of the ARM toolchains (no flag in
+ * cactus/CMakeLists.txt:21,34), which g_fused models. */
+static inline float mad_stmt(float a, float b, float c) {
+    if (g_fused) return fmaf(a, b, c);
+    float p = a * b;
+    return p + c;
+}
+
+/* ------------------------------------------------------------------------ */
+/* binary16 helpers                                                          */
+/* ------------------------------------------------------------------------ */
+
+float oracle_h2f(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112u) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+/* double -> binary16, round-to-nearest-even, straight from the double's bits
+ * (no intermediate float, so no double rounding). */
+static uint16_t d2h(double d) {
+    uint64_t bits;
+    memcpy(&bits, &d, 8);
+    uint16_t sign = (uint16_t)((bits >> 48) & 0x8000u);
+    int exp = (int)((bits >> 52) & 0x7FF);
+    uint64_t man = bits & 0xFFFFFFFFFFFFFull;
+    if (exp == 0x7FF) return (uint16_t)(sign | 0x7C00u | (man ? 0x200u : 0));
+    if (exp == 0) return sign; /* double subnormal: far below half's range */
+    int e = exp - 1023;        /* unbiased */
+    uint64_t sig = man | (1ull << 52); /* 53-bit significand, value = sig * 2^(e-52) */
+    int shift;                 /* bits dropped from sig */
+    int hexp;                  /* biased half exponent of the result before carry */
+    if (e >= -14) {
+        shift = 42;            /* keep 11 bits */
+        hexp = e + 15;
+    } else {
+        shift = 42 + (-14 - e); /* subnormal half: fewer bits kept */
+        hexp = 0;
+        if (shift > 63) return sign; /* rounds to zero (value < 2^-25 / tie impossible) */
+    }
+    uint64_t kept = sig >> shift;
+    uint64_t rem = sig & ((1ull << shift) - 1);
+    uint64_t half = 1ull << (shift - 1);
+    if (rem > half || (rem == half && (kept & 1))) kept++;
+    uint32_t out;
+    if (hexp == 0) {
+        out = (uint32_t)kept; /* a carry into bit 10 makes it the smallest normal: correct */
+    } else {
+        out = ((uint32_t)hexp << 10) + (uint32_t)(kept - 0x400u); /* carry bumps exponent */
+    }
+    if (out >= 0x7C00u) out = 0x7C00u; /* overflow -> inf */
+    return (uint16_t)(sign | out);
+}
+
+uint16_t oracle_f2h(float f) { return d2h((double)f); }
+
+/* fp16 a*b+c with ONE rounding to binary16 (NEON vfmaq_f16 lane semantics).
+ * p is exact in double; the sum is made exact-or-sticky (round to odd) before
+ * the single rounding to half. */
+static uint16_t h_fma(uint16_t c, uint16_t a, uint16_t b) {
+    double p = (double)oracle_h2f(a) * (double)oracle_h2f(b);
+    double cc = (double)oracle_h2f(c);
+    double s = cc + p;
+    if (isfinite(s)) {
+        double bb = s - cc;
+        double err = (cc - (s - bb)) + (p - bb);
+        if (err != 0.0) {
+            uint64_t bits;
+            memcpy(&bits, &s, 8);
+            if (!(bits & 1)) {
+                /* move one ulp toward the true value, which makes the last bit odd */
+                int toward_up = (err > 0.0) == (s > 0.0);
+                if (s == 0.0) { s = err; }
+                else { bits += toward_up ? 1 : (uint64_t)-1; memcpy(&s, &bits, 8); }
+            }
+        }
+    }
+    return d2h(s);
+}
+
+/* fp16 a+b with one rounding (vadd_f16); exact in double. */
+static uint16_t h_add(uint16_t a, uint16_t b) {
+    return d2h((double)oracle_h2f(a) + (double)oracle_h2f(b));
+}
+
+/* ------------------------------------------------------------------------ */
+/* INT4 nibble decode: cactus/kernel/kernel_utils.h:165-185                  */
+/* low nibble = even element, high nibble = odd element, value n>7 ? n-16 : n */
+/* ------------------------------------------------------------------------ */
+static inline int8_t nib_lo(uint8_t b) { int n = b & 0x0F; return (int8_t)(n > 7 ? n - 16 : n); }
+static inline int8_t nib_hi(uint8_t b) { int n = b >> 4;   return (int8_t)(n > 7 ? n - 16 : n); }
+
+/* cactus/kernel/kernel_quants.cpp:295-351 */
+void oracle_unpack_int4_to_int8(const uint8_t* packed, int8_t* unpacked, size_t unpacked_count) {
+    size_t packed_count = (unpacked_count + 1) / 2;
+    /* The 16-byte vector body only stores a 16-element half when it fits
+     * entirely (kernel_quants.cpp:325-330); the byte tail stores element-wise
+     * (:343-348).  With one thread simd_end = (packed_count/16)*16. */
+    const size_t simd_end = (packed_count / 16) * 16;
+    for (size_t i = 0; i < packed_count; i++) {
+        size_t o = 2 * i;
+        if (i < simd_end) {
+            size_t blk = (i / 16) * 16;      /* first packed byte of this vector */
+            size_t out0 = blk * 2;           /* first output of val[0] */
+            size_t half_start = (o < out0 + 16) ? out0 : out0 + 16;
+            if (half_start + 16 > unpacked_count) continue; /* half not stored */
+        }
+        if (o < unpacked_count) unpacked[o] = nib_lo(packed[i]);
+        if (o + 1 < unpacked_count) unpacked[o + 1] = nib_hi(packed[i]);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Grouped INT8 / INT4 matmul                                                */
+/* cactus/kernel/kernel_gemm.cpp:128-327 (int8), :329-529 (int4)             */
+/*   num_groups = K / group_size              (:147, :348; K tail dropped)   */
+/*   acc_g = sum_{k in g} A[m,k]*B[n,k]       exact INT32 (:170-309)         */
+/*   running_sum += (float)acc_g * (float)Bs[n,g], g ascending (:311-316)    */
+/*   C[m,n] = (__fp16)(running_sum * A_scales[m]) (:319-324)                 */
+/* ------------------------------------------------------------------------ */
+static void matmul_q(const int8_t* A, const float* A_scales,
+                     const int8_t* B8, const uint8_t* B4, const uint16_t* B_scales,
+                     uint16_t* C, size_t M, size_t K, size_t N, size_t gs,
+                     int32_t* gsum_out) {
+    if (M == 0 || K == 0 || N == 0) return; /* kernel_gemm.cpp:137, :338 */
+    const size_t G = K / gs;
+    const size_t Kp = K / 2;
+    #pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
+        int8_t* brow = (int8_t*)malloc(gs ? gs : 1);
+        float* run = (float*)malloc(sizeof(float) * M);
+        #pragma omp for schedule(static)
+        for (long long nn = 0; nn < (long long)N; nn++) {
+            size_t n = (size_t)nn;
+            for (size_t m = 0; m < M; m++) run[m] = 0.0f;
+            for (size_t g = 0; g < G; g++) {
+                const int8_t* bp;
+                if (B4) {
+                    const uint8_t* p = B4 + n * Kp + (g * gs) / 2;
+                    for (size_t k = 0; k < gs; k += 2) {
+                        brow[k] = nib_lo(p[k / 2]);
+                        brow[k + 1] = nib_hi(p[k / 2]);
+                    }
+                    bp = brow;
+                } else {
+                    bp = B8 + n * K + g * gs;
+                }
+                const float bscale = oracle_h2f(B_scales[n * G + g]);
+                for (size_t m = 0; m < M; m++) {
+                    const int8_t* ap = A + m * K + g * gs;
+                    int32_t acc = 0;
+                    for (size_t k = 0; k < gs; k++) acc += (int32_t)ap[k] * (int32_t)bp[k];
+                    if (gsum_out) gsum_out[(m * N + n) * G + g] = acc;
+                    run[m] = mad_stmt((float)acc, bscale, run[m]);
+                }
+            }
+            for (size_t m = 0; m < M; m++) C[m * N + n] = oracle_f2h(run[m] * A_scales[m]);
+        }
+        free(brow);
+        free(run);
+    }
+}
+
+void oracle_matmul_int8(const int8_t* A, const float* A_scales, const int8_t* B,
+                        const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
+                        size_t group_size, int32_t* group_sums_out) {
+    matmul_q(A, A_scales, B, NULL, B_scales, C, M, K, N, group_size, group_sums_out);
+}
+
+void oracle_matmul_int4(const int8_t* A, const float* A_scales, const uint8_t* B_packed,
+                        const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
+                        size_t group_size, int32_t* group_sums_out) {
+    matmul_q(A, A_scales, NULL, B_packed, B_scales, C, M, K, N, group_size, group_sums_out);
+}
+
+/* ------------------------------------------------------------------------ */
+/* FP16 matmul with fp16 accumulators: cactus/kernel/kernel_gemm.cpp:8-126   */
+/* Lane j of the 8-wide accumulator takes k = 16i+j then 16i+8+j (two        */
+/* vfmaq_f16 per 16-step, :57-58), then k = K16+8i+j (:76), lane 0 takes the */
+/* scalar tail in float (:88), and hsum_f16x8 folds (l0+l4)+(l2+l6) with     */
+/* (l1+l5)+(l3+l7) (:8-15).                                                  */
+/* ------------------------------------------------------------------------ */
+void oracle_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c,
+                       size_t M, size_t K, size_t N) {
+    const size_t K16 = (K / 16) * 16, K8 = (K / 8) * 8;
+    #pragma omp parallel for num_threads(g_threads) if (g_threads > 1) schedule(static)
+    for (long long mm = 0; mm < (long long)M; mm++) {
+        size_t m = (size_t)mm;
+        for (size_t n = 0; n < N; n++) {
+            uint16_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint16_t* ar = a + m * K;
+            const uint16_t* br = bT + n * K;
+            for (size_t k = 0; k < K16; k += 16) {
+                for (int j = 0; j < 8; j++) acc[j] = h_fma(acc[j], ar[k + j], br[k + j]);
+                for (int j = 0; j < 8; j++) acc[j] = h_fma(acc[j], ar[k + 8 + j], br[k + 8 + j]);
+            }
+            for (size_t k = K16; k < K8; k += 8)
+                for (int j = 0; j < 8; j++) acc[j] = h_fma(acc[j], ar[k + j], br[k + j]);
+            for (size_t k = K8; k < K; k++) {
+                /* __fp16 operands promote to float; the product is exact in float */
+                float t = oracle_h2f(acc[0]) + oracle_h2f(ar[k]) * oracle_h2f(br[k]);
+                acc[0] = oracle_f2h(t);
+            }
+            uint16_t s4[4];
+            for (int j = 0; j < 4; j++) s4[j] = h_add(acc[j], acc[j + 4]);
+            uint16_t s2_0 = h_add(s4[0], s4[2]);
+            uint16_t s2_1 = h_add(s4[1], s4[3]);
+            c[m * N + n] = h_add(s2_0, s2_1);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Activation quantization                                                   */
+/* cactus/kernel/kernel_quants.cpp:196-221 (max_abs), :158-194 (to_int8),    */
+/* cactus/graph/graph_ops_nn.cpp:46-50 (scale rule).                         */
+/* Restates the single-thread partition (count < 5000, the ELEMENT_WISE gate */
+/* of kernel_utils.h:431): multiples of 8 round to nearest even after the    */
+/* clamp; the count%8 tail rounds half away from zero.                       */
+/* ------------------------------------------------------------------------ */
+float oracle_fp16_max_abs(const uint16_t* src, size_t count) {
+    float m = 0.0f;
+    for (size_t i = 0; i < count; i++) {
+        float v = fabsf(oracle_h2f(src[i]));
+        if (v > m) m = v;
+    }
+    return m;
+}
+
+static inline int8_t sat8(long v) { return (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v)); }
+
+void oracle_fp16_to_int8(const uint16_t* src, int8_t* dst, size_t count, float scale) {
+    const float inv = 1.0f / scale;              /* kernel_quants.cpp:159 */
+    const size_t simd_end = (count / 8) * 8;
+    for (size_t i = 0; i < count; i++) {
+        float q = oracle_h2f(src[i]) * inv;
+        q = fmaxf(fminf(q, 127.0f), -128.0f);    /* :177-178 / :191 */
+        if (i < simd_end) dst[i] = sat8(lrintf(q));   /* vcvtnq_s32_f32: ties to even */
+        else dst[i] = (int8_t)roundf(q);              /* std::round: ties away */
+    }
+}
+
+void oracle_quantize_activations(const uint16_t* src, int8_t* dst, float* scales,
+                                 size_t M, size_t K) {
+    for (size_t m = 0; m < M; m++) {
+        float max_abs = oracle_fp16_max_abs(src + m * K, K);
+        float scale = max_abs / 127.0f;
+        if (scale < 1e-10f) scale = 1e-10f;
+        scales[m] = scale;
+        oracle_fp16_to_int8(src + m * K, dst + m * K, K, scale);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* KV quantization: cactus/kernel/kernel_quants.cpp:223-293                  */
+/* No clamp before the rounding in the vector body (:248-252, saturating     */
+/* narrows); the count%8 tail uses roundf then clamps (:256-261).            */
+/* ------------------------------------------------------------------------ */
+static float quantize_group(const uint16_t* src, int8_t* dst, size_t count) {
+    float max_abs = 0.0f;
+    for (size_t k = 0; k < count; k++) {
+        float v = fabsf(oracle_h2f(src[k]));
+        if (v > max_abs) max_abs = v;
+    }
+    float scale = max_abs / 127.0f;
+    if (scale < 1e-10f) scale = 1e-10f;
+    const float inv = 1.0f / scale;
+    const size_t simd_end = (count / 8) * 8;
+    for (size_t k = 0; k < count; k++) {
+        float v = oracle_h2f(src[k]) * inv;
+        if (k < simd_end) dst[k] = sat8(lrintf(v));
+        else dst[k] = sat8((long)roundf(v));
+    }
+    return scale;
+}
+
+void oracle_quantize_kv_fp16_to_int8(const uint16_t* src, int8_t* dst, float* scales,
+                                     size_t seq_len, size_t kv_heads, size_t head_dim,
+                                     size_t group_size) {
+    const size_t G = (head_dim + group_size - 1) / group_size;
+    for (size_t idx = 0; idx < seq_len * kv_heads; idx++) {
+        for (size_t g = 0; g < G; g++) {
+            size_t start = g * group_size;
+            size_t cnt = head_dim - start < group_size ? head_dim - start : group_size;
+            scales[idx * G + g] = quantize_group(src + idx * head_dim + start,
+                                                 dst + idx * head_dim + start, cnt);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Attention.  Shared skeleton of cactus/kernel/kernel_attention.cpp:        */
+/*   8 fp32 lanes per dot product: lane j sums dims d = j (mod 8) with fmas  */
+/*   (:132-133, :369-370, :385-386); score = vaddvq(low+high) = ((s0+s1)+    */
+/*   (s2+s3)) with s_j = low_j + high_j (:136, :390).  Blocks of 32 keys;    */
+/*   per block the running max is REPLACED by the block max and running sum  */
+/*   / accumulators are rescaled by expf(running_max - block_max) (:160-169, */
+/*   :395-404).  Output accumulators are fmas in key order (:221-222,        */
+/*   :438-439), final = acc * (1/running_sum) rounded to fp16 (:229-243).    */
+/* ------------------------------------------------------------------------ */
+static inline float lanes_sum8(const float* l) {
+    float s0 = l[0] + l[4], s1 = l[1] + l[5], s2 = l[2] + l[6], s3 = l[3] + l[7];
+    return (s0 + s1) + (s2 + s3);
+}
+
+/* 4-wide polynomial 2^x used by cactus_attention_f16 (kernel_attention.cpp:174-195),
+ * restated on one element with the same integer steps (wrapping shift included). */
+static inline float poly_exp_weight(float score, float block_max) {
+    if (score == -INFINITY) return 0.0f;                  /* inf_mask -> 0 (:176,191) */
+    float x = (score - block_max) * 1.442695f;
+    int32_t xi;
+    if (isnan(x)) xi = 0;
+    else if (x <= -2147483648.0f) xi = INT32_MIN;
+    else if (x >= 2147483648.0f) xi = INT32_MAX;
+    else xi = (int32_t)x;                                 /* vcvtq_s32_f32: toward zero */
+    float xf = x - (float)xi;
+    float y = fmaf(xf, 0.6931472f, 1.0f);                 /* vfmaq_n_f32 */
+    y = fmaf(xf * xf, 0.2402265f, y);                     /* vfmaq_f32   */
+    uint32_t e = ((uint32_t)xi + 127u) << 23;             /* vaddq_s32 + vshlq_n_s32 */
+    float p2;
+    memcpy(&p2, &e, 4);
+    return y * p2;
+}
+
+void oracle_attention_f16(const uint16_t* queries, const uint16_t* keys, const uint16_t* values,
+                          uint16_t* output, size_t B, size_t S, size_t KV,
+                          size_t Hq, size_t Hkv, size_t D, float scale,
+                          const uint16_t* mask, size_t position_offset, size_t window_size,
+                          int is_causal) {
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);   /* :27-29 */
+    const size_t BLOCK = 32, Da = (D / 8) * 8;
+    const size_t gq = Hq / Hkv;
+    const long long total = (long long)(B * Hq * S);
+    #pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
+        float* acc = (float*)malloc(sizeof(float) * (Da ? Da : 1));
+        float bs[32];
+        #pragma omp for schedule(static)
+        for (long long w = 0; w < total; w++) {
+            size_t b = (size_t)w / (Hq * S), rem = (size_t)w % (Hq * S);
+            size_t h = rem / S, qp = rem % S, kvh = h / gq;
+            const uint16_t* q = queries + b * S * Hq * D + qp * Hq * D + h * D;
+            const uint16_t* Kb = keys + b * KV * Hkv * D;
+            const uint16_t* Vb = values + b * KV * Hkv * D;
+            const uint16_t* Mk = mask ? mask + b * S * KV : NULL;
+            uint16_t* o = output + b * S * Hq * D + qp * Hq * D + h * D;
+            float run_max = -INFINITY, run_sum = 0.0f;
+            for (size_t d = 0; d < Da; d++) acc[d] = 0.0f;
+            const int is_decode = (qp == S - 1) && S > 1;  /* :75 */
+            const size_t qabs = position_offset + qp;
+            size_t kv_start = 0, kv_end = KV;
+            if (window_size > 0 && window_size < KV) {   /* :81-90 */
+                if (qabs > window_size) kv_start = qabs - window_size;
+                if (is_causal && qabs + 1 < kv_end) kv_end = qabs + 1;
+            } else if (is_causal) {
+                if (qabs + 1 < kv_end) kv_end = qabs + 1;
+            }
+            for (size_t kb = kv_start; kb < kv_end; kb += BLOCK) {
+                size_t ke = kb + BLOCK < KV ? kb + BLOCK : KV; /* clamps to KV, not kv_end (:93) */
+                size_t bsz = ke - kb;
+                float bmax = -INFINITY;
+                if (!is_decode && is_causal && kb > qabs) continue; /* :98-103 */
+                for (size_t i = 0; i < bsz; i++) {
+                    size_t kp = kb + i;
+                    if (!is_decode && is_causal && kp > qabs) { bs[i] = -INFINITY; continue; }
+                    const uint16_t* k = Kb + kp * Hkv * D + kvh * D;
+                    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (size_t d = 0; d < Da; d += 8)
+                        for (int j = 0; j < 8; j++)
+                            l[j] = fmaf(oracle_h2f(q[d + j]), oracle_h2f(k[d + j]), l[j]);
+                    float sc = lanes_sum8(l);
+                    for (size_t d = Da; d < D; d++)          /* scalar tail (:138-140) */
+                        sc = mad_stmt(oracle_h2f(q[d]), oracle_h2f(k[d]), sc);
+                    sc *= scale;
+                    if (is_causal && kp > qabs) sc = -INFINITY;              /* :146 */
+                    else if (window_size > 0 && kp < qabs && (qabs - kp) > window_size) sc = -INFINITY;
+                    else if (Mk && oracle_h2f(Mk[qp * KV + kp]) == 0.0f) sc = -INFINITY;
+                    bs[i] = sc;
+                    if (sc > bmax) bmax = sc;
+                }
+                if (bmax > -INFINITY) {
+                    float corr = expf(run_max - bmax);
+                    run_sum *= corr;
+                    for (size_t d = 0; d < Da; d++) acc[d] *= corr;
+                    run_max = bmax;
+                }
+                float bsum = 0.0f;
+                size_t vec = (bsz / 4) * 4;
+                for (size_t i = 0; i < vec; i += 4) {        /* :174-195 */
+                    float y[4];
+                    for (int j = 0; j < 4; j++) { y[j] = poly_exp_weight(bs[i + j], bmax); bs[i + j] = y[j]; }
+                    bsum += (y[0] + y[1]) + (y[2] + y[3]);
+                }
+                for (size_t i = vec; i < bsz; i++) {         /* :197-204 */
+                    if (bs[i] != -INFINITY) { bs[i] = expf(bs[i] - bmax); bsum += bs[i]; }
+                    else bs[i] = 0.0f;
+                }
+                for (size_t i = 0; i < bsz; i++) {
+                    float wgt = bs[i];
+                    if (wgt == 0.0f) continue;
+                    const uint16_t* v = Vb + (kb + i) * Hkv * D + kvh * D;
+                    for (size_t d = 0; d < Da; d++) acc[d] = fmaf(oracle_h2f(v[d]), wgt, acc[d]);
+                }
+                run_sum += bsum;
+            }
+            if (run_sum > 0.0f) {
+                float inv = 1.0f / run_sum;
+                for (size_t d = 0; d < Da; d++) o[d] = oracle_f2h(acc[d] * inv);
+                for (size_t d = Da; d < D; d++) o[d] = 0;   /* :245-247 */
+            } else {
+                for (size_t d = 0; d < D; d++) o[d] = 0;
+            }
+        }
+        free(acc);
+    }
+}
+
+/* cactus/kernel/kernel_attention.cpp:257-482 */
+void oracle_attention_hybrid_int8_fp16(const uint16_t* queries,
+                                       const int8_t* keys_cached, const int8_t* values_cached,
+                                       const float* k_scales, const float* v_scales,
+                                       const uint16_t* keys_new, const uint16_t* values_new,
+                                       uint16_t* output,
+                                       size_t B, size_t S, size_t cache_len, size_t new_len,
+                                       size_t Hq, size_t Hkv, size_t D, float scale,
+                                       size_t position_offset, int is_causal, size_t qgs) {
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);   /* :278-280 */
+    const size_t KV = cache_len + new_len;
+    const size_t BLOCK = 32, Da = (D / 8) * 8;
+    const size_t gq = Hq / Hkv;
+    const size_t G = (D + qgs - 1) / qgs;
+    const long long total = (long long)(B * Hq * S);
+    #pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
+        float* acc = (float*)malloc(sizeof(float) * (Da ? Da : 1));
+        float bs[32];
+        #pragma omp for schedule(static)
+        for (long long w = 0; w < total; w++) {
+            size_t b = (size_t)w / (Hq * S), rem = (size_t)w % (Hq * S);
+            size_t h = rem / S, qp = rem % S, kvh = h / gq;
+            const uint16_t* q = queries + b * S * Hq * D + qp * Hq * D + h * D;
+            const int8_t* Kc = keys_cached + b * cache_len * Hkv * D;
+            const int8_t* Vc = values_cached + b * cache_len * Hkv * D;
+            const uint16_t* Kn = keys_new + b * new_len * Hkv * D;
+            const uint16_t* Vn = values_new + b * new_len * Hkv * D;
+            uint16_t* o = output + b * S * Hq * D + qp * Hq * D + h * D;
+            float run_max = -INFINITY, run_sum = 0.0f;
+            for (size_t d = 0; d < Da; d++) acc[d] = 0.0f;
+            const size_t qabs = position_offset + qp;
+            size_t kv_end = KV;
+            if (is_causal && qabs + 1 < KV) kv_end = qabs + 1;  /* :331-332 */
+            for (size_t kb = 0; kb < kv_end; kb += BLOCK) {
+                size_t ke = kb + BLOCK < kv_end ? kb + BLOCK : kv_end;
+                size_t bsz = ke - kb;
+                float bmax = -INFINITY;
+                for (size_t i = 0; i < bsz; i++) {
+                    size_t kp = kb + i;
+                    if (is_causal && kp > qabs) { bs[i] = -INFINITY; continue; }
+                    float l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (kp < cache_len) {
+                        const int8_t* k = Kc + kp * Hkv * D + kvh * D;
+                        const float* ks = k_scales + (kp * Hkv + kvh) * G;  /* :353 (no batch stride) */
+                        for (size_t d = 0; d < Da; d += 8) {
+                            float s = ks[d / qgs];
+                            for (int j = 0; j < 8; j++) {
+                                float kd = (float)k[d + j] * s;             /* :366-367 */
+                                l[j] = fmaf(oracle_h2f(q[d + j]), kd, l[j]);
+                            }
+                        }
+                    } else {
+                        const uint16_t* k = Kn + (kp - cache_len) * Hkv * D + kvh * D;
+                        for (size_t d = 0; d < Da; d += 8)
+                            for (int j = 0; j < 8; j++)
+                                l[j] = fmaf(oracle_h2f(q[d + j]), oracle_h2f(k[d + j]), l[j]);
+                    }
+                    float sc = lanes_sum8(l) * scale;                       /* :390 */
+                    bs[i] = sc;
+                    if (sc > bmax) bmax = sc;
+                }
+                if (bmax > -INFINITY) {
+                    float corr = expf(run_max - bmax);
+                    run_sum *= corr;
+                    for (size_t d = 0; d < Da; d++) acc[d] *= corr;
+                    run_max = bmax;
+                }
+                float bsum = 0.0f;
+                for (size_t i = 0; i < bsz; i++) {                          /* :407-414 */
+                    if (bs[i] != -INFINITY) { bs[i] = expf(bs[i] - bmax); bsum += bs[i]; }
+                    else bs[i] = 0.0f;
+                }
+                for (size_t i = 0; i < bsz; i++) {
+                    float wgt = bs[i];
+                    if (wgt == 0.0f) continue;
+                    size_t kp = kb + i;
+                    if (kp < cache_len) {
+                        const int8_t* v = Vc + kp * Hkv * D + kvh * D;
+                        const float* vs = v_scales + (kp * Hkv + kvh) * G;
+                        for (size_t d = 0; d < Da; d++) {
+                            float vd = (float)v[d] * vs[d / qgs];
+                            acc[d] = fmaf(vd, wgt, acc[d]);
+                        }
+                    } else {
+                        const uint16_t* v = Vn + (kp - cache_len) * Hkv * D + kvh * D;
+                        for (size_t d = 0; d < Da; d++) acc[d] = fmaf(oracle_h2f(v[d]), wgt, acc[d]);
+                    }
+                }
+                run_sum += bsum;
+            }
+            if (run_sum > 0.0f) {
+                float inv = 1.0f / run_sum;
+                /* dims beyond the last multiple of 8 are not written (:464-474) */
+                for (size_t d = 0; d < Da; d++) o[d] = oracle_f2h(acc[d] * inv);
+            } else {
+                for (size_t d = 0; d < D; d++) o[d] = 0;
+            }
+        }
+        free(acc);
+    }
+}
