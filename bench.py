@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the quantized hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): the synthetic INT8-weight x FP16-activation matmul sweep,
+K, N in {1024, 2048, 4096, 8192}.  One *step* is one pass of the decode-shaped (M = 1) sweep:
+for each of the 16 (K, N) shapes, quantize the FP16 activation row (graph_ops_nn.cpp:35-66) and
+run the grouped INT8 matmul (kernel_gemm.cpp:128-327), FP16 in / FP16 out, on weights already
+resident in HBM.  Two complete weight sets (450 MB) alternate between steps so that no weight is
+served from the 256 MiB Infinity Cache.  `value` is algorithmic bytes of a step (weights + scales
++ activations + outputs) times ranks, divided by the slowest rank's time per step.
+
+Ranks are independent replicas (independent sequences): no collective on the data path, weak
+scaling.  The same JSON line carries
+  roofline      -- the dominant kernel (8192 x 8192 INT8 GEMV) timed alone with HIP events
+  cpu_baseline  -- the CPU restatement of the reference kernel on the same sweep (rank 0, N=1)
+  extra         -- per-shape GEMV rates (INT8 and packed INT4), M = 16, M = 512 MFMA rate,
+                   decode attention over the INT8 KV cache.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SIZES = [1024, 2048, 4096, 8192]
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E, spec
+INT8_MFMA_PEAK_TOPS = 5000.0  # dense INT8 = 2x the ~2.5 PF dense BF16 rate
+
+
+def gemv_bytes(M, K, N, int4=False, fused_quant=True):
+    """Algorithmic bytes of one matmul call (weights + scales + activations + outputs)."""
+    w = N * K // 2 if int4 else N * K
+    act = 2 * M * K if fused_quant else (M * K + 4 * M)
+    return w + 2 * N * (K // 128) + act + 2 * M * N
+
+
+def make_weights(K, N, int4, gen):
+    if int4:
+        B = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device="cuda", generator=gen)
+    else:
+        B = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda", generator=gen)
+    Bs = (0.01 + torch.rand((N, K // 128), device="cuda", generator=gen) * 0.05).half()
+    return B, Bs
+
+
+def time_events(fn, iters, warm=3):
+    """Average milliseconds per call of fn(i), HIP events on torch's current stream (the stream
+    the kernels are launched on)."""
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(steps=5):
+    """The oracle (CPU restatement of the reference kernel -- its NEON sources do not build on
+    x86) on the same M=1 sweep, with the reference's thread policy for M <= 1: 4 GEMM threads
+    (kernel_utils.h:450-455); 1 warm-up + `steps` timed passes (tests/test_threading.cpp:111-120)."""
+    from oracle import binding as O
+    rng = np.random.default_rng(42)
+    threads = min(4, os.cpu_count() or 1)
+    O.set_threads(threads)
+    work = []
+    total = 0
+    for K in SIZES:
+        x = rng.uniform(-1, 1, (1, K)).astype(np.float16)
+        for N in SIZES:
+            B = rng.integers(-127, 128, (N, K), dtype=np.int8)
+            Bs = (0.01 + np.abs(rng.uniform(-1, 1, (N, K // 128))) * 0.05).astype(np.float16)
+            work.append((x, B, Bs))
+            total += gemv_bytes(1, K, N)
+
+    def one_pass():
+        for x, B, Bs in work:
+            A, As = O.quantize_activations(x)
+            O.matmul_int8(A, As, B, Bs, 128)
+
+    one_pass()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    dt = (time.perf_counter() - t0) / steps
+    O.set_threads(1)
+    return {"value": round(total / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"full M=1 INT8 sweep (16 shapes, {total / 1e6:.0f} MB/pass), 1 warm-up + {steps} "
+                      f"timed passes, {threads} threads = the reference's GEMM policy for M<=1; scalar C "
+                      "restatement compiled with gcc -O3 -march=x86-64-v3 (NEON reference is unbuildable on x86)",
+            "ms_per_pass": round(dt * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / M=16 / M=512 / attention table")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    import cactus_amd.hip as H
+    H.init(torch.cuda.current_device())
+
+    gen = torch.Generator(device="cuda").manual_seed(42 + rank)
+
+    # ---- workload: two complete weight sets, FP16 activation rows per K
+    sets = []
+    for _ in range(2):
+        sets.append({(K, N): make_weights(K, N, False, gen) for K in SIZES for N in SIZES})
+    acts = {K: (torch.rand((1, K), device="cuda", generator=gen) * 2 - 1).half() for K in SIZES}
+    outs = {N: torch.empty((1, N), dtype=torch.float16, device="cuda") for N in SIZES}
+    step_bytes = sum(gemv_bytes(1, K, N) for K in SIZES for N in SIZES)
+
+    def step(i):
+        ws = sets[i & 1]
+        for K in SIZES:
+            x = acts[K]
+            for N in SIZES:
+                q, s = H.quantize_activations(x)
+                B, Bs = ws[(K, N)]
+                H.matmul_int8(q, s, B, Bs, 128, out=outs[N])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = step_bytes * world / (dt / args.steps) / 1e9
+
+    # ---- roofline: dominant kernel alone (8192 x 8192 INT8, M = 1), 8 distinct weight buffers
+    # (512 MB > Infinity Cache) visited round robin.
+    K = N = 8192
+    big = [sets[0][(K, N)], sets[1][(K, N)]] + [make_weights(K, N, False, gen) for _ in range(6)]
+    q, s = H.quantize_activations(acts[K])
+    o = outs[N]
+    ms = time_events(lambda i: H.matmul_int8(q, s, big[i % 8][0], big[i % 8][1], 128, out=o), 80, warm=8)
+    kbytes = gemv_bytes(1, K, N, fused_quant=False)
+    achieved = kbytes / (ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "skinny_kernel<false> (INT8 GEMV, M=1, K=N=8192)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": kbytes, "us_per_launch": round(ms * 1e3, 2)}
+
+    extra = {}
+    if not args.no_extra and rank == 0:
+        extra = extra_table(H, gen, big)
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "quant_gemv_hbm_throughput", "value": round(value, 1), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+            "config": {"workload": "INT8-weight x FP16-activation matmul sweep, M=1, K,N in {1024,2048,4096,8192} "
+                                   "(16 shapes/step: activation quant + grouped INT8 GEMV, group 128); "
+                                   "two alternating weight sets (450 MB)",
+                       "bytes_per_step": step_bytes, "parallelism": f"replicas x{world} (independent sequences)"},
+            "roofline": roofline,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        if extra:
+            line["extra"] = extra
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def extra_table(H, gen, big):
+    """Secondary measurements (HIP-event timed, rotating buffers where the operand is big)."""
+    ex = {}
+    # per-shape GEMV, INT8 and packed INT4, M = 1 and M = 16
+    for int4 in (False, True):
+        tag = "int4" if int4 else "int8"
+        for M in (1, 16):
+            rows = {}
+            for K, N in ((1024, 1024), (4096, 4096), (8192, 8192), (1024, 151936)):
+                nb = max(2, int(600e6 // max(1, (N * K // (2 if int4 else 1)))) + 1)
+                nb = min(nb, 64)
+                ws = [make_weights(K, N, int4, gen) for _ in range(nb)]
+                x = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
+                q, s = H.quantize_activations(x)
+                o = torch.empty((M, N), dtype=torch.float16, device="cuda")
+                fn = H.matmul_int4 if int4 else H.matmul_int8
+                ms = time_events(lambda i: fn(q, s, ws[i % nb][0], ws[i % nb][1], 128, out=o), 60, warm=6)
+                gb = gemv_bytes(M, K, N, int4, fused_quant=False) / (ms * 1e-3) / 1e9
+                rows[f"K{K}_N{N}"] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1),
+                                      "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
+                del ws
+            ex[f"gemv_{tag}_M{M}"] = rows
+    # M = 512 GEMM: MFMA rate
+    for int4 in (False, True):
+        rows = {}
+        for K, N in ((4096, 4096), (8192, 8192)):
+            B, Bs = make_weights(K, N, int4, gen)
+            x = (torch.rand((512, K), device="cuda", generator=gen) * 2 - 1).half()
+            q, s = H.quantize_activations(x)
+            o = torch.empty((512, N), dtype=torch.float16, device="cuda")
+            fn = H.matmul_int4 if int4 else H.matmul_int8
+            ms = time_events(lambda i: fn(q, s, B, Bs, 128, out=o), 20, warm=3)
+            tops = 2.0 * 512 * N * K / (ms * 1e-3) / 1e12
+            rows[f"K{K}_N{N}"] = {"us": round(ms * 1e3, 1), "TOPS": round(tops, 1),
+                                  "frac_int8_mfma_peak": round(tops / INT8_MFMA_PEAK_TOPS, 4)}
+        ex["gemm_%s_M512" % ("int4" if int4 else "int8")] = rows
+    # decode attention over the INT8 KV cache
+    rows = {}
+    for name, Hq, Hkv, D, cache, Bn in (("qwen3_c512", 16, 8, 128, 512, 1), ("qwen3_c4096", 16, 8, 128, 4096, 1),
+                                        ("8b_c32768", 32, 8, 128, 32768, 1), ("qwen3_c4096_b64", 16, 8, 128, 4096, 64)):
+        kq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+        vq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+        ks = torch.rand((Bn, cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+        vs = torch.rand((Bn, cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+        qh = (torch.rand((Bn, 1, Hq, D), device="cuda", generator=gen) * 2 - 1).half()
+        kn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+        vn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+        lens = torch.full((Bn,), cache, dtype=torch.int32, device="cuda")
+        ms = time_events(lambda i: H.attention_hybrid_batched(qh, kq, vq, ks, vs, kn, vn, 0.0, lens, lens), 30, warm=3)
+        byts = Bn * (2 * cache * Hkv * (D + 4) + 2 * Hkv * D * 2 + 2 * Hq * D * 2)
+        gb = byts / (ms * 1e-3) / 1e9
+        rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
+    ex["attn_decode_int8kv"] = rows
+    return ex
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,68 @@
+// Internal launcher declarations shared by the kernel translation units and the C ABI.
+// Every launcher validates nothing: operand shapes are checked by the C ABI (api.hip)
+// before a kernel is enqueued.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace cactus_hip {
+
+// quant_kernels.hip
+hipError_t launch_act_quant(const uint16_t* src, int8_t* dst, float* scales, size_t M, size_t K,
+                            hipStream_t st);
+hipError_t launch_fp16_to_int8(const uint16_t* src, int8_t* dst, size_t count, float scale,
+                               hipStream_t st);
+hipError_t launch_max_abs(const uint16_t* src, size_t count, float* out, hipStream_t st);
+hipError_t launch_kv_quant(const uint16_t* src, int8_t* dst, float* scales, size_t seq, size_t heads,
+                           size_t D, size_t gs, hipStream_t st);
+hipError_t launch_unpack_int4(const uint8_t* packed, int8_t* unpacked, size_t count, hipStream_t st);
+
+// matmul_skinny.hip: M <= 16, group_size == 128.  B is int8[N,K] or packed uint8[N,K/2].
+// If gsums != nullptr the kernel also writes the INT32 group sums [M,N,G]; C may then be null.
+hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,
+                                const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
+                                size_t K, size_t N, hipStream_t st);
+
+// matmul_gemm.hip: any M, group_size == 128, MFMA tiles staged through LDS.
+hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
+                              const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
+                              size_t K, size_t N, hipStream_t st);
+
+// matmul_generic.hip: any group_size (whole groups of K only), one thread per output.
+hipError_t launch_matmul_generic(bool int4, const int8_t* A, const float* A_scales, const void* B,
+                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
+                                 size_t K, size_t N, size_t gs, hipStream_t st);
+
+// matmul_f16.hip
+hipError_t launch_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K,
+                             size_t N, hipStream_t st);
+
+// attention.hip
+struct AttnArgs {
+    const uint16_t* q;
+    const int8_t* k_cached;
+    const int8_t* v_cached;
+    const float* k_scales;
+    const float* v_scales;
+    const uint16_t* k_new;   // hybrid: new keys; f16 mode: all keys
+    const uint16_t* v_new;
+    uint16_t* out;
+    const uint16_t* mask;        // f16 mode only
+    const int32_t* cache_lens;   // optional per-sequence cache length (batched decode)
+    const int32_t* pos_offsets;  // optional per-sequence position offset
+    size_t B, S, cache_len, new_len, Hq, Hkv, D;
+    float scale;
+    size_t position_offset, window_size;
+    int is_causal;
+    size_t qgs;                  // KV quant group size
+    size_t cache_batch_stride;   // elements between sequences in k_cached/v_cached
+    size_t scale_batch_stride;   // elements between sequences in k_scales/v_scales
+    int f16_mode;                // 1: cactus_attention_f16 semantics, 0: hybrid
+};
+// workspace: float scratch for split-KV partials; needs attn_workspace_bytes(args) bytes.
+size_t attn_workspace_bytes(const AttnArgs& a);
+hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
+
+}  // namespace cactus_hip

@@ -1,0 +1,90 @@
+// FP16 matmul C = A * B^T (a half[M,K], b_transposed half[N,K]) on the FP16 matrix cores with
+// fp32 accumulation.  Replaces cactus_matmul_f16 (kernel_gemm.cpp:102-126), which accumulates
+// in fp16 lanes; results therefore agree to a tolerance, with this kernel the closer of the two
+// to the exact product.
+//
+// 64x64 output tile per 256-thread workgroup (4 waves, each 32x32 = 2x2 MFMA tiles of
+// v_mfma_f32_16x16x32_f16), K walked in steps of 32 through LDS rows padded to 80 bytes.
+// Any M, N, K: out-of-range rows and the K tail are zero-filled while staging.
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace cactus_hip {
+
+constexpr int F16_LDS_STRIDE = 40;  // halfs per LDS row (32 + 8 pad, keeps 16-byte alignment)
+
+__global__ __launch_bounds__(256) void matmul_f16_kernel(const uint16_t* __restrict__ A,
+                                                        const uint16_t* __restrict__ BT,
+                                                        uint16_t* __restrict__ C, int M, int K, int N,
+                                                        int vec_ok) {
+    __shared__ __attribute__((aligned(16))) uint16_t sA[64 * F16_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[64 * F16_LDS_STRIDE];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1, r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+
+    v4f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = t / 4, 8-half chunk = t % 4) of each 64x32 tile
+    const int srow = t >> 2, sch = t & 3;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+        const int kk = k0 + sch * 8;
+        const int gm = m0 + srow, gn = n0 + srow;
+        if (vec_ok && kk + 8 <= K) {
+            if (gm < M) va = *reinterpret_cast<const uint4*>(A + (size_t)gm * K + kk);
+            if (gn < N) vb = *reinterpret_cast<const uint4*>(BT + (size_t)gn * K + kk);
+        } else {
+            uint16_t ta[8], tb[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                ta[e] = (gm < M && kk + e < K) ? A[(size_t)gm * K + kk + e] : (uint16_t)0;
+                tb[e] = (gn < N && kk + e < K) ? BT[(size_t)gn * K + kk + e] : (uint16_t)0;
+            }
+            va = make_uint4(ta[0] | (uint32_t)ta[1] << 16, ta[2] | (uint32_t)ta[3] << 16,
+                            ta[4] | (uint32_t)ta[5] << 16, ta[6] | (uint32_t)ta[7] << 16);
+            vb = make_uint4(tb[0] | (uint32_t)tb[1] << 16, tb[2] | (uint32_t)tb[3] << 16,
+                            tb[4] | (uint32_t)tb[5] << 16, tb[6] | (uint32_t)tb[7] << 16);
+        }
+        __syncthreads();
+        *reinterpret_cast<uint4*>(sA + srow * F16_LDS_STRIDE + sch * 8) = va;
+        *reinterpret_cast<uint4*>(sB + srow * F16_LDS_STRIDE + sch * 8) = vb;
+        __syncthreads();
+        v8h fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            fa[i] = *reinterpret_cast<const v8h*>(sA + (wm * 32 + i * 16 + r) * F16_LDS_STRIDE + q * 8);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            fb[j] = *reinterpret_cast<const v8h*>(sB + (wn * 32 + j * 16 + r) * F16_LDS_STRIDE + q * 8);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int m = m0 + wm * 32 + i * 16 + q * 4 + e, n = n0 + wn * 32 + j * 16 + r;
+                if (m < M && n < N) C[(size_t)m * N + n] = f2h(acc[i][j][e]);
+            }
+}
+
+hipError_t launch_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K,
+                             size_t N, hipStream_t st) {
+    const int vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(bT) & 15) == 0);
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), block(256);
+    matmul_f16_kernel<<<grid, block, 0, st>>>(a, bT, c, (int)M, (int)K, (int)N, vec_ok);
+    return hipGetLastError();
+}
+
+}  // namespace cactus_hip

@@ -1,0 +1,216 @@
+"""ctypes view of libcactus_hip.so for torch device tensors.
+
+Every function enqueues on torch's current stream and returns without
+synchronising (the *_dev family of include/cactus_hip.h).  Halves are
+torch.float16 tensors; their bits are what the C ABI calls cactus_half_t.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libcactus_hip.so")
+
+if not os.path.exists(SO_PATH):
+    raise ImportError(
+        f"{SO_PATH} is missing: build it with `python -m cactus_amd.build` "
+        "(there is no fallback path)")
+
+lib = C.CDLL(SO_PATH)
+
+_sz, _vp, _i, _f = C.c_size_t, C.c_void_p, C.c_int, C.c_float
+
+SIGNATURES = {
+    "cactus_hip_init": (_i, [_i]),
+    "cactus_hip_device_count": (_i, []),
+    "cactus_hip_last_error": (C.c_char_p, []),
+    "cactus_hip_clear_error": (None, []),
+    "cactus_hip_malloc": (_vp, [_sz]),
+    "cactus_hip_free": (None, [_vp]),
+    "cactus_hip_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "cactus_hip_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "cactus_hip_synchronize": (_i, [_vp]),
+    "cactus_hip_release_weights": (None, [_vp]),
+    "cactus_hip_matmul_int8_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_group_sums_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_group_sums_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp]),
+    "cactus_hip_quantize_activations_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _vp]),
+    "cactus_hip_fp16_max_abs_dev": (_i, [_vp, _sz, _vp, _vp]),
+    "cactus_hip_fp16_to_int8_dev": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "cactus_hip_quantize_kv_fp16_to_int8_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_unpack_int4_to_int8_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "cactus_hip_attention_f16_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _f, _vp,
+                                          _sz, _sz, _i, _vp]),
+    "cactus_hip_attention_hybrid_int8_fp16_dev": (_i, [_vp] * 8 + [_sz] * 7 + [_f, _sz, _i, _sz, _vp]),
+    "cactus_hip_attention_hybrid_int8_fp16_batched_dev": (
+        _i, [_vp] * 8 + [_sz, _sz, _vp, _sz, _sz, _sz, _sz, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8": (None, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz]),
+    "cactus_hip_matmul_int4": (None, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz]),
+    "cactus_hip_matmul_f16": (None, [_vp, _vp, _vp, _sz, _sz, _sz]),
+    "cactus_hip_attention_f16": (None, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _f, _vp, _sz,
+                                        _sz, _i]),
+    "cactus_hip_attention_hybrid_int8_fp16": (None, [_vp] * 8 + [_sz] * 7 + [_f, _sz, _i, _sz]),
+    "cactus_hip_quantize_kv_fp16_to_int8": (None, [_vp, _vp, _vp, _sz, _sz, _sz, _sz]),
+    "cactus_hip_fp16_max_abs": (_f, [_vp, _sz]),
+    "cactus_hip_fp16_to_int8": (None, [_vp, _vp, _sz, _f]),
+    "cactus_hip_unpack_int4_to_int8": (None, [_vp, _vp, _sz]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the library does not export the header's symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class CactusHipError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise CactusHipError(f"cactus_hip error {rc}: {lib.cactus_hip_last_error().decode()}")
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype):
+    assert t.is_cuda and t.is_contiguous() and t.dtype == dtype, (t.device, t.dtype, dtype)
+    return t
+
+
+def init(device=0):
+    _check(lib.cactus_hip_init(device))
+
+
+def quantize_activations(x):
+    """fp16 [M,K] -> (int8 [M,K], fp32 scales [M])."""
+    _dev(x, torch.float16)
+    M, K = x.shape
+    q = torch.empty((M, K), dtype=torch.int8, device=x.device)
+    s = torch.empty((M,), dtype=torch.float32, device=x.device)
+    _check(lib.cactus_hip_quantize_activations_dev(_p(x), _p(q), _p(s), M, K, _stream()))
+    return q, s
+
+
+def matmul_int8(A, A_scales, B, B_scales, group_size=128, out=None):
+    _dev(A, torch.int8); _dev(B, torch.int8); _dev(A_scales, torch.float32); _dev(B_scales, torch.float16)
+    M, K = A.shape
+    N = B.shape[0]
+    Cc = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=A.device)
+    _check(lib.cactus_hip_matmul_int8_dev(_p(A), _p(A_scales), _p(B), _p(B_scales), _p(Cc), M, K, N,
+                                          group_size, _stream()))
+    return Cc
+
+
+def matmul_int4(A, A_scales, B_packed, B_scales, group_size=128, out=None):
+    _dev(A, torch.int8); _dev(B_packed, torch.uint8); _dev(A_scales, torch.float32)
+    _dev(B_scales, torch.float16)
+    M, K = A.shape
+    N = B_packed.shape[0]
+    Cc = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=A.device)
+    _check(lib.cactus_hip_matmul_int4_dev(_p(A), _p(A_scales), _p(B_packed), _p(B_scales), _p(Cc), M, K, N,
+                                          group_size, _stream()))
+    return Cc
+
+
+def matmul_group_sums(A, B, group_size=128, int4=False):
+    M, K = A.shape
+    N = B.shape[0]
+    out = torch.empty((M, N, K // group_size), dtype=torch.int32, device=A.device)
+    fn = lib.cactus_hip_matmul_int4_group_sums_dev if int4 else lib.cactus_hip_matmul_int8_group_sums_dev
+    _check(fn(_p(A), _p(B), _p(out), M, K, N, group_size, _stream()))
+    return out
+
+
+def matmul_f16(a, bT, out=None):
+    _dev(a, torch.float16); _dev(bT, torch.float16)
+    M, K = a.shape
+    N = bT.shape[0]
+    c = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=a.device)
+    _check(lib.cactus_hip_matmul_f16_dev(_p(a), _p(bT), _p(c), M, K, N, _stream()))
+    return c
+
+
+def fp16_max_abs(x):
+    _dev(x, torch.float16)
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    _check(lib.cactus_hip_fp16_max_abs_dev(_p(x), x.numel(), _p(out), _stream()))
+    return out
+
+
+def fp16_to_int8(x, scale):
+    _dev(x, torch.float16)
+    q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
+    _check(lib.cactus_hip_fp16_to_int8_dev(_p(x), _p(q), x.numel(), float(scale), _stream()))
+    return q
+
+
+def quantize_kv(src, group_size=128, out=None, out_scales=None):
+    """fp16 [seq, kv_heads, head_dim] -> (int8 same shape, fp32 [seq, kv_heads, ceil(D/gs)])."""
+    _dev(src, torch.float16)
+    S, H, D = src.shape
+    G = (D + group_size - 1) // group_size
+    q = out if out is not None else torch.empty((S, H, D), dtype=torch.int8, device=src.device)
+    sc = out_scales if out_scales is not None else torch.empty((S, H, G), dtype=torch.float32,
+                                                                device=src.device)
+    _check(lib.cactus_hip_quantize_kv_fp16_to_int8_dev(_p(src), _p(q), _p(sc), S, H, D, group_size,
+                                                       _stream()))
+    return q, sc
+
+
+def unpack_int4(packed, count, out=None):
+    _dev(packed, torch.uint8)
+    o = out if out is not None else torch.zeros((count,), dtype=torch.int8, device=packed.device)
+    _check(lib.cactus_hip_unpack_int4_to_int8_dev(_p(packed), _p(o), count, _stream()))
+    return o
+
+
+def attention_f16(q, k, v, scale, mask=None, position_offset=0, window_size=0, is_causal=True):
+    _dev(q, torch.float16); _dev(k, torch.float16); _dev(v, torch.float16)
+    B, S, Hq, D = q.shape
+    KV, Hkv = k.shape[1], k.shape[2]
+    out = torch.empty_like(q)
+    _check(lib.cactus_hip_attention_f16_dev(_p(q), _p(k), _p(v), _p(out), B, S, KV, Hq, Hkv, D,
+                                            float(scale), _p(mask), position_offset, window_size,
+                                            int(bool(is_causal)), _stream()))
+    return out
+
+
+def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale, position_offset=0,
+                     is_causal=True, group_size=128, cache_len=None):
+    _dev(q, torch.float16)
+    B, S, Hq, D = q.shape
+    new_len, Hkv = k_new.shape[1], k_new.shape[2]
+    if cache_len is None:
+        cache_len = k_cached.shape[-3]
+    out = torch.empty_like(q)
+    _check(lib.cactus_hip_attention_hybrid_int8_fp16_dev(
+        _p(q), _p(k_cached), _p(v_cached), _p(k_scales), _p(v_scales), _p(k_new), _p(v_new), _p(out),
+        B, S, cache_len, new_len, Hq, Hkv, D, float(scale), position_offset, int(bool(is_causal)),
+        group_size, _stream()))
+    return out
+
+
+def attention_hybrid_batched(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale, cache_lens,
+                             position_offsets, group_size=128):
+    """k_cached/v_cached int8 [B, max_cache, Hkv, D]; scales fp32 [B, max_cache, Hkv, G];
+    cache_lens / position_offsets int32 [B]."""
+    B, S, Hq, D = q.shape
+    new_len, Hkv = k_new.shape[1], k_new.shape[2]
+    max_cache = k_cached.shape[1]
+    G = k_scales.shape[-1]
+    out = torch.empty_like(q)
+    _check(lib.cactus_hip_attention_hybrid_int8_fp16_batched_dev(
+        _p(q), _p(k_cached), _p(v_cached), _p(k_scales), _p(v_scales), _p(k_new), _p(v_new), _p(out),
+        B, S, _p(cache_lens), new_len, Hq, Hkv, D, float(scale), _p(position_offsets), group_size,
+        max_cache * Hkv * D, max_cache * Hkv * G, max_cache, _stream()))
+    return out

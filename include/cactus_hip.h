@@ -1,0 +1,193 @@
+/*
+ * cactus_hip.h -- C ABI of the MI355X (gfx950) backend for Cactus's quantized
+ * hot path: grouped INT8/INT4 weight matmul, FP16 matmul, activation / KV
+ * quantization and attention over the INT8 KV cache.
+ *
+ * Each entry point replaces one free function of the reference's kernel ABI
+ * (cactus/kernel/kernel.h); the line it replaces is cited beside it.  Halves
+ * are IEEE binary16 bit patterns (uint16_t) so the header is plain C.
+ *
+ * Two families:
+ *   cactus_hip_<op>_dev(...)  operands are DEVICE pointers already resident in
+ *                             HBM; work is enqueued on `stream` (a hipStream_t,
+ *                             or NULL for the library's own stream) and the call
+ *                             returns without synchronising.  This is the hot
+ *                             path.
+ *   cactus_hip_<op>(...)      operands are HOST pointers with exactly the
+ *                             reference's signature; results are complete on
+ *                             return (the reference's contract).  Weight and
+ *                             weight-scale pointers are uploaded once and cached
+ *                             by address (they are mmap'd file regions that live
+ *                             as long as the graph: graph_io.cpp:43-45), every
+ *                             other operand is staged per call.
+ *
+ * Errors: the reference kernels return void and cannot fail.  The *_dev family
+ * returns 0 or a negative CACTUS_HIP_E* code; the host family records the
+ * failure, readable with cactus_hip_last_error(), so that the graph layer can
+ * throw (graph_ops_nn.cpp's std::runtime_error convention).
+ */
+#ifndef CACTUS_HIP_H
+#define CACTUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t cactus_half_t;
+
+#define CACTUS_HIP_OK            0
+#define CACTUS_HIP_EINVAL       -1   /* shape/argument the kernels do not accept */
+#define CACTUS_HIP_ERUNTIME     -2   /* a HIP runtime call failed */
+#define CACTUS_HIP_ENOMEM       -3   /* device allocation failed */
+
+/* KV quantization group (cactus/kernel/kernel.h:18). */
+#define CACTUS_KV_QUANT_GROUP_SIZE 128
+
+/* ---------------------------------------------------------------- runtime */
+
+/* Select the device this thread's calls run on and create the library stream. */
+int  cactus_hip_init(int device);
+int  cactus_hip_device_count(void);
+const char* cactus_hip_last_error(void);
+void cactus_hip_clear_error(void);
+
+void* cactus_hip_malloc(size_t bytes);
+void  cactus_hip_free(void* dptr);
+int   cactus_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int   cactus_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int   cactus_hip_synchronize(void* stream);
+
+/* Host-pointer family: drop cached device copies of weights (all, or the one
+ * registered under host_ptr). */
+void cactus_hip_release_weights(const void* host_ptr);
+
+/* ------------------------------------------------- device-resident hot path */
+
+/* cactus_matmul_int8 (kernel.h:41-43; kernel_gemm.cpp:128-327).
+ * C[m,n] = fp16( A_scales[m] * sum_g float(sum_{k in g} A[m,k]*B[n,k]) * B_scales[n,g] )
+ * A int8[M,K], B int8[N,K] (K contiguous), B_scales half[N, K/group_size], C half[M,N].
+ * K/group_size whole groups are used, a K tail is ignored as in the reference. */
+int cactus_hip_matmul_int8_dev(const int8_t* A, const float* A_scales,
+                               const int8_t* B, const cactus_half_t* B_scales,
+                               cactus_half_t* C, size_t M, size_t K, size_t N,
+                               size_t group_size, void* stream);
+
+/* cactus_matmul_int4 (kernel.h:45-47; kernel_gemm.cpp:329-529).  B_packed
+ * uint8[N, K/2]: byte j of a row holds element 2j in its low nibble and 2j+1 in
+ * its high nibble, two's-complement 4-bit (kernel_utils.h:165-185). */
+int cactus_hip_matmul_int4_dev(const int8_t* A, const float* A_scales,
+                               const uint8_t* B_packed, const cactus_half_t* B_scales,
+                               cactus_half_t* C, size_t M, size_t K, size_t N,
+                               size_t group_size, void* stream);
+
+/* The exact INT32 group sums [M, N, K/group_size] of the two kernels above
+ * (kernel_gemm.cpp:173, 404: group_acc), for bit-exact parity checks. */
+int cactus_hip_matmul_int8_group_sums_dev(const int8_t* A, const int8_t* B, int32_t* sums,
+                                          size_t M, size_t K, size_t N, size_t group_size,
+                                          void* stream);
+int cactus_hip_matmul_int4_group_sums_dev(const int8_t* A, const uint8_t* B_packed, int32_t* sums,
+                                          size_t M, size_t K, size_t N, size_t group_size,
+                                          void* stream);
+
+/* cactus_matmul_f16 (kernel.h:49-50; kernel_gemm.cpp:102-126): C = A * B^T,
+ * a half[M,K], b_transposed half[N,K].  Accumulates in fp32 (the reference
+ * accumulates in fp16 lanes), so it is compared by tolerance. */
+int cactus_hip_matmul_f16_dev(const cactus_half_t* a, const cactus_half_t* b_transposed,
+                              cactus_half_t* c, size_t M, size_t K, size_t N, void* stream);
+
+/* quantize_activations_fp16_to_int8 (graph_ops_nn.cpp:35-66): per row
+ * scale = max(absmax/127, 1e-10), q = sat8(rne(clamp(x * (1/scale)))). */
+int cactus_hip_quantize_activations_dev(const cactus_half_t* src, int8_t* dst, float* scales,
+                                        size_t M, size_t K, void* stream);
+
+/* cactus_fp16_max_abs (kernel.h:149); result written to *out_dev (device float). */
+int cactus_hip_fp16_max_abs_dev(const cactus_half_t* src, size_t count, float* out_dev,
+                                void* stream);
+/* cactus_fp16_to_int8 (kernel.h:148; kernel_quants.cpp:158-194). */
+int cactus_hip_fp16_to_int8_dev(const cactus_half_t* src, int8_t* dst, size_t count, float scale,
+                                void* stream);
+
+/* cactus_quantize_kv_fp16_to_int8 (kernel.h:151-156; kernel_quants.cpp:266-293).
+ * src half[seq,kv_heads,head_dim] -> dst int8 same shape, scales float[seq,kv_heads,ceil(D/gs)]. */
+int cactus_hip_quantize_kv_fp16_to_int8_dev(const cactus_half_t* src, int8_t* dst, float* scales,
+                                            size_t seq_len, size_t kv_heads, size_t head_dim,
+                                            size_t group_size, void* stream);
+
+/* cactus_unpack_int4_to_int8 (kernel.h:163; kernel_quants.cpp:295-351). */
+int cactus_hip_unpack_int4_to_int8_dev(const uint8_t* packed, int8_t* unpacked,
+                                       size_t unpacked_count, void* stream);
+
+/* cactus_attention_f16 (kernel.h:87-90; kernel_attention.cpp:10-255).
+ * Q half[B,S,Hq,D], K/V half[B,KV,Hkv,D], O half[B,S,Hq,D]; mask half[B,S,KV]
+ * (0 = masked) or NULL.  scale 0 means 1/sqrt(D). */
+int cactus_hip_attention_f16_dev(const cactus_half_t* queries, const cactus_half_t* keys,
+                                 const cactus_half_t* values, cactus_half_t* output,
+                                 size_t batch_size, size_t seq_len, size_t kv_seq_len,
+                                 size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+                                 float scale, const cactus_half_t* mask, size_t position_offset,
+                                 size_t window_size, int is_causal, void* stream);
+
+/* cactus_attention_hybrid_int8_fp16 (kernel.h:92-104; kernel_attention.cpp:257-482).
+ * Cached K/V int8[B, cache_len, Hkv, D] with scales float[cache_len, Hkv, ceil(D/gs)]
+ * (the reference indexes scales WITHOUT a batch stride, kernel_attention.cpp:353,425;
+ * so does this entry point), new K/V half[B,new_len,Hkv,D]. */
+int cactus_hip_attention_hybrid_int8_fp16_dev(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales,
+    const cactus_half_t* keys_new, const cactus_half_t* values_new, cactus_half_t* output,
+    size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+    float scale, size_t position_offset, int is_causal, size_t group_size, void* stream);
+
+/* Batched-decode form of the same kernel for independent sequences (one per
+ * batch row): per-sequence cache length and position offset, and cache/scales
+ * addressed with explicit per-sequence strides (in elements).  Has no
+ * counterpart in the reference, whose engine is batch-1 (model_qwen.cpp:74-76);
+ * with one sequence it computes exactly what the entry point above computes. */
+int cactus_hip_attention_hybrid_int8_fp16_batched_dev(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales,
+    const cactus_half_t* keys_new, const cactus_half_t* values_new, cactus_half_t* output,
+    size_t batch_size, size_t seq_len, const int32_t* cache_lens, size_t new_len,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+    float scale, const int32_t* position_offsets, size_t group_size,
+    size_t cache_batch_stride, size_t scale_batch_stride, size_t max_cache_len, void* stream);
+
+/* ------------------------------------------------ host-pointer drop-in family
+ * Same argument lists as cactus/kernel/kernel.h, host memory in and out.      */
+
+void  cactus_hip_matmul_int8(const int8_t* A, const float* A_scales,
+                             const int8_t* B, const cactus_half_t* B_scales,
+                             cactus_half_t* C, size_t M, size_t K, size_t N, size_t group_size);
+void  cactus_hip_matmul_int4(const int8_t* A, const float* A_scales,
+                             const uint8_t* B_packed, const cactus_half_t* B_scales,
+                             cactus_half_t* C, size_t M, size_t K, size_t N, size_t group_size);
+void  cactus_hip_matmul_f16(const cactus_half_t* a, const cactus_half_t* b_transposed,
+                            cactus_half_t* c, size_t M, size_t K, size_t N);
+void  cactus_hip_attention_f16(const cactus_half_t* queries, const cactus_half_t* keys,
+                               const cactus_half_t* values, cactus_half_t* output,
+                               size_t batch_size, size_t seq_len, size_t kv_seq_len,
+                               size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+                               float scale, const cactus_half_t* mask, size_t position_offset,
+                               size_t window_size, int is_causal);
+void  cactus_hip_attention_hybrid_int8_fp16(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales,
+    const cactus_half_t* keys_new, const cactus_half_t* values_new, cactus_half_t* output,
+    size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+    float scale, size_t position_offset, int is_causal, size_t group_size);
+void  cactus_hip_quantize_kv_fp16_to_int8(const cactus_half_t* src, int8_t* dst, float* scales,
+                                          size_t seq_len, size_t kv_heads, size_t head_dim,
+                                          size_t group_size);
+float cactus_hip_fp16_max_abs(const cactus_half_t* src, size_t count);
+void  cactus_hip_fp16_to_int8(const cactus_half_t* src, int8_t* dst, size_t count, float scale);
+void  cactus_hip_unpack_int4_to_int8(const uint8_t* packed, int8_t* unpacked, size_t unpacked_count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CACTUS_HIP_H */

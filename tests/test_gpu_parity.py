@@ -1,0 +1,401 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (cactus_amd.hip -> libcactus_hip.so),
+against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for integer / byte / index work (quantized values, scales, INT32 group sums, INT4
+unpack) and -- because the kernels keep the reference's fp32 operation order -- bit-exact fp16
+outputs for the quantized matmuls too.  Attention and the FP16 matmul are floating-point kernels
+with a different summation order and are held to the tolerances written in each test.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import (parse_cact, f16, rand_weights_int8, rand_weights_int4, rand_act_f16,
+                           ulp_diff_f16)
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def H():
+    import cactus_amd.hip as hip
+    hip.init(0)
+    return hip
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def bits(t):
+    return t.cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+# ------------------------------------------------------------------ quantization
+@pytest.mark.parametrize("M,K", [(1, 1024), (3, 3072), (16, 4096), (5, 264), (2, 100), (1, 12288), (40, 128)])
+def test_quantize_activations_bit_exact(H, M, K):
+    rng = np.random.default_rng(M * 1000 + K)
+    x = rand_act_f16(rng, M, K)
+    if M > 1:
+        x[1] = 0                       # all-zero row: scale floor 1e-10
+    x[0, :8] = np.array([0.25, -0.25, 0.125, 0.375, -0.375, 0.5, -0.5, 1.0], np.float16)  # ties
+    q, s = H.quantize_activations(dev(x))
+    oq, os_ = O.quantize_activations(x)
+    assert (host(s).view(np.uint32) == os_.view(np.uint32)).all()
+    assert (host(q) == oq).all()
+
+
+def test_quantize_activations_ties_to_even(H):
+    # scale = 2^-9 exactly (absmax 127*2^-9): x*inv lands on .5 ties
+    K = 256
+    x = (np.arange(K, dtype=np.float32) - 128) * 2.0 ** -10
+    x[0] = 127 * 2.0 ** -9
+    x = x.astype(np.float16).reshape(1, K)
+    q, s = H.quantize_activations(dev(x))
+    oq, os_ = O.quantize_activations(x)
+    assert float(os_[0]) == 2.0 ** -9
+    assert (host(q) == oq).all() and (host(s) == os_).all()
+
+
+@pytest.mark.parametrize("count", [8, 12, 1000, 1003])
+def test_fp16_to_int8_and_max_abs(H, count):
+    rng = np.random.default_rng(count)
+    x = rng.uniform(-3, 3, count).astype(np.float16)
+    x[:4] = np.array([0.5, 1.5, 2.5, -2.5], np.float16)
+    x[-4:] = np.array([0.5, 1.5, 2.5, -2.5], np.float16)   # tail elements round half away
+    got = host(H.fp16_to_int8(dev(x), 1.0))
+    assert (got == O.fp16_to_int8(x, 1.0)).all()
+    got = host(H.fp16_to_int8(dev(x), 0.02))
+    assert (got == O.fp16_to_int8(x, 0.02)).all()
+    assert float(host(H.fp16_max_abs(dev(x)))[0]) == O.fp16_max_abs(x)
+
+
+@pytest.mark.parametrize("S,Hk,D,gs", [(1, 8, 128, 128), (256, 8, 128, 128), (7, 1, 256, 128), (5, 8, 64, 128),
+                                       (3, 2, 72, 128), (3, 2, 132, 128), (4, 2, 128, 64), (2, 3, 20, 128)])
+def test_quantize_kv_bit_exact(H, S, Hk, D, gs):
+    rng = np.random.default_rng(S * 100 + D)
+    x = rng.uniform(-2, 2, (S, Hk, D)).astype(np.float16)
+    x[0, 0, :] = 0
+    q, s = H.quantize_kv(dev(x), gs)
+    oq, os_ = O.quantize_kv(x, gs)
+    assert (host(s).view(np.uint32) == os_.view(np.uint32)).all()
+    assert (host(q) == oq).all()
+
+
+@pytest.mark.parametrize("count", [32, 64, 1000, 4096, 33, 95, 511])
+def test_unpack_int4_bit_exact(H, count):
+    rng = np.random.default_rng(count)
+    packed = rng.integers(0, 256, (count + 1) // 2, dtype=np.uint8)
+    got = host(H.unpack_int4(dev(packed), count))
+    assert (got == O.unpack_int4(packed, count)).all()
+
+
+# ------------------------------------------------------------------ quantized matmul
+SHAPES = [
+    # M, K, N
+    (1, 1024, 1024), (1, 3072, 1000), (2, 4096, 48), (5, 256, 13), (16, 1024, 2048), (8, 8192, 64),
+    (1, 5120, 16), (3, 128, 7),                                      # skinny path (M <= 16)
+    (17, 1024, 256), (64, 512, 130), (200, 1024, 384), (256, 3072, 128),   # LDS/MFMA tile path
+]
+
+
+def _check_matmul(H, M, K, N, gs, int4, seed):
+    rng = np.random.default_rng(seed)
+    B, Bs = (rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K, gs)
+    A16 = rand_act_f16(rng, M, K)
+    A, As = O.quantize_activations(A16)
+    ofn = O.matmul_int4 if int4 else O.matmul_int8
+    oc, og = ofn(A, As, B, Bs, gs, True)
+    dA, dAs, dB, dBs = dev(A), dev(As), dev(B), dev(Bs)
+    g = host(H.matmul_group_sums(dA, dB, gs, int4=int4))
+    assert (g == og).all(), "INT32 group sums differ"
+    c = bits((H.matmul_int4 if int4 else H.matmul_int8)(dA, dAs, dB, dBs, gs))
+    assert (c == oc).all(), f"fp16 outputs differ, max ulp {ulp_diff_f16(c, oc).max()}"
+    # against the non-contracted evaluation of the same statements: FP16 tolerance
+    O.set_fma(0)
+    oc2 = ofn(A, As, B, Bs, gs)
+    O.set_fma(1)
+    ref = f16(oc2)
+    assert np.abs(f16(c) - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())
+    assert ulp_diff_f16(c, oc2).max() <= 1
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_matmul_int8_bit_exact(H, M, K, N):
+    _check_matmul(H, M, K, N, 128, False, M + K + N)
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_matmul_int4_bit_exact(H, M, K, N):
+    _check_matmul(H, M, K, N, 128, True, M + K + N + 1)
+
+
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,N,gs", [(2, 128, 4, 64), (3, 256, 9, 64), (2, 512, 5, 256), (1, 192, 3, 128)])
+def test_matmul_other_group_sizes(H, M, K, N, gs, int4):
+    """group 64 is what the reference's own tests use (tests/test_kernel.cpp:217); K = 192 with
+    group 128 has a dropped K tail (kernel_gemm.cpp:147)."""
+    _check_matmul(H, M, K, N, gs, int4, 77)
+
+
+def test_matmul_zero_sized(H):
+    A = torch.zeros((0, 128), dtype=torch.int8, device="cuda")
+    As = torch.zeros((0,), dtype=torch.float32, device="cuda")
+    B = torch.zeros((4, 128), dtype=torch.int8, device="cuda")
+    Bs = torch.ones((4, 1), dtype=torch.float16, device="cuda")
+    assert H.matmul_int8(A, As, B, Bs).shape == (0, 4)
+
+
+@pytest.mark.parametrize("name", ["tensor_io_a.npz", "tensor_io_b.npz", "tensor_io_pad.npz"])
+def test_matmul_on_reference_written_weights(H, name):
+    """Weights quantized and written by the reference's tensor_io.py (committed fixture):
+    packed INT4 straight from the file == INT8 on unpacked values == oracle."""
+    z = np.load(os.path.join(GOLD, name))
+    rng = np.random.default_rng(9)
+    for key, int4 in (("file_int8", False), ("file_int4", True)):
+        f = parse_cact(z[key])
+        N, K = f["shape"]
+        A, As = O.quantize_activations(rand_act_f16(rng, 4, K))
+        Bs = f["scales"].view(np.float16).reshape(N, K // 128)
+        if int4:
+            Bp = f["data"].reshape(N, K // 2)
+            c = bits(H.matmul_int4(dev(A), dev(As), dev(Bp), dev(Bs)))
+            assert (c == O.matmul_int4(A, As, Bp, Bs, 128)).all()
+            un = host(H.unpack_int4(dev(f["data"]), N * K)).reshape(N, K)
+            c8 = bits(H.matmul_int8(dev(A), dev(As), dev(un), dev(Bs)))
+            assert (c8 == c).all()
+        else:
+            Bq = f["data"].view(np.int8).reshape(N, K)
+            c = bits(H.matmul_int8(dev(A), dev(As), dev(Bq), dev(Bs)))
+            assert (c == O.matmul_int8(A, As, Bq, Bs, 128)).all()
+
+
+def test_matmul_full_size_properties(H):
+    """BASELINE sweep's largest shape (K = N = 8192), too big for the scalar oracle to be the
+    only check: size-independent properties instead.
+      * INT32 group sums are linear in A (exact integers);
+      * packed INT4 == INT8 on the unpacked nibbles, bit for bit;
+      * the M<=16 streaming kernel and the LDS-tiled kernel give identical bits;
+      * a sampled set of rows against the oracle."""
+    K = N = 8192
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda", generator=g)
+    Bs = (0.01 + torch.rand((N, K // 128), device="cuda", generator=g) * 0.05).half()
+    A1 = torch.randint(-60, 61, (16, K), dtype=torch.int8, device="cuda", generator=g)
+    A2 = torch.randint(-60, 61, (16, K), dtype=torch.int8, device="cuda", generator=g)
+    s1 = H.matmul_group_sums(A1, B)
+    s2 = H.matmul_group_sums(A2, B)
+    s12 = H.matmul_group_sums((A1 + A2), B)
+    assert torch.equal(s1 + s2, s12)
+    As = torch.rand((16,), device="cuda", generator=g) * 0.01
+    c16 = H.matmul_int8(A1, As, B, Bs)
+    A17 = torch.cat([A1, A2[:1]]); As17 = torch.cat([As, As[:1]])
+    c17 = H.matmul_int8(A17, As17, B, Bs)            # tiled kernel
+    assert torch.equal(c16.view(torch.int16), c17[:16].view(torch.int16))
+    c1 = H.matmul_int8(A1[:1].contiguous(), As[:1].contiguous(), B, Bs)   # M = 1
+    assert torch.equal(c1.view(torch.int16), c16[:1].view(torch.int16))
+    # INT4: pack random nibbles, compare with INT8 on the unpacked values
+    Bp = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device="cuda", generator=g)
+    Bu = H.unpack_int4(Bp.view(-1), N * K).view(N, K)
+    assert torch.equal(H.matmul_int4(A1, As, Bp, Bs).view(torch.int16),
+                       H.matmul_int8(A1, As, Bu, Bs).view(torch.int16))
+    # sampled rows against the oracle
+    rows = np.array([0, 1, 17, 4095, 8191])
+    oc = O.matmul_int8(host(A1), host(As), host(B[rows]), bits(Bs[rows]), 128)
+    assert (bits(c16[:, rows].contiguous()) == oc).all()
+
+
+def test_host_pointer_family_matches_device_family(H):
+    rng = np.random.default_rng(5)
+    M, K, N = 3, 1024, 256
+    B, Bs = rand_weights_int8(rng, N, K)
+    A, As = O.quantize_activations(rand_act_f16(rng, M, K))
+    Cc = np.zeros((M, N), np.uint16)
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    H.lib.cactus_hip_clear_error()
+    for _ in range(2):   # second call hits the resident-weight cache
+        H.lib.cactus_hip_matmul_int8(p(A), p(As), p(B), p(Bs), p(Cc), M, K, N, 128)
+    assert H.lib.cactus_hip_last_error() == b""
+    assert (Cc == O.matmul_int8(A, As, B, Bs, 128)).all()
+    x = rand_act_f16(rng, 1, 1000)
+    assert H.lib.cactus_hip_fp16_max_abs(p(x), x.size) == O.fp16_max_abs(x)
+    kv = rng.uniform(-2, 2, (3, 2, 128)).astype(np.float16)
+    q = np.zeros(kv.shape, np.int8); s = np.zeros((3, 2, 1), np.float32)
+    H.lib.cactus_hip_quantize_kv_fp16_to_int8(p(kv), p(q), p(s), 3, 2, 128, 128)
+    oq, os_ = O.quantize_kv(kv)
+    assert (q == oq).all() and (s == os_).all()
+    H.lib.cactus_hip_release_weights(None)
+
+
+# ------------------------------------------------------------------ FP16 matmul
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 64), (4, 100, 33), (70, 256, 130), (2, 3, 2), (256, 1024, 256)])
+def test_matmul_f16_tolerance(H, M, K, N):
+    """fp32-accumulating MFMA vs the reference's fp16-lane accumulation: both are compared with
+    the fp64 product; the GPU error must not exceed the reference's own error (+1 fp16 ulp)."""
+    rng = np.random.default_rng(M + K + N)
+    a = rng.uniform(-1, 1, (M, K)).astype(np.float16)
+    b = rng.uniform(-1, 1, (N, K)).astype(np.float16)
+    got = f16(bits(H.matmul_f16(dev(a), dev(b))))
+    exact = a.astype(np.float64) @ b.astype(np.float64).T
+    ref_err = np.abs(f16(O.matmul_f16(a, b)) - exact).max()
+    ulp = np.abs(exact).max() * 2.0 ** -10
+    assert np.abs(got - exact).max() <= max(ref_err, 0.0) + ulp
+
+
+def test_matmul_f16_reference_kat(H):
+    a = np.array([[1, 2, 3], [4, 5, 6]], np.float16)
+    b = np.array([[1, 2], [3, 4], [5, 6]], np.float16)
+    got = host(H.matmul_f16(dev(a), dev(np.ascontiguousarray(b.T))))
+    assert (got == np.array([[22, 28], [49, 64]], np.float16)).all()
+
+
+# ------------------------------------------------------------------ attention
+def _hybrid_case(rng, B, S, Hq, Hkv, D, cache, new, gs=128):
+    q = rng.uniform(-1, 1, (B, S, Hq, D)).astype(np.float16)
+    kq, ks = O.quantize_kv(rng.uniform(-2, 2, (cache, Hkv, D)).astype(np.float16), gs)
+    vq, vs = O.quantize_kv(rng.uniform(-2, 2, (cache, Hkv, D)).astype(np.float16), gs)
+    kq = np.broadcast_to(kq, (B,) + kq.shape).copy()
+    vq = np.broadcast_to(vq, (B,) + vq.shape).copy()
+    if B > 1:   # different cache content per batch row (scales are shared: reference quirk)
+        kq[1:] = rng.integers(-127, 128, kq[1:].shape, dtype=np.int8)
+    kn = rng.uniform(-2, 2, (B, new, Hkv, D)).astype(np.float16)
+    vn = rng.uniform(-2, 2, (B, new, Hkv, D)).astype(np.float16)
+    return q, kq, vq, ks, vs, kn, vn
+
+
+HYBRID = [
+    # B, S, Hq, Hkv, D, cache, new, offset(None -> cache)
+    (1, 1, 16, 8, 128, 512, 1, None),     # Qwen3-0.6B decode
+    (1, 1, 16, 8, 128, 70, 1, None),
+    (1, 1, 4, 1, 256, 100, 1, None),      # Gemma-3-270m heads
+    (1, 1, 32, 8, 64, 333, 1, None),      # LFM2-1.2B heads
+    (1, 1, 32, 8, 128, 4096, 1, None),    # long context, split-KV path
+    (1, 5, 4, 2, 128, 70, 5, None),       # prefill chunk over a cache
+    (1, 37, 4, 2, 64, 33, 37, None),
+    (1, 4, 4, 2, 128, 0, 4, 0),           # empty cache
+    (2, 3, 6, 2, 128, 40, 3, None),       # GQA ratio 3
+    (1, 3, 4, 4, 72, 21, 3, None),        # head_dim not a multiple of 16
+    (1, 2, 2, 2, 128, 64, 2, 700),        # window has slid: offset > cache_len (no masking inside chunk)
+    (1, 4, 2, 1, 128, 50, 4, 10),         # offset < cache_len: causal cut inside the cache
+]
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,cache,new,off", HYBRID)
+def test_attention_hybrid_vs_oracle(H, B, S, Hq, Hkv, D, cache, new, off):
+    """fp32 softmax with a different summation order and __expf: |diff| <= 2e-3 + 4e-3*|ref|
+    (2e-3 is about 2 fp16 ulps at 1.0; outputs here have magnitude <= 2)."""
+    rng = np.random.default_rng(B * 7 + S + D + cache)
+    q, kq, vq, ks, vs, kn, vn = _hybrid_case(rng, B, S, Hq, Hkv, D, cache, new)
+    off = cache if off is None else off
+    want = O.attention_hybrid(q, kq, vq, ks, vs, kn, vn, 0.0, position_offset=off, cache_len=cache)
+    got = bits(H.attention_hybrid(dev(q), dev(kq), dev(vq), dev(ks), dev(vs), dev(kn), dev(vn), 0.0,
+                                  position_offset=off, cache_len=cache))
+    d = np.abs(f16(got) - f16(want))
+    assert (d <= 2e-3 + 4e-3 * np.abs(f16(want))).all(), d.max()
+
+
+def test_attention_hybrid_noncausal_and_scale(H):
+    rng = np.random.default_rng(3)
+    q, kq, vq, ks, vs, kn, vn = _hybrid_case(rng, 1, 3, 4, 2, 128, 45, 3)
+    for causal, scale in ((False, 0.0), (True, 0.05)):
+        want = O.attention_hybrid(q, kq, vq, ks, vs, kn, vn, scale, position_offset=45, is_causal=causal)
+        got = bits(H.attention_hybrid(dev(q), dev(kq), dev(vq), dev(ks), dev(vs), dev(kn), dev(vn), scale,
+                                      position_offset=45, is_causal=causal))
+        assert np.abs(f16(got) - f16(want)).max() <= 2e-3
+
+
+def test_attention_hybrid_batched_matches_single(H):
+    """The batched-decode entry point on sequences of different lengths == one call per sequence."""
+    rng = np.random.default_rng(8)
+    Bn, Hq, Hkv, D, maxc = 3, 16, 8, 128, 96
+    lens = np.array([96, 10, 57], np.int32)
+    q = rng.uniform(-1, 1, (Bn, 1, Hq, D)).astype(np.float16)
+    kn = rng.uniform(-2, 2, (Bn, 1, Hkv, D)).astype(np.float16)
+    vn = rng.uniform(-2, 2, (Bn, 1, Hkv, D)).astype(np.float16)
+    kq = np.zeros((Bn, maxc, Hkv, D), np.int8); vq = np.zeros_like(kq)
+    ks = np.ones((Bn, maxc, Hkv, 1), np.float32); vs = np.ones_like(ks)
+    for b in range(Bn):
+        a, s_ = O.quantize_kv(rng.uniform(-2, 2, (lens[b], Hkv, D)).astype(np.float16))
+        kq[b, :lens[b]] = a; ks[b, :lens[b]] = s_
+        a, s_ = O.quantize_kv(rng.uniform(-2, 2, (lens[b], Hkv, D)).astype(np.float16))
+        vq[b, :lens[b]] = a; vs[b, :lens[b]] = s_
+    got = bits(H.attention_hybrid_batched(dev(q), dev(kq), dev(vq), dev(ks), dev(vs), dev(kn), dev(vn), 0.0,
+                                          dev(lens), dev(lens)))
+    for b in range(Bn):
+        L = int(lens[b])
+        want = O.attention_hybrid(q[b:b + 1], kq[b, :L], vq[b, :L], ks[b, :L], vs[b, :L], kn[b:b + 1],
+                                  vn[b:b + 1], 0.0, position_offset=L, cache_len=L)
+        assert np.abs(f16(got[b:b + 1]) - f16(want)).max() <= 2e-3
+
+
+F16ATT = [
+    # B, S, KV, Hq, Hkv, D, offset, window, causal, mask
+    (1, 64, 64, 4, 2, 64, 0, 0, True, False),
+    (2, 37, 37, 4, 2, 128, 0, 0, True, False),
+    (1, 256, 256, 16, 8, 128, 0, 0, True, False),    # Qwen3 prefill chunk 0
+    (1, 40, 40, 4, 1, 256, 0, 16, True, False),      # Gemma local layer window
+    (1, 9, 50, 2, 2, 64, 41, 0, True, False),        # offset
+    (1, 7, 30, 4, 4, 64, 0, 0, False, False),        # non-causal (encoders)
+    (1, 6, 35, 2, 1, 64, 0, 0, False, True),         # explicit mask
+    (1, 1, 131, 4, 2, 128, 130, 0, True, False),     # single query, kv tail of 3 uses expf
+]
+
+
+@pytest.mark.parametrize("B,S,KV,Hq,Hkv,D,off,win,causal,use_mask", F16ATT)
+def test_attention_f16_vs_oracle(H, B, S, KV, Hq, Hkv, D, off, win, causal, use_mask):
+    """Same per-block polynomial weights as the reference; only fp32 summation order and
+    expf-vs-__expf differ: |diff| <= 2e-3 + 4e-3*|ref|."""
+    rng = np.random.default_rng(S * 3 + KV + D)
+    q = rng.uniform(-1, 1, (B, S, Hq, D)).astype(np.float16)
+    k = rng.uniform(-1, 1, (B, KV, Hkv, D)).astype(np.float16)
+    v = rng.uniform(-1, 1, (B, KV, Hkv, D)).astype(np.float16)
+    mask = None
+    if use_mask:
+        mask = (rng.random((B, S, KV)) > 0.3).astype(np.float16)
+        mask[:, :, 0] = 1
+    want = O.attention_f16(q, k, v, 0.0, mask=mask, position_offset=off, window_size=win, is_causal=causal)
+    got = bits(H.attention_f16(dev(q), dev(k), dev(v), 0.0, mask=None if mask is None else dev(mask),
+                               position_offset=off, window_size=win, is_causal=causal))
+    d = np.abs(f16(got) - f16(want))
+    assert (d <= 2e-3 + 4e-3 * np.abs(f16(want))).all(), d.max()
+
+
+def test_attention_long_context_properties(H):
+    """32k-token INT8 cache (config 5 shape: Hq 32, Hkv 8, D 128): the oracle is too slow for the
+    whole thing, so (a) all 32 heads against the oracle on 2 of the 8 kv heads, and (b) the
+    property that duplicating the cache (K,V repeated twice) leaves the output unchanged when
+    the new token is masked out of neither copy."""
+    rng = np.random.default_rng(11)
+    cache, Hq, Hkv, D = 32768, 32, 8, 128
+    q = rng.uniform(-1, 1, (1, 1, Hq, D)).astype(np.float16)
+    k16 = torch.empty((cache, Hkv, D), device="cuda").uniform_(-2, 2).half()
+    v16 = torch.empty((cache, Hkv, D), device="cuda").uniform_(-2, 2).half()
+    kq, ks = H.quantize_kv(k16); vq, vs = H.quantize_kv(v16)
+    kn = rng.uniform(-2, 2, (1, 1, Hkv, D)).astype(np.float16)
+    vn = rng.uniform(-2, 2, (1, 1, Hkv, D)).astype(np.float16)
+    got = bits(H.attention_hybrid(dev(q), kq, vq, ks, vs, dev(kn), dev(vn), 0.0, position_offset=cache))
+    # (a) kv heads 0 and 5 -> q heads 0-3 and 20-23
+    for kvh in (0, 5):
+        sl = slice(kvh, kvh + 1)
+        want = O.attention_hybrid(q[:, :, kvh * 4:(kvh + 1) * 4], host(kq[:, sl]), host(vq[:, sl]),
+                                  host(ks[:, sl]), host(vs[:, sl]), kn[:, :, sl], vn[:, :, sl], 0.0,
+                                  position_offset=cache)
+        assert np.abs(f16(got[:, :, kvh * 4:(kvh + 1) * 4]) - f16(want)).max() <= 2e-3
+    # (b) softmax over two copies of the same keys == over one copy (new token excluded: new_len 0)
+    empty = torch.empty((1, 0, Hkv, D), dtype=torch.float16, device="cuda")
+    one = H.attention_hybrid(dev(q), kq[:8192].contiguous(), vq[:8192].contiguous(), ks[:8192].contiguous(),
+                             vs[:8192].contiguous(), empty, empty, 0.0, is_causal=False)
+    two = H.attention_hybrid(dev(q), torch.cat([kq[:8192]] * 2), torch.cat([vq[:8192]] * 2),
+                             torch.cat([ks[:8192]] * 2), torch.cat([vs[:8192]] * 2), empty, empty, 0.0,
+                             is_causal=False)
+    assert np.abs(f16(bits(one)) - f16(bits(two))).max() <= 1e-3
