@@ -87,7 +87,7 @@ int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const c
     const bool tiled_ok = gs == 128 && (K % 128) == 0 && aligned(A, 16) && aligned(B, 16) &&
                           K < (size_t(1) << 30) && N < (size_t(1) << 30);
     hipError_t e;
-    if (tiled_ok && M <= 16)
+    if (tiled_ok && M <= 16 && (!int4 || K % 256 == 0))
         e = launch_matmul_skinny(int4, A, As, B, Bs, C, gsums, M, K, N, S(stream));
     else if (tiled_ok)
         e = launch_matmul_gemm(int4, A, As, B, Bs, C, gsums, M, K, N, S(stream));

@@ -25,6 +25,12 @@ hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scale
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                                 size_t K, size_t N, hipStream_t st);
 
+extern int g_skinny_ablate;
+// Benchmark hook: variant = waves_per_workgroup*100 + ring_depth (0 = the default choice).
+hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A, const float* A_scales,
+                                        const void* B, const uint16_t* B_scales, uint16_t* C, int32_t* gsums,
+                                        size_t M, size_t K, size_t N, hipStream_t st);
+
 // matmul_gemm.hip: any M, group_size == 128, MFMA tiles staged through LDS.
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
                               const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,

@@ -3,181 +3,366 @@
 // Roofline: HBM.  Algorithmic bytes per call = N*K (INT8) or N*K/2 (INT4) weight bytes
 // + 2*N*K/128 scale bytes + M*K + 4*M activation bytes + 2*M*N output bytes.
 //
-// Layout.  One workgroup (8 waves) owns 16 consecutive weight rows n0..n0+15 and walks K in
-// chunks of 32 groups (4096 values).  Inside a chunk wave w takes groups w, w+8, w+16, w+24,
-// so the 8 waves stream disjoint 128-value slices of the same 16 rows: every dwordx4 load of
-// a wave covers 16 rows x 64 contiguous bytes and goes straight to VGPRs (no LDS round trip:
-// nothing is shared between waves).  The INT32 dot products come from
-// v_mfma_i32_16x16x64_i8 with the activations as the row operand (rows m >= M are zero) and
-// the 16 weight rows as the column operand; two MFMAs cover one 128-wide group, which makes
-// the group sum exact and does the cross-lane reduction for free.  INT4 weights stay packed
-// in HBM: one 16-byte load holds 32 values, the low nibbles feed the first MFMA and the high
-// nibbles the second, each moved to the top of its byte (value*16, sign included) so no
-// sign-extension arithmetic is needed; the factor 16 is folded into the scale (exactly, it
-// is a power of two).  The activation operand is permuted to match (even / odd k).
+// Layout.  One workgroup of W waves owns 16 consecutive weight rows n0..n0+15.  The row is cut
+// into units of 128 bytes (one quantization group of INT8, two of packed INT4); wave w streams
+// units w, w+W, w+2W, ... so the waves read disjoint slices and every 128-byte line is fetched
+// by exactly one wave.  A unit is two dwordx4 loads per lane (16 rows x 64 contiguous bytes
+// each) that go straight to VGPRs: nothing is shared between waves, so there is no LDS staging
+// of weights.  Each wave keeps a ring of P units in flight; the steady-state loop is
+// branch-free so the compiler can retire loads with counted s_waitcnt vmcnt(N) and a slot is
+// refilled as soon as its MFMAs are issued.
 //
-// Any consistent permutation of k inside a group leaves an integer sum unchanged, so the
-// lane->k mapping is chosen for coalescing, not for the MFMA's nominal k order.
+// The INT32 dot products come from v_mfma_i32_16x16x64_i8 with the activations as the row
+// operand (rows m >= M are zeroed) and the 16 weight rows as the column operand; two MFMAs
+// cover one group, which makes the group sum exact and does the cross-lane reduction for free.
+// INT4 weights stay packed in HBM: a 16-byte load holds 32 values, the low nibbles feed the
+// first MFMA of a group and the high nibbles the second, each moved to the top of its byte
+// (value*16, sign included) so no sign-extension arithmetic is needed; the factor 16 is folded
+// into the scale (exactly: a power of two).  The activation operand is permuted to match (even
+// / odd k).  Any consistent permutation of k inside a group leaves an integer sum unchanged,
+// so the lane->k mapping is chosen for coalescing, not for the MFMA's nominal k order.
 //
 // The fp32 part follows the reference order exactly (kernel_gemm.cpp:311-324):
 //   running = fma(float(group_sum_g), float(B_scale[n,g]), running)   g ascending
 //   C = half(running * A_scale[m])
-// Waves drop their converted group sums into LDS; after one barrier per chunk, thread
-// (m, n) of the workgroup runs the g-ordered fma chain.  LDS is double buffered so the
-// chain of chunk c overlaps the streaming of chunk c+1.
+// Waves drop their converted group sums into LDS; thread (m, n) of the workgroup then runs the
+// g-ordered fma chain with the tile's scales, which are copied to LDS behind the first weight
+// loads.  K is processed in chunks only when the M*G group sums exceed the LDS budget.
 #include "common.hip.h"
 #include "kernels.h"
 
 namespace cactus_hip {
 
-constexpr int SK_WAVES = 8;
-constexpr int SK_GPW = 4;
-constexpr int SK_S = SK_WAVES * SK_GPW;  // groups per chunk
-constexpr int SK_TN = 16;                // weight rows per workgroup
-constexpr int SK_THREADS = SK_WAVES * 64;
+constexpr int SK_TN = 16;  // weight rows per workgroup
 
-__device__ __forceinline__ v4i ldg_nt(const void* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const v4i*>(p));
-}
 __device__ __forceinline__ v4i ldg(const void* p) { return *reinterpret_cast<const v4i*>(p); }
 
-template <bool INT4>
-struct ChunkRegs {
-    v4i b[SK_GPW][INT4 ? 1 : 2];
-    v4i a[SK_GPW][2];
+// Raw buffer loads: one SGPR descriptor per operand, a 32-bit per-lane byte offset, hardware
+// range check (offsets >= num_records return 0 without touching memory, which is how rows
+// beyond N / M and units beyond K are padded).  AUX 2 = non-temporal (weights are read once).
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned SK_OOB = 0x80000000u;   // added to an offset to push it out of range
+template <int AUX>
+__device__ __forceinline__ v4i buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int imm) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + imm), 0, AUX);
+    return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+}
+
+template <bool INT4, bool ALDS>
+struct UnitRegs {
+    v4i b[2];
+    v4i a[ALDS ? 1 : (INT4 ? 4 : 2)];   // ALDS: the activation operand is read from LDS at use
 };
 
-template <bool INT4>
-__global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
+// INT4:  packed weights.   W: waves per workgroup.   P: ring depth (units in flight per wave).
+// ALDS:  activations (M*K bytes) are staged in LDS once per workgroup and the MFMA row operand
+//        is read from there; otherwise it is loaded from global memory (L2) with the ring.
+// GS:    also write the INT32 group sums (parity checks); C may then be null.
+template <bool INT4, int W, int P, bool ALDS, bool GS>
+__global__ __launch_bounds__(W * 64) void skinny_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales,
     const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
-    uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G) {
-    extern __shared__ __attribute__((aligned(16))) float sk_lds[];  // [2][SK_S][M][16]
+    uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
+    int ablate) {
+    constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    // Rows are padded by 4 floats: 16-byte aligned for the chain's ds_read_b128, and the 16
+    // lanes that write one group land on 8 different banks.
+    const int SCP = SC + 4, GP = ((G + 3) & ~3) + 4;
+    float* gbuf = sk_lds;                                                        // [M*16][SCP] group sums
+    float* scl = sk_lds + (size_t)M * 16 * SCP;                                  // [16][GP] fp32 scales
+    int8_t* lds_a = reinterpret_cast<int8_t*>(scl + SK_TN * GP);                 // [M][K] (ALDS)
 
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15;   // MFMA row (activation row m) for A, column (weight row) for B
     const int q = lane >> 4;   // k block of the MFMA operand
     const int n0 = blockIdx.x * SK_TN;
-    const int brow = min(n0 + r, N - 1);
-    const size_t row_bytes = INT4 ? (size_t)K / 2 : (size_t)K;
-    const uint8_t* bptr = B + (size_t)brow * row_bytes;
-    const int8_t* aptr = A + (size_t)min(r, M - 1) * K;
+    const unsigned row_bytes = INT4 ? (unsigned)K / 2 : (unsigned)K;
+    const __amdgpu_buffer_rsrc_t brsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t arsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(A), 0, M * K, 0x00020000);
+    // per-lane byte offsets; rows past the end are pushed out of range and read as zero
+    const unsigned boff = (n0 + r < N) ? (unsigned)(n0 + r) * row_bytes + q * 16 : SK_OOB;
+    const unsigned aoff = (r < M) ? (unsigned)r * K + (INT4 ? q * 32 : q * 16) : SK_OOB;
+    const int arow = min(r, M - 1);
+    const int8_t* aptr_lds = lds_a + (size_t)arow * K + (INT4 ? q * 32 : q * 16);
     const bool a_live = r < M;
     const v4i zero4 = {0, 0, 0, 0};
+    const bool want_c = C != nullptr;
+    const int nunits = G / GPU_;   // units per weight row
 
-    auto load_chunk = [&](int c, ChunkRegs<INT4>& R) {
+    // u: unit index in the row; units >= nunits are read as zeros (no memory traffic)
+    auto load_unit = [&](int u, UnitRegs<INT4, ALDS>& R) {
+        const unsigned uo = (u < nunits) ? (unsigned)u * 128u : SK_OOB;
+        R.b[0] = buf_load<2>(brsrc, boff + uo, 0);
+        R.b[1] = buf_load<2>(brsrc, boff + uo, 64);
+        if constexpr (!ALDS) {
+            const unsigned ao = (u < nunits) ? (unsigned)u * (INT4 ? 256u : 128u) : SK_OOB;
+            if constexpr (INT4) {
+                R.a[0] = buf_load<0>(arsrc, aoff + ao, 0);
+                R.a[1] = buf_load<0>(arsrc, aoff + ao, 16);
+                R.a[2] = buf_load<0>(arsrc, aoff + ao, 128);
+                R.a[3] = buf_load<0>(arsrc, aoff + ao, 144);
+            } else {
+                R.a[0] = buf_load<0>(arsrc, aoff + ao, 0);
+                R.a[1] = buf_load<0>(arsrc, aoff + ao, 64);
+            }
+        }
+    };
+
+    // store one group's 16x16 INT32 tile: lane holds column n = lane & 15, rows m = 4*(lane>>4)+i
+    auto put_group = [&](int g, int gl, int ng, v4i acc) {
 #pragma unroll
-        for (int j = 0; j < SK_GPW; j++) {
-            const int g = c * SK_S + j * SK_WAVES + w;
-            if (g < G) {
-                if constexpr (INT4) {
-                    R.b[j][0] = ldg_nt(bptr + (size_t)g * 64 + q * 16);
-                    const int8_t* ap = aptr + (size_t)g * 128 + q * 32;
-                    R.a[j][0] = a_live ? ldg(ap) : zero4;
-                    R.a[j][1] = a_live ? ldg(ap + 16) : zero4;
-                } else {
-                    const uint8_t* bp = bptr + (size_t)g * 128 + q * 16;
-                    R.b[j][0] = ldg_nt(bp);
-                    R.b[j][1] = ldg_nt(bp + 64);
-                    const int8_t* ap = aptr + (size_t)g * 128 + q * 16;
-                    R.a[j][0] = a_live ? ldg(ap) : zero4;
-                    R.a[j][1] = a_live ? ldg(ap + 64) : zero4;
+        for (int i = 0; i < 4; i++) {
+            const int m = q * 4 + i;
+            if (m < M && gl < ng && !(ablate & 2)) {
+                gbuf[(m * 16 + r) * SCP + gl] = (float)acc[i];
+                if constexpr (GS) {
+                    if (n0 + r < N) gsums[((size_t)m * N + n0 + r) * G + g] = INT4 ? (acc[i] >> 4) : acc[i];
                 }
             }
         }
     };
 
-    const int nchunks = (G + SK_S - 1) / SK_S;
-    const int t = threadIdx.x;
-    const bool chain = (t < M * 16) && C != nullptr;  // C == nullptr: group sums only
-    const int cm = t >> 4, cn = t & 15;
-    const uint16_t* sc_ptr = B_scales + (size_t)min(n0 + cn, N - 1) * G;
-    float run = 0.0f;
-
-    ChunkRegs<INT4> cur, nxt;
-    load_chunk(0, cur);
-
-    for (int c = 0; c < nchunks; c++) {
-        if (c + 1 < nchunks) load_chunk(c + 1, nxt);
-
-        // scales of this chunk for the chain thread (issued early, consumed after the barrier)
-        const int ng = min(SK_S, G - c * SK_S);
-        float sc[SK_S];
-        if (chain) {
+    // u: unit index inside the chunk; g0: first group of the chunk
+    auto compute_unit = [&](int u, int g0, int ng, const UnitRegs<INT4, ALDS>& R) {
+        if constexpr (INT4) {
+            v4i a[4];
+            if constexpr (ALDS) {
+                const int8_t* ap = aptr_lds + (size_t)min(g0 / 2 + u, nunits - 1) * 256;
+                a[0] = ldg(ap); a[1] = ldg(ap + 16); a[2] = ldg(ap + 128); a[3] = ldg(ap + 144);
+            } else {
 #pragma unroll
-            for (int gl = 0; gl < SK_S; gl++) {
-                const float s = (gl < ng) ? h2f(sc_ptr[c * SK_S + gl]) : 0.0f;
-                sc[gl] = INT4 ? s * 0.0625f : s;
+                for (int i = 0; i < 4; i++) a[i] = R.a[i];
             }
-        }
-
-        float* buf = sk_lds + (size_t)(c & 1) * SK_S * M * 16;
 #pragma unroll
-        for (int j = 0; j < SK_GPW; j++) {
-            const int gl = j * SK_WAVES + w;
-            const int g = c * SK_S + gl;
-            if (g < G) {
-                v4i acc = zero4;
-                if constexpr (INT4) {
-                    v4i blo, bhi, ae, ao;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t x = (uint32_t)cur.b[j][0][i];
-                        blo[i] = (int)((x & 0x0F0F0F0Fu) << 4);
-                        bhi[i] = (int)(x & 0xF0F0F0F0u);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t lo = (uint32_t)cur.a[j][i >> 1][(2 * i) & 3];
-                        const uint32_t hi = (uint32_t)cur.a[j][i >> 1][((2 * i) & 3) + 1];
-                        ae[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x06040200u);
-                        ao[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x07050301u);
-                    }
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, blo, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bhi, acc, 0, 0, 0);
-                } else {
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[j][0], cur.b[j][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(cur.a[j][1], cur.b[j][1], acc, 0, 0, 0);
-                }
-                // result layout: lane holds column n = lane & 15, rows m = 4*(lane >> 4) + i
+            for (int h = 0; h < 2; h++) {   // the unit's two groups: 64 packed bytes each
+                v4i blo, bhi, ae, ao;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const int m = q * 4 + i;
-                    if (m < M) {
-                        buf[(gl * M + m) * 16 + r] = (float)acc[i];
-                        if (gsums != nullptr && n0 + r < N)
-                            gsums[((size_t)m * N + n0 + r) * G + g] = INT4 ? (acc[i] >> 4) : acc[i];
-                    }
+                    const uint32_t x = (uint32_t)R.b[h][i];
+                    blo[i] = (int)((x & 0x0F0F0F0Fu) << 4);
+                    bhi[i] = (int)(x & 0xF0F0F0F0u);
                 }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lo = (uint32_t)a[2 * h + (i >> 1)][(2 * i) & 3];
+                    const uint32_t hi = (uint32_t)a[2 * h + (i >> 1)][((2 * i) & 3) + 1];
+                    ae[i] = (!ALDS || a_live) ? (int)__builtin_amdgcn_perm(hi, lo, 0x06040200u) : 0;
+                    ao[i] = (!ALDS || a_live) ? (int)__builtin_amdgcn_perm(hi, lo, 0x07050301u) : 0;
+                }
+                v4i acc = zero4;
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, blo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bhi, acc, 0, 0, 0);
+                put_group(g0 + 2 * u + h, 2 * u + h, ng, acc);
+            }
+        } else {
+            v4i a0, a1;
+            if constexpr (ALDS) {
+                const int8_t* ap = aptr_lds + (size_t)min(g0 + u, nunits - 1) * 128;
+                a0 = ldg(ap); a1 = ldg(ap + 64);
+            } else {
+                a0 = R.a[0]; a1 = R.a[1];
+            }
+            if constexpr (ALDS) {
+                a0 = a_live ? a0 : zero4;
+                a1 = a_live ? a1 : zero4;
+            }
+            v4i acc = zero4;
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, R.b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, R.b[1], acc, 0, 0, 0);
+            put_group(g0 + u, u, ng, acc);
+        }
+    };
+
+    // chain element e = t + k*W*64 -> (m = e / 16, n = e % 16); NR elements per thread
+    constexpr int NR = (256 + W * 64 - 1) / (W * 64);
+    float run[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) run[k] = 0.0f;
+
+    for (int g0 = 0; g0 < G; g0 += SC) {
+        const int ng = min(SC, G - g0);
+        const int nu = ng / GPU_;                    // units in this chunk
+        const int ubase = g0 / GPU_;                 // first unit of the chunk
+        UnitRegs<INT4, ALDS> ring[P];
+
+        // activations -> LDS (ALDS runs as a single chunk): requested first, written to LDS
+        // after the first weight loads have been issued
+        constexpr int AST = 4;   // 16-byte pieces per thread held in registers
+        v4i a_stage[AST];
+        if constexpr (ALDS) {
+#pragma unroll
+            for (int j = 0; j < AST; j++) {
+                const int i16 = t + j * W * 64;
+                a_stage[j] = (i16 < M * K / 16) ? ldg(A + (size_t)i16 * 16) : zero4;
+            }
+        }
+        // every wave runs the same number of rounds; units past the chunk read as zeros
+        const int nu_end = ubase + nu;               // one past the chunk's last unit
+        auto chunk_unit = [&](int ul) { return (ul < nu) ? ubase + ul : nunits; };
+#pragma unroll
+        for (int p = 0; p < P; p++) load_unit(chunk_unit(w + p * W), ring[p]);
+        (void)nu_end;
+
+        // tile scales: requested behind the first weight loads, parked in registers, and written
+        // to LDS (as fp32, x 1/16 for INT4) only after the stream, so no wait sits in the ring
+        const bool sc_fast = (n0 + SK_TN <= N) && ((G & 7) == 0) && (SK_TN * G / 8 <= W * 64) &&
+                             ((reinterpret_cast<uintptr_t>(B_scales) & 15) == 0);
+        v4i sc_regs = zero4;
+        const bool sc_mine = g0 == 0 && want_c && !(ablate & 4) && sc_fast && t < SK_TN * G / 8;
+        if (sc_mine) sc_regs = ldg(B_scales + (size_t)n0 * G + (size_t)t * 8);
+        if (g0 == 0 && want_c && !(ablate & 4) && !sc_fast) {
+            for (int idx = t; idx < SK_TN * G; idx += W * 64) {
+                const int row = idx / G, g = idx - row * G;
+                const float s = h2f(B_scales[(size_t)min(n0 + row, N - 1) * G + g]);
+                scl[row * GP + g] = INT4 ? s * 0.0625f : s;
+            }
+        }
+        if constexpr (ALDS) {   // LDS writes visible, weight loads stay in flight
+#pragma unroll
+            for (int j = 0; j < AST; j++) {
+                const int i16 = t + j * W * 64;
+                if (i16 < M * K / 16) *reinterpret_cast<v4i*>(lds_a + (size_t)i16 * 16) = a_stage[j];
+            }
+            for (int i16 = t + AST * W * 64; i16 < M * K / 16; i16 += W * 64)
+                *reinterpret_cast<v4i*>(lds_a + (size_t)i16 * 16) = ldg(A + (size_t)i16 * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+
+        const int rounds = (nu + W * P - 1) / (W * P);
+        for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int ul = w + (rd * P + p) * W; // unit index inside the chunk
+                compute_unit(ul, g0, ng, ring[p]);
+                load_unit(chunk_unit(ul + P * W), ring[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++)                  // last round: nothing left to request
+            compute_unit(w + ((rounds - 1) * P + p) * W, g0, ng, ring[p]);
+        if (sc_mine) {   // 8 consecutive scales of one row (G % 8 == 0)
+            const int row = (t * 8) / G, g = (t * 8) - row * G;
+            float* dst = scl + row * GP + g;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = (uint32_t)sc_regs[i];
+                const float lo = h2f((uint16_t)(x & 0xFFFFu)), hi = h2f((uint16_t)(x >> 16));
+                dst[2 * i] = INT4 ? lo * 0.0625f : lo;
+                dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
             }
         }
         __syncthreads();
-        if (chain) {
+        if (want_c && !(ablate & 1)) {
 #pragma unroll
-            for (int gl = 0; gl < SK_S; gl++)
-                if (gl < ng) run = fmaf(buf[(gl * M + cm) * 16 + cn], sc[gl], run);
+            for (int k = 0; k < NR; k++) {
+                const int e = t + k * W * 64;
+                if (e < M * 16) {
+                    const float* sp = scl + (e & 15) * GP + g0;   // g0 and GP are multiples of 4
+                    const float* gp = gbuf + (size_t)e * SCP;
+                    int gl = 0;
+                    // 16 groups per batch: eight ds_read_b128, then the serial fma chain
+                    for (; gl + 16 <= ng; gl += 16) {
+                        v4f gv[4], sv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            gv[u] = *reinterpret_cast<const v4f*>(gp + gl + 4 * u);
+                            sv[u] = *reinterpret_cast<const v4f*>(sp + gl + 4 * u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 16; u++) run[k] = fmaf(gv[u >> 2][u & 3], sv[u >> 2][u & 3], run[k]);
+                    }
+                    for (; gl < ng; gl++) run[k] = fmaf(gp[gl], sp[gl], run[k]);
+                }
+            }
         }
-        cur = nxt;
+        if (g0 + SC < G) __syncthreads();
     }
 
-    if (chain && n0 + cn < N)
-        C[(size_t)cm * N + n0 + cn] = f2h_mul(run, A_scales[cm]);
+    if (want_c) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int e = t + k * W * 64;
+            const int cm = e >> 4, cn = e & 15;
+            if (e < M * 16 && n0 + cn < N) C[(size_t)cm * N + n0 + cn] = f2h_mul(run[k], A_scales[cm]);
+        }
+    }
+}
+
+int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging
+
+namespace {
+
+template <bool INT4, int W, int P, bool ALDS>
+hipError_t launch_cfg(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
+                      uint16_t* C, int32_t* gsums, size_t M, size_t K, size_t N, hipStream_t st) {
+    const int G = (int)(K / 128);
+    constexpr int GPU_ = INT4 ? 2 : 1;
+    if (INT4 && (G & 1)) return hipErrorInvalidValue;   // packed units hold two groups
+    if (N * (INT4 ? K / 2 : K) > (size_t(1) << 31) || M * K > (size_t(1) << 31)) return hipErrorInvalidValue;
+    // chunk of groups whose sums fit a 16 KB (M <= 4) / 32 KB LDS budget: a multiple of W units
+    const int step = W * GPU_;
+    int SC = (int)(((M > 4 ? 32 : 16) * 1024) / (M * 64));
+    SC = (SC / step) * step;
+    if (SC < step) SC = step;
+    while (SC % 4) SC += step;   // chunk starts stay 16-byte aligned in the fp32 LDS rows
+    const int Gr = ((G + step - 1) / step) * step;
+    if (SC > Gr) SC = Gr;
+    size_t lds = ((size_t)M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~3) + 4)) * sizeof(float);
+    if (ALDS) lds += M * K;
+    if (ALDS && (SC < Gr || lds > 64 * 1024)) return hipErrorInvalidValue;   // single chunk only
+    const dim3 grid((unsigned)((N + SK_TN - 1) / SK_TN)), block(W * 64);
+    if (gsums != nullptr)
+        skinny_kernel<INT4, W, P, ALDS, true><<<grid, block, lds, st>>>(
+            A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
+    else
+        skinny_kernel<INT4, W, P, ALDS, false><<<grid, block, lds, st>>>(
+            A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// variant: 0 = default choice; otherwise [1 if ALDS]*10000 + W*100 + P (benchmarks only).
+hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A, const float* A_scales,
+                                        const void* B, const uint16_t* B_scales, uint16_t* C, int32_t* gsums,
+                                        size_t M, size_t K, size_t N, hipStream_t st) {
+#define SK_CASE(WW, PP)                                                                                \
+    case WW * 100 + PP:                                                                                 \
+        return int4 ? launch_cfg<true, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)  \
+                    : launch_cfg<false, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st); \
+    case 10000 + WW * 100 + PP:                                                                         \
+        return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
+                    : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
+    switch (variant) {
+        SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
+        SK_CASE(16, 2) SK_CASE(16, 4) SK_CASE(2, 4) SK_CASE(2, 8) SK_CASE(8, 1) SK_CASE(4, 1) SK_CASE(2, 2)
+        SK_CASE(16, 1) SK_CASE(1, 4) SK_CASE(1, 8)
+        default: return hipErrorInvalidValue;
+    }
+#undef SK_CASE
 }
 
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                                 size_t K, size_t N, hipStream_t st) {
-    const int G = (int)(K / 128);
-    const size_t lds = (size_t)2 * SK_S * M * 16 * sizeof(float);
-    const dim3 grid((unsigned)((N + SK_TN - 1) / SK_TN)), block(SK_THREADS);
-    if (int4)
-        skinny_kernel<true><<<grid, block, lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C, gsums,
-                                                      (int)M, (int)K, (int)N, G);
-    else
-        skinny_kernel<false><<<grid, block, lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C, gsums,
-                                                       (int)M, (int)K, (int)N, G);
-    return hipGetLastError();
+    // Measured on MI355X (scripts/gemv_bench): ring depth 4 everywhere; about 4 units per wave,
+    // i.e. short rows get few waves per tile (more, smaller workgroups in flight) and long rows 8.
+    const size_t nu = K / (int4 ? 256 : 128);
+    int W = 1;
+    while (W < 8 && (size_t)W * 8 <= nu) W *= 2;
+    // activations through LDS whenever activations + group sums + scales fit 64 KB
+    const size_t G = K / 128;
+    const size_t lds_alds = (M * 16 * (G + 8 + 4) + 16 * (G + 8)) * sizeof(float) + M * K;
+    const bool alds = M <= 4 && lds_alds <= 60 * 1024;
+    return launch_matmul_skinny_variant((alds ? 10000 : 0) + W * 100 + 4, int4, A, A_scales, B, B_scales, C,
+                                        gsums, M, K, N, st);
 }
 
 }  // namespace cactus_hip
