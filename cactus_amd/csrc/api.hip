@@ -35,6 +35,14 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, #expr, e_); \
     } while (0)
 
+}  // namespace
+
+namespace cactus_hip {
+void set_last_error(const char* msg) { g_err = msg ? msg : ""; }
+}  // namespace cactus_hip
+
+namespace {
+
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 

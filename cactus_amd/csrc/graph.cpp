@@ -1,0 +1,716 @@
+// Device-resident mirror of the reference's graph dispatch for the hot path (see graph.h).
+#include "graph.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/cactus_hip.h"
+#include "../../include/cactus_hip_graph.h"
+#include "kernels.h"
+
+namespace cactus_hip {
+
+namespace {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void abi_check(int rc) {
+    if (rc != CACTUS_HIP_OK) throw std::runtime_error(std::string("cactus_hip: ") + cactus_hip_last_error());
+}
+void* dev_alloc(size_t bytes) {
+    void* p = nullptr;
+    hip_check(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc");
+    return p;
+}
+size_t product(const std::vector<size_t>& s) {
+    size_t n = 1;
+    for (size_t d : s) n *= d;
+    return n;
+}
+
+}  // namespace
+
+size_t precision_size(Precision p) {
+    switch (p) {
+        case Precision::INT8: return 1;
+        case Precision::FP16: return 2;
+        case Precision::FP32: return 4;
+        case Precision::INT4: return 1;
+    }
+    return 1;
+}
+
+// ------------------------------------------------------------------------- CactusGraph
+
+CactusGraph::CactusGraph() = default;
+CactusGraph::~CactusGraph() { hard_reset(); }
+
+GraphNode& CactusGraph::node(size_t id) { return *nodes_[node_index_map_.at(id)]; }
+const GraphNode& CactusGraph::node(size_t id) const { return *nodes_[node_index_map_.at(id)]; }
+const BufferDesc& CactusGraph::get_output_buffer(size_t node_id) const { return node(node_id).output_buffer; }
+
+// graph_builder.cpp:572-596.  One deliberate difference: a QUANTIZE_ACTIVATIONS node keeps the
+// INT8 precision it asks for (the reference's rule hands it its input's FP16 precision, which
+// leaves that builder unusable: no model calls it).
+size_t CactusGraph::add_node(OpType op_type, const std::vector<size_t>& inputs,
+                             const std::vector<size_t>& output_shape, const OpParams& params) {
+    auto n = std::make_unique<GraphNode>();
+    n->id = next_node_id_;
+    n->op_type = op_type;
+    n->input_ids = inputs;
+    n->params = params;
+    std::vector<size_t> shape = output_shape;
+    if (shape.empty() && !inputs.empty()) shape = node(inputs[0]).output_buffer.shape;
+    Precision prec = params.output_precision;
+    if (op_type != OpType::QUANTIZE_ACTIVATIONS && prec == Precision::INT8 && !inputs.empty())
+        prec = node(inputs[0]).output_buffer.precision;
+    n->output_buffer.shape = shape;
+    n->output_buffer.precision = prec;
+    n->output_buffer.total_size = product(shape);
+    n->output_buffer.byte_size = n->output_buffer.total_size * precision_size(prec);
+    const size_t id = next_node_id_++;
+    node_index_map_[id] = nodes_.size();
+    nodes_.push_back(std::move(n));
+    return id;
+}
+
+size_t CactusGraph::input(const std::vector<size_t>& shape, Precision precision) {
+    OpParams p;
+    p.output_precision = precision;
+    return add_node(OpType::INPUT, {}, shape, p);
+}
+
+size_t CactusGraph::quantize_activations(size_t input) {   // graph_builder.cpp:560-570
+    const auto& in = get_output_buffer(input);
+    if (in.precision != Precision::FP16) throw std::invalid_argument("quantize_activations requires FP16 input");
+    OpParams p;
+    p.output_precision = Precision::INT8;
+    return add_node(OpType::QUANTIZE_ACTIVATIONS, {input}, in.shape, p);
+}
+
+size_t CactusGraph::matmul(size_t input1, size_t input2, bool pretransposed_rhs, ComputeBackend backend) {
+    const auto& lhs = get_output_buffer(input1);   // graph_builder.cpp:61-81
+    const auto& rhs = get_output_buffer(input2);
+    if (lhs.shape.size() != 2 || rhs.shape.size() != 2)
+        throw std::invalid_argument("Matrix multiplication requires 2D tensors");
+    const size_t M = lhs.shape[0], K = lhs.shape[1];
+    const size_t rhs_K = pretransposed_rhs ? rhs.shape[1] : rhs.shape[0];
+    const size_t N = pretransposed_rhs ? rhs.shape[0] : rhs.shape[1];
+    if (K != rhs_K) throw std::invalid_argument("Matrix dimensions incompatible for multiplication");
+    OpParams p;
+    p.pretransposed_rhs = pretransposed_rhs;
+    p.backend = backend;
+    p.output_precision = Precision::FP16;   // every matmul branch writes FP16 (graph_ops_nn.cpp:154,184,218)
+    return add_node(OpType::MATMUL, {input1, input2}, {M, N}, p);
+}
+
+size_t CactusGraph::attention(size_t q, size_t k, size_t v, float scale, bool is_causal, ComputeBackend backend) {
+    OpParams p;
+    p.scale = scale; p.is_causal = is_causal; p.backend = backend;
+    return add_node(OpType::ATTENTION, {q, k, v}, {}, p);
+}
+size_t CactusGraph::attention(size_t q, size_t k, size_t v, float scale, size_t position_offset,
+                              ComputeBackend backend) {
+    OpParams p;
+    p.scale = scale; p.position_offset = position_offset; p.backend = backend;
+    return add_node(OpType::ATTENTION, {q, k, v}, {}, p);
+}
+size_t CactusGraph::attention(size_t q, size_t k, size_t v, float scale, size_t position_offset,
+                              size_t window_size, ComputeBackend backend) {
+    OpParams p;
+    p.scale = scale; p.position_offset = position_offset; p.window_size = window_size; p.backend = backend;
+    return add_node(OpType::ATTENTION, {q, k, v}, {}, p);
+}
+size_t CactusGraph::attention_int8_hybrid(size_t q, size_t key_new, size_t value_new, float scale,
+                                          size_t position_offset, const int8_t* cached_keys,
+                                          const int8_t* cached_values, const float* k_scales,
+                                          const float* v_scales, size_t cache_len, size_t num_kv_heads,
+                                          size_t head_dim) {
+    OpParams p;   // graph_builder.cpp:301-316
+    p.scale = scale; p.position_offset = position_offset;
+    p.cached_keys_int8 = cached_keys; p.cached_values_int8 = cached_values;
+    p.cached_k_scales = k_scales; p.cached_v_scales = v_scales;
+    p.cache_seq_len = cache_len; p.num_kv_heads = num_kv_heads; p.head_dim = head_dim;
+    return add_node(OpType::ATTENTION_INT8_HYBRID, {q, key_new, value_new}, {}, p);
+}
+
+void CactusGraph::ensure_device(BufferDesc& b) {
+    if (b.device_data == nullptr) {
+        b.device_data = dev_alloc(b.byte_size);
+        b.owns_device = true;
+    }
+}
+
+void* CactusGraph::resident_copy(const void* host, size_t bytes) {
+    auto it = resident_.find(host);
+    if (it != resident_.end() && it->second.bytes == bytes) return it->second.dev;
+    if (it != resident_.end()) {
+        (void)hipFree(it->second.dev);
+        resident_.erase(it);
+    }
+    void* d = dev_alloc(bytes);
+    hip_check(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D (resident)");
+    resident_[host] = Resident{d, bytes};
+    return d;
+}
+
+void CactusGraph::set_input(size_t node_id, const void* data, Precision) {
+    auto& n = node(node_id);
+    if (n.op_type != OpType::INPUT) throw std::invalid_argument("Can only set data on input nodes");
+    BufferDesc& b = n.output_buffer;
+    if (b.device_data != nullptr && !b.owns_device) b.device_data = nullptr;
+    ensure_device(b);
+    hip_check(hipMemcpy(b.device_data, data, b.byte_size, hipMemcpyHostToDevice), "hipMemcpy H2D (input)");
+    b.device_valid = true;
+}
+
+void CactusGraph::set_external_input(size_t node_id, void* data, Precision) {
+    auto& n = node(node_id);
+    if (n.op_type != OpType::INPUT) throw std::invalid_argument("Can only set data on input nodes");
+    BufferDesc& b = n.output_buffer;
+    if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
+    b.device_data = resident_copy(data, b.byte_size);
+    b.owns_device = false;
+    b.device_valid = true;
+    is_weight_[node_id] = true;
+}
+
+void CactusGraph::set_device_input(size_t node_id, void* device_ptr, Precision) {
+    auto& n = node(node_id);
+    if (n.op_type != OpType::INPUT) throw std::invalid_argument("Can only set data on input nodes");
+    BufferDesc& b = n.output_buffer;
+    if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
+    b.device_data = device_ptr;
+    b.owns_device = false;
+    b.device_valid = true;
+}
+
+void CactusGraph::set_grouped_scales(size_t node_id, size_t group_size, size_t num_groups, void* scales_ptr) {
+    BufferDesc& b = node(node_id).output_buffer;   // graph_io.cpp:106-112
+    if (b.shape.empty()) throw std::invalid_argument("set_grouped_scales on a shapeless node");
+    b.group_size = group_size;
+    b.num_groups = num_groups;
+    b.scales_device = resident_copy(scales_ptr, b.shape[0] * num_groups * sizeof(uint16_t));
+    b.owns_scales = false;
+}
+
+void CactusGraph::set_packed_int4(size_t node_id, const void* packed, size_t packed_bytes) {
+    BufferDesc& b = node(node_id).output_buffer;
+    b.packed_int4_device = resident_copy(packed, packed_bytes);
+    b.packed_int4_size = packed_bytes;
+    b.device_valid = true;
+    is_weight_[node_id] = true;
+}
+
+// graph_ops_nn.cpp:129-231
+void CactusGraph::compute_matmul_node(GraphNode& n) {
+    BufferDesc& lhs = node(n.input_ids[0]).output_buffer;
+    BufferDesc& rhs = node(n.input_ids[1]).output_buffer;
+    const size_t M = lhs.shape[lhs.shape.size() - 2];
+    const size_t K = lhs.shape[lhs.shape.size() - 1];
+    const bool pre = n.params.pretransposed_rhs;
+    const size_t N = pre ? rhs.shape[rhs.shape.size() - 2] : rhs.shape[rhs.shape.size() - 1];
+    if (n.params.backend == ComputeBackend::NPU)
+        throw std::runtime_error("NPU matrix multiplication not yet implemented");
+    auto* out = static_cast<cactus_half_t*>(n.output_buffer.device_data);
+    const bool lhs_prequant = lhs.precision == Precision::INT8 && lhs.has_activation_scales();
+
+    const bool int4 = rhs.is_packed_int4();
+    if (int4 || rhs.is_grouped_int8()) {
+        if (!pre)
+            throw std::runtime_error(int4 ? "INT4 matmul requires pretransposed weights"
+                                          : "Group-wise INT8 matmul requires pretransposed weights");
+        const int8_t* a8;
+        const float* as;
+        if (lhs_prequant) {
+            a8 = static_cast<const int8_t*>(lhs.device_data);
+            as = static_cast<const float*>(lhs.activation_scales_device);
+        } else if (lhs.precision == Precision::FP16) {
+            // quantize once per FP16 node and step; q/k/v (and gate/up) share one input node
+            QuantCache& qc = quant_cache_[n.input_ids[0]];
+            if (qc.q == nullptr || qc.M != M || qc.K != K) {
+                if (qc.q) { (void)hipFree(qc.q); (void)hipFree(qc.scales); }
+                qc.q = dev_alloc(M * K);
+                qc.scales = dev_alloc(M * sizeof(float));
+                qc.M = M; qc.K = K;
+                abi_check(cactus_hip_quantize_activations_dev(static_cast<const cactus_half_t*>(lhs.device_data),
+                                                              static_cast<int8_t*>(qc.q),
+                                                              static_cast<float*>(qc.scales), M, K, nullptr));
+            }
+            a8 = static_cast<const int8_t*>(qc.q);
+            as = static_cast<const float*>(qc.scales);
+        } else {
+            throw std::runtime_error(int4 ? "INT4 matmul requires INT8 (pre-quantized) or FP16 activations"
+                                          : "INT8 matmul requires INT8 (pre-quantized) or FP16 activations");
+        }
+        const auto* bs = static_cast<const cactus_half_t*>(rhs.scales_device);
+        if (int4)
+            abi_check(cactus_hip_matmul_int4_dev(a8, as, static_cast<const uint8_t*>(rhs.packed_int4_device), bs,
+                                                 out, M, K, N, rhs.group_size, nullptr));
+        else
+            abi_check(cactus_hip_matmul_int8_dev(a8, as, static_cast<const int8_t*>(rhs.device_data), bs, out, M,
+                                                 K, N, rhs.group_size, nullptr));
+        return;
+    }
+    if (lhs.precision != Precision::FP16) throw std::runtime_error("FP16 matmul requires FP16 activations");
+    const auto* a = static_cast<const cactus_half_t*>(lhs.device_data);
+    const auto* b = static_cast<const cactus_half_t*>(rhs.device_data);
+    if (pre) {
+        abi_check(cactus_hip_matmul_f16_dev(a, b, out, M, K, N, nullptr));
+    } else {
+        // rhs is [K, N]: transpose into a scratch buffer, then the same kernel
+        // (graph_ops_nn.cpp:222-229 does the same on the host)
+        void* bt = dev_alloc(N * K * 2);
+        hipError_t e = launch_transpose_f16(static_cast<const uint16_t*>(rhs.device_data),
+                                            static_cast<uint16_t*>(bt), K, N, nullptr);
+        int rc = CACTUS_HIP_OK;
+        if (e == hipSuccess) rc = cactus_hip_matmul_f16_dev(a, static_cast<const cactus_half_t*>(bt), out, M, K, N, nullptr);
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(bt);
+        hip_check(e, "transpose launch");
+        abi_check(rc);
+    }
+}
+
+// graph_ops_nn.cpp:78-127
+void CactusGraph::compute_quantize_activations_node(GraphNode& n) {
+    BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    if (in.precision != Precision::FP16) throw std::runtime_error("QUANTIZE_ACTIVATIONS requires FP16 input");
+    if (in.shape.size() < 2) throw std::runtime_error("QUANTIZE_ACTIVATIONS requires at least 2D tensor");
+    const size_t K = in.shape.back();
+    const size_t M = in.total_size / K;
+    BufferDesc& out = n.output_buffer;
+    if (!out.has_activation_scales() || out.num_rows_for_activation_scales != M) {
+        if (out.activation_scales_device) (void)hipFree(out.activation_scales_device);
+        out.activation_scales_device = dev_alloc(M * sizeof(float));
+        out.num_rows_for_activation_scales = M;
+    }
+    abi_check(cactus_hip_quantize_activations_dev(static_cast<const cactus_half_t*>(in.device_data),
+                                                  static_cast<int8_t*>(out.device_data),
+                                                  static_cast<float*>(out.activation_scales_device), M, K, nullptr));
+}
+
+// graph_ops_nn.cpp:302-338
+void CactusGraph::compute_attention_node(GraphNode& n) {
+    if (n.params.backend == ComputeBackend::NPU)
+        throw std::runtime_error("NPU attention operation not yet implemented");
+    if (n.input_ids.size() < 3)
+        throw std::runtime_error("Attention operation requires 3 inputs (query, key, value), got " +
+                                 std::to_string(n.input_ids.size()) + " inputs");
+    const BufferDesc& q = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& k = node(n.input_ids[1]).output_buffer;
+    const BufferDesc& v = node(n.input_ids[2]).output_buffer;
+    if (q.shape.size() < 4)
+        throw std::runtime_error("Attention operation requires 4D tensors [batch, seq_len, num_heads, head_dim], got " +
+                                 std::to_string(q.shape.size()) + "D tensor");
+    if (q.precision != Precision::FP16) throw std::runtime_error("Attention operation only supports FP16 precision");
+    abi_check(cactus_hip_attention_f16_dev(
+        static_cast<const cactus_half_t*>(q.device_data), static_cast<const cactus_half_t*>(k.device_data),
+        static_cast<const cactus_half_t*>(v.device_data), static_cast<cactus_half_t*>(n.output_buffer.device_data),
+        q.shape[0], q.shape[1], k.shape[1], q.shape[2], k.shape[2], q.shape[3], n.params.scale, nullptr,
+        n.params.position_offset, n.params.window_size, n.params.is_causal ? 1 : 0, nullptr));
+}
+
+// graph_ops_nn.cpp:340-371
+void CactusGraph::compute_attention_int8_hybrid_node(GraphNode& n) {
+    const BufferDesc& q = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& kn = node(n.input_ids[1]).output_buffer;
+    const BufferDesc& vn = node(n.input_ids[2]).output_buffer;
+    if (q.shape.size() < 4) throw std::runtime_error("ATTENTION_INT8_HYBRID requires 4D query tensor");
+    abi_check(cactus_hip_attention_hybrid_int8_fp16_dev(
+        static_cast<const cactus_half_t*>(q.device_data), n.params.cached_keys_int8, n.params.cached_values_int8,
+        n.params.cached_k_scales, n.params.cached_v_scales, static_cast<const cactus_half_t*>(kn.device_data),
+        static_cast<const cactus_half_t*>(vn.device_data), static_cast<cactus_half_t*>(n.output_buffer.device_data),
+        q.shape[0], q.shape[1], n.params.cache_seq_len, kn.shape[1], q.shape[2], n.params.num_kv_heads,
+        n.params.head_dim, n.params.scale, n.params.position_offset, 1, CACTUS_KV_QUANT_GROUP_SIZE, nullptr));
+}
+
+void CactusGraph::execute() {
+    for (auto& kv : quant_cache_) {
+        if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
+    }
+    quant_cache_.clear();
+    for (auto& up : nodes_) {
+        GraphNode& n = *up;
+        if (n.op_type == OpType::INPUT) {
+            if (!n.output_buffer.device_valid)
+                throw std::runtime_error("Input node " + std::to_string(n.id) + " has no data");
+            continue;
+        }
+        for (size_t in : n.input_ids)
+            if (!node(in).output_buffer.device_valid)
+                throw std::runtime_error("Node " + std::to_string(n.id) + " reads a node without data");
+        ensure_device(n.output_buffer);
+        switch (n.op_type) {
+            case OpType::MATMUL: compute_matmul_node(n); break;
+            case OpType::ATTENTION: compute_attention_node(n); break;
+            case OpType::ATTENTION_INT8_HYBRID: compute_attention_int8_hybrid_node(n); break;
+            case OpType::QUANTIZE_ACTIVATIONS: compute_quantize_activations_node(n); break;
+            default: break;
+        }
+        n.output_buffer.device_valid = true;
+    }
+}
+
+void* CactusGraph::get_device_output(size_t node_id) { return node(node_id).output_buffer.device_data; }
+
+void* CactusGraph::get_output(size_t node_id) {   // graph_execute.cpp:223-229; synchronises
+    BufferDesc& b = node(node_id).output_buffer;
+    if (!b.device_valid || b.device_data == nullptr) return nullptr;
+    b.host_copy.resize(b.byte_size);
+    hip_check(hipMemcpy(b.host_copy.data(), b.device_data, b.byte_size, hipMemcpyDeviceToHost), "hipMemcpy D2H");
+    return b.host_copy.data();
+}
+
+static void free_node(GraphNode& n) {
+    BufferDesc& b = n.output_buffer;
+    if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
+    if (b.activation_scales_device) (void)hipFree(b.activation_scales_device);
+    b.device_data = nullptr;
+    b.activation_scales_device = nullptr;
+}
+
+void CactusGraph::soft_reset() {   // graph_execute.cpp:640-675: weights survive, everything else goes
+    std::vector<std::unique_ptr<GraphNode>> keep;
+    for (auto& up : nodes_) {
+        if (is_weight_.count(up->id)) keep.push_back(std::move(up));
+        else free_node(*up);
+    }
+    nodes_ = std::move(keep);
+    node_index_map_.clear();
+    for (size_t i = 0; i < nodes_.size(); i++) node_index_map_[nodes_[i]->id] = i;
+    for (auto& kv : quant_cache_)
+        if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
+    quant_cache_.clear();
+}
+
+void CactusGraph::hard_reset() {
+    for (auto& up : nodes_) free_node(*up);
+    nodes_.clear();
+    node_index_map_.clear();
+    is_weight_.clear();
+    for (auto& kv : resident_) (void)hipFree(kv.second.dev);
+    resident_.clear();
+    for (auto& kv : quant_cache_)
+        if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
+    quant_cache_.clear();
+    next_node_id_ = 0;
+}
+
+// ------------------------------------------------------------------------------ KVCache
+
+KVCache::~KVCache() {
+    for (auto& c : layer_caches) {
+        if (c.keys) (void)hipFree(c.keys);
+        if (c.values) (void)hipFree(c.values);
+        if (c.key_scales) (void)hipFree(c.key_scales);
+        if (c.value_scales) (void)hipFree(c.value_scales);
+    }
+}
+
+void KVCache::init(size_t layers, size_t max_seq, size_t kv_heads, size_t dim) {   // engine_cache.cpp:11-23
+    num_layers = layers;
+    max_seq_len = max_seq;
+    num_kv_heads = kv_heads;
+    head_dim = dim;
+    layer_caches.resize(layers);
+    current_seq_len = 0;
+    total_seq_len = 0;
+}
+
+void KVCache::ensure_capacity(LayerCache& c, size_t tokens) {
+    if (c.capacity_tokens >= tokens) return;
+    const size_t G = (head_dim + CACTUS_KV_QUANT_GROUP_SIZE - 1) / CACTUS_KV_QUANT_GROUP_SIZE;
+    const size_t eb = tokens * num_kv_heads * head_dim, sb = tokens * num_kv_heads * G * sizeof(float);
+    auto grow = [&](void* old, size_t old_bytes, size_t new_bytes) {
+        void* p = dev_alloc(new_bytes);
+        if (old) {
+            hip_check(hipMemcpy(p, old, old_bytes, hipMemcpyDeviceToDevice), "hipMemcpy D2D (grow)");
+            (void)hipFree(old);
+        }
+        return p;
+    };
+    const size_t oe = c.capacity_tokens * num_kv_heads * head_dim, os = c.capacity_tokens * num_kv_heads * G * sizeof(float);
+    c.keys = static_cast<int8_t*>(grow(c.keys, oe, eb));
+    c.values = static_cast<int8_t*>(grow(c.values, oe, eb));
+    c.key_scales = static_cast<float*>(grow(c.key_scales, os, sb));
+    c.value_scales = static_cast<float*>(grow(c.value_scales, os, sb));
+    c.capacity_tokens = tokens;
+}
+
+// engine_cache.cpp:25-46: the reference sizes every layer to the window here, zero-fills the
+// payload and sets every scale to 1.0.  The logical size this leaves behind (size_tokens) is
+// what the whole-sequence branch of update_from_graph compares against to decide whether the
+// sink tokens still have to be written (:169), so it is tracked the same way.
+void KVCache::set_window_size(size_t window, size_t sink) {
+    window_size = window;
+    sink_size = sink;
+    if (num_kv_heads > 0 && head_dim > 0 && window_size > 0) {
+        const size_t G = (head_dim + CACTUS_KV_QUANT_GROUP_SIZE - 1) / CACTUS_KV_QUANT_GROUP_SIZE;
+        const size_t eb = window_size * num_kv_heads * head_dim, ns = window_size * num_kv_heads * G;
+        const std::vector<float> ones(ns, 1.0f);
+        for (auto& c : layer_caches) {
+            ensure_capacity(c, window_size);
+            hip_check(hipMemset(c.keys, 0, eb), "hipMemset (kv keys)");
+            hip_check(hipMemset(c.values, 0, eb), "hipMemset (kv values)");
+            hip_check(hipMemcpy(c.key_scales, ones.data(), ns * sizeof(float), hipMemcpyHostToDevice), "kv scales");
+            hip_check(hipMemcpy(c.value_scales, ones.data(), ns * sizeof(float), hipMemcpyHostToDevice), "kv scales");
+            c.size_tokens = window_size;
+        }
+    }
+}
+
+void KVCache::reset() {
+    current_seq_len = 0;
+    total_seq_len = 0;
+}
+
+const int8_t* KVCache::get_keys_int8(size_t layer) const {
+    return (current_seq_len == 0 || layer >= num_layers) ? nullptr : layer_caches[layer].keys;
+}
+const int8_t* KVCache::get_values_int8(size_t layer) const {
+    return (current_seq_len == 0 || layer >= num_layers) ? nullptr : layer_caches[layer].values;
+}
+const float* KVCache::get_key_scales(size_t layer) const {
+    return (current_seq_len == 0 || layer >= num_layers) ? nullptr : layer_caches[layer].key_scales;
+}
+const float* KVCache::get_value_scales(size_t layer) const {
+    return (current_seq_len == 0 || layer >= num_layers) ? nullptr : layer_caches[layer].value_scales;
+}
+
+// engine_cache.cpp:101-337.  A layer's K/V node holds either every token so far
+// (old + new, :136-233) or only the new ones (:234-329); the first test wins when both match.
+// Tokens are quantized on the device straight into their slots.  Once the window is full the
+// recent region slides down by seq_len tokens (the reference memmoves, :284-301); an appended
+// chunk that does not fit beside the sink tokens makes the reference's unsigned
+// tokens_to_shift wrap (:276) and is rejected here instead.
+void KVCache::update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_nodes,
+                                const std::vector<size_t>& v_nodes, size_t seq_len, size_t layers,
+                                size_t kv_heads, size_t dim) {
+    const size_t old_seq_len = current_seq_len;
+    const size_t new_total_len = old_seq_len + seq_len;
+    const size_t ept = kv_heads * dim;
+    const size_t G = (dim + CACTUS_KV_QUANT_GROUP_SIZE - 1) / CACTUS_KV_QUANT_GROUP_SIZE;
+    const size_t spt = kv_heads * G;
+    const bool sliding = window_size > 0 && new_total_len > window_size;
+    if (layers > layer_caches.size() || k_nodes.size() < layers || v_nodes.size() < layers)
+        throw std::invalid_argument("KVCache: fewer layer caches or K/V nodes than layers");
+    if (kv_heads != num_kv_heads || dim != head_dim)
+        throw std::invalid_argument("KVCache: kv_heads/head_dim differ from init()");
+    if (sliding && sink_size > window_size)
+        throw std::runtime_error("KVCache: sink larger than the window");
+
+    auto quant = [&](const cactus_half_t* src, size_t src_token, LayerCache& c, bool keys, size_t dst_token,
+                     size_t tokens) {
+        if (tokens == 0) return;
+        int8_t* d = (keys ? c.keys : c.values) + dst_token * ept;
+        float* sc = (keys ? c.key_scales : c.value_scales) + dst_token * spt;
+        abi_check(cactus_hip_quantize_kv_fp16_to_int8_dev(src + src_token * ept, d, sc, tokens, kv_heads, dim,
+                                                          CACTUS_KV_QUANT_GROUP_SIZE, nullptr));
+    };
+
+    // validate before any state changes
+    std::vector<int> mode(layers, 0);   // 0 skip, 1 whole sequence, 2 new tokens only
+    for (size_t l = 0; l < layers; l++) {
+        const BufferDesc& kb = gb->get_output_buffer(k_nodes[l]);
+        const BufferDesc& vb = gb->get_output_buffer(v_nodes[l]);
+        if (!gb->get_device_output(k_nodes[l]) || !gb->get_device_output(v_nodes[l])) continue;
+        if (kb.precision != Precision::FP16 || vb.precision != Precision::FP16)
+            throw std::runtime_error("KVCache: K/V nodes must be FP16");
+        if (kb.total_size == new_total_len * ept && vb.total_size == new_total_len * ept) mode[l] = 1;
+        else if (kb.total_size == seq_len * ept && vb.total_size == seq_len * ept) mode[l] = 2;
+        if (mode[l] == 2 && sliding && seq_len + sink_size > window_size)
+            throw std::runtime_error("KVCache: appended chunk does not fit the window beside the sink tokens");
+    }
+
+    total_seq_len += seq_len;
+    bool any = false;
+    void* scratch = nullptr;
+    for (size_t l = 0; l < layers; l++) {
+        if (!mode[l]) continue;
+        any = true;
+        auto* ksrc = static_cast<const cactus_half_t*>(gb->get_device_output(k_nodes[l]));
+        auto* vsrc = static_cast<const cactus_half_t*>(gb->get_device_output(v_nodes[l]));
+        LayerCache& c = layer_caches[l];
+        if (mode[l] == 1) {
+            if (!sliding) {
+                ensure_capacity(c, new_total_len);
+                quant(ksrc, 0, c, true, 0, new_total_len);
+                quant(vsrc, 0, c, false, 0, new_total_len);
+                c.size_tokens = new_total_len;
+            } else {
+                ensure_capacity(c, window_size);
+                const size_t remaining_window = window_size - sink_size;
+                const size_t skip_tokens = new_total_len - window_size;
+                const bool first_slide = c.size_tokens != window_size;
+                if (first_slide) {
+                    quant(ksrc, 0, c, true, 0, sink_size);
+                    quant(vsrc, 0, c, false, 0, sink_size);
+                }
+                quant(ksrc, sink_size + skip_tokens, c, true, sink_size, remaining_window);
+                quant(vsrc, sink_size + skip_tokens, c, false, sink_size, remaining_window);
+                c.size_tokens = window_size;
+            }
+            continue;
+        }
+        size_t dst_token;
+        if (!sliding) {
+            ensure_capacity(c, new_total_len);
+            dst_token = old_seq_len;
+            c.size_tokens = new_total_len;
+        } else {
+            ensure_capacity(c, window_size);
+            c.size_tokens = window_size;
+            const size_t tokens_to_shift = window_size - sink_size - seq_len;
+            if (tokens_to_shift > 0 && old_seq_len > sink_size) {
+                const size_t shift_src = old_seq_len - tokens_to_shift;
+                if (shift_src > sink_size) {
+                    // overlapping move toward lower addresses: stage through scratch
+                    const size_t eb = tokens_to_shift * ept, sb = tokens_to_shift * spt * sizeof(float);
+                    if (!scratch) scratch = dev_alloc(std::max(eb, sb));
+                    auto move = [&](void* base, size_t dst_off, size_t src_off, size_t bytes) {
+                        hip_check(hipMemcpyAsync(scratch, static_cast<char*>(base) + src_off, bytes,
+                                                 hipMemcpyDeviceToDevice, nullptr), "kv shift");
+                        hip_check(hipMemcpyAsync(static_cast<char*>(base) + dst_off, scratch, bytes,
+                                                 hipMemcpyDeviceToDevice, nullptr), "kv shift");
+                    };
+                    move(c.keys, sink_size * ept, shift_src * ept, eb);
+                    move(c.values, sink_size * ept, shift_src * ept, eb);
+                    move(c.key_scales, sink_size * spt * sizeof(float), shift_src * spt * sizeof(float), sb);
+                    move(c.value_scales, sink_size * spt * sizeof(float), shift_src * spt * sizeof(float), sb);
+                }
+            }
+            dst_token = window_size - seq_len;
+        }
+        quant(ksrc, 0, c, true, dst_token, seq_len);
+        quant(vsrc, 0, c, false, dst_token, seq_len);
+    }
+    if (scratch) {
+        (void)hipStreamSynchronize(nullptr);
+        (void)hipFree(scratch);
+    }
+    if (any) current_seq_len = sliding ? window_size : new_total_len;
+}
+
+}  // namespace cactus_hip
+
+// ------------------------------------------------------------------------- C ABI wrappers
+using cactus_hip::CactusGraph;
+using cactus_hip::KVCache;
+using cactus_hip::Precision;
+
+namespace cactus_hip { void set_last_error(const char* msg); }
+
+template <class R, class F>
+static R guarded(R failval, F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        cactus_hip::set_last_error(e.what());
+        return failval;
+    }
+}
+#define G_(g) static_cast<CactusGraph*>(g)
+#define K_(c) static_cast<KVCache*>(c)
+
+extern "C" {
+
+void* cactus_hip_graph_create(void) { return new CactusGraph(); }
+void cactus_hip_graph_destroy(void* g) { delete G_(g); }
+
+long cactus_hip_graph_input(void* g, const size_t* shape, size_t ndim, int precision) {
+    return guarded<long>(-1, [&] {
+        return (long)G_(g)->input(std::vector<size_t>(shape, shape + ndim), static_cast<Precision>(precision));
+    });
+}
+long cactus_hip_graph_matmul(void* g, size_t a, size_t b, int pretransposed_rhs) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->matmul(a, b, pretransposed_rhs != 0); });
+}
+long cactus_hip_graph_quantize_activations(void* g, size_t input) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->quantize_activations(input); });
+}
+long cactus_hip_graph_attention(void* g, size_t q, size_t k, size_t v, float scale, size_t position_offset,
+                                size_t window_size, int is_causal) {
+    return guarded<long>(-1, [&] {
+        if (!is_causal) return (long)G_(g)->attention(q, k, v, scale, false);
+        return (long)G_(g)->attention(q, k, v, scale, position_offset, window_size);
+    });
+}
+long cactus_hip_graph_attention_int8_hybrid(void* g, size_t q, size_t key_new, size_t value_new, float scale,
+                                            size_t position_offset, const int8_t* cached_keys,
+                                            const int8_t* cached_values, const float* k_scales,
+                                            const float* v_scales, size_t cache_len, size_t num_kv_heads,
+                                            size_t head_dim) {
+    return guarded<long>(-1, [&] {
+        return (long)G_(g)->attention_int8_hybrid(q, key_new, value_new, scale, position_offset, cached_keys,
+                                                  cached_values, k_scales, v_scales, cache_len, num_kv_heads,
+                                                  head_dim);
+    });
+}
+int cactus_hip_graph_set_input(void* g, size_t node, const void* data, int precision) {
+    return guarded<int>(-1, [&] { G_(g)->set_input(node, data, static_cast<Precision>(precision)); return 0; });
+}
+int cactus_hip_graph_set_external_input(void* g, size_t node, void* data, int precision) {
+    return guarded<int>(-1, [&] {
+        G_(g)->set_external_input(node, data, static_cast<Precision>(precision));
+        return 0;
+    });
+}
+int cactus_hip_graph_set_grouped_scales(void* g, size_t node, size_t group_size, size_t num_groups, void* scales) {
+    return guarded<int>(-1, [&] { G_(g)->set_grouped_scales(node, group_size, num_groups, scales); return 0; });
+}
+int cactus_hip_graph_set_packed_int4(void* g, size_t node, const void* packed, size_t bytes) {
+    return guarded<int>(-1, [&] { G_(g)->set_packed_int4(node, packed, bytes); return 0; });
+}
+int cactus_hip_graph_execute(void* g) {
+    return guarded<int>(-1, [&] { G_(g)->execute(); return 0; });
+}
+int cactus_hip_graph_get_output(void* g, size_t node, void* dst, size_t bytes) {
+    return guarded<int>(-1, [&] {
+        void* p = G_(g)->get_output(node);
+        if (!p) throw std::runtime_error("node has no output");
+        if (bytes > G_(g)->get_output_buffer(node).byte_size) throw std::runtime_error("output smaller than request");
+        std::memcpy(dst, p, bytes);
+        return 0;
+    });
+}
+void* cactus_hip_graph_get_device_output(void* g, size_t node) {
+    return guarded<void*>(nullptr, [&] { return G_(g)->get_device_output(node); });
+}
+int cactus_hip_graph_soft_reset(void* g) {
+    return guarded<int>(-1, [&] { G_(g)->soft_reset(); return 0; });
+}
+int cactus_hip_graph_hard_reset(void* g) {
+    return guarded<int>(-1, [&] { G_(g)->hard_reset(); return 0; });
+}
+size_t cactus_hip_graph_node_count(void* g) { return G_(g)->get_node_count(); }
+
+void* cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim) {
+    auto* c = new KVCache();
+    c->init(layers, max_seq, kv_heads, head_dim);
+    return c;
+}
+void cactus_hip_kvcache_destroy(void* c) { delete K_(c); }
+int cactus_hip_kvcache_set_window(void* c, size_t window, size_t sink) {
+    return guarded<int>(-1, [&] { K_(c)->set_window_size(window, sink); return 0; });
+}
+void cactus_hip_kvcache_reset(void* c) { K_(c)->reset(); }
+int cactus_hip_kvcache_update(void* c, void* g, const size_t* k_nodes, const size_t* v_nodes, size_t seq_len) {
+    return guarded<int>(-1, [&] {
+        KVCache* kc = K_(c);
+        std::vector<size_t> k(k_nodes, k_nodes + kc->num_layers), v(v_nodes, v_nodes + kc->num_layers);
+        kc->update_from_graph(G_(g), k, v, seq_len, kc->num_layers, kc->num_kv_heads, kc->head_dim);
+        return 0;
+    });
+}
+size_t cactus_hip_kvcache_len(void* c) { return K_(c)->get_effective_seq_len(); }
+size_t cactus_hip_kvcache_total_len(void* c) { return K_(c)->get_total_seq_len(); }
+const int8_t* cactus_hip_kvcache_keys(void* c, size_t layer) { return K_(c)->get_keys_int8(layer); }
+const int8_t* cactus_hip_kvcache_values(void* c, size_t layer) { return K_(c)->get_values_int8(layer); }
+const float* cactus_hip_kvcache_key_scales(void* c, size_t layer) { return K_(c)->get_key_scales(layer); }
+const float* cactus_hip_kvcache_value_scales(void* c, size_t layer) { return K_(c)->get_value_scales(layer); }
+
+}  // extern "C"

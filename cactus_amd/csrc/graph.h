@@ -1,0 +1,198 @@
+// Host-side mirror of the slice of cactus/graph that drives the quantized hot path, with a
+// device-buffer path added: the same builder calls (input / matmul / attention /
+// attention_int8_hybrid / quantize_activations / set_grouped_scales / set_input / execute /
+// get_output) and the same error behaviour as the reference's CactusGraph
+// (cactus/graph/graph.h:386-500, graph_builder.cpp:61-81, 286-316, 560-596;
+// dispatch in graph_ops_nn.cpp:129-231, 302-371), but every node buffer lives in HBM and the
+// node kernels are the *_dev entry points of include/cactus_hip.h.
+//
+// Differences that are deliberate:
+//   * BufferDesc carries a device pointer next to the host pointer and a residency flag; host
+//     inputs are uploaded once per set_input, weights (set_external_input) once per pointer.
+//   * the activation-quantization cache is keyed by node id, not by host pointer
+//     (graph_ops_nn.cpp:15-17, 36-38 keys on the pointer and can go stale).
+//   * packed INT4 weights stay packed in HBM (the reference unpacks them to INT8 at load,
+//     graph_io.cpp:435-463); results are identical.
+//   * KVCache keeps its INT8 payload and fp32 scales in HBM and quantizes appended tokens with
+//     the device kernel; window/sink bookkeeping follows engine_cache.cpp:101-337.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace cactus_hip {
+
+enum class Precision { INT8 = 0, FP16 = 1, FP32 = 2, INT4 = 3 };   // values as graph.h:99-104
+enum class ComputeBackend { CPU = 0, NPU = 1, HIP = 2 };           // HIP is the additive enumerator
+enum class OpType { INPUT, MATMUL, ATTENTION, ATTENTION_INT8_HYBRID, QUANTIZE_ACTIVATIONS };
+
+size_t precision_size(Precision p);   // bytes per element (INT4 counted as 1, graph.h:128-136)
+
+struct BufferDesc {
+    std::vector<size_t> shape;
+    size_t total_size = 0;   // elements
+    size_t byte_size = 0;
+    Precision precision = Precision::FP16;
+
+    void* device_data = nullptr;     // HBM; owned unless external_device
+    bool owns_device = false;
+    bool device_valid = false;       // device_data holds the node's current value
+    std::vector<char> host_copy;     // filled by get_output()
+
+    // grouped weight quantization (graph.h:203-209)
+    size_t group_size = 0, num_groups = 0;
+    void* scales_device = nullptr;   // fp16 [N, num_groups]
+    bool owns_scales = false;
+    void* packed_int4_device = nullptr;   // uint8 [N, K/2]
+    size_t packed_int4_size = 0;
+
+    // per-row activation scales of a QUANTIZE_ACTIVATIONS output (graph.h:211-213)
+    void* activation_scales_device = nullptr;
+    size_t num_rows_for_activation_scales = 0;
+
+    bool is_grouped_int8() const { return precision == Precision::INT8 && group_size > 0; }
+    bool is_packed_int4() const { return packed_int4_device != nullptr && packed_int4_size > 0; }
+    bool has_activation_scales() const {
+        return activation_scales_device != nullptr && num_rows_for_activation_scales > 0;
+    }
+};
+
+struct OpParams {
+    float scale = 1.0f;
+    bool pretransposed_rhs = false;
+    size_t position_offset = 0;
+    size_t window_size = 0;
+    bool is_causal = true;
+    Precision output_precision = Precision::INT8;
+    ComputeBackend backend = ComputeBackend::HIP;
+    // device pointers into the INT8 KV cache (graph.h:314-320 carries host pointers)
+    const int8_t* cached_keys_int8 = nullptr;
+    const int8_t* cached_values_int8 = nullptr;
+    const float* cached_k_scales = nullptr;
+    const float* cached_v_scales = nullptr;
+    size_t cache_seq_len = 0;
+    size_t num_kv_heads = 0;
+    size_t head_dim = 0;
+};
+
+struct GraphNode {
+    size_t id;
+    OpType op_type;
+    std::vector<size_t> input_ids;
+    BufferDesc output_buffer;
+    OpParams params;
+};
+
+class CactusGraph {
+public:
+    CactusGraph();
+    ~CactusGraph();
+    CactusGraph(const CactusGraph&) = delete;
+    CactusGraph& operator=(const CactusGraph&) = delete;
+
+    size_t input(const std::vector<size_t>& shape, Precision precision = Precision::INT8);
+    size_t quantize_activations(size_t input);
+    size_t matmul(size_t input1, size_t input2, bool pretransposed_rhs = false,
+                  ComputeBackend backend = ComputeBackend::HIP);
+    size_t attention(size_t query, size_t key, size_t value, float scale, bool is_causal = true,
+                     ComputeBackend backend = ComputeBackend::HIP);
+    size_t attention(size_t query, size_t key, size_t value, float scale, size_t position_offset,
+                     ComputeBackend backend = ComputeBackend::HIP);
+    size_t attention(size_t query, size_t key, size_t value, float scale, size_t position_offset,
+                     size_t window_size, ComputeBackend backend = ComputeBackend::HIP);
+    size_t attention_int8_hybrid(size_t query, size_t key_new, size_t value_new, float scale,
+                                 size_t position_offset, const int8_t* cached_keys,
+                                 const int8_t* cached_values, const float* k_scales, const float* v_scales,
+                                 size_t cache_len, size_t num_kv_heads, size_t head_dim);
+
+    // Host data: copied to HBM now (set_input) or once per distinct pointer and kept resident
+    // (set_external_input: weights that outlive the graph's steps).
+    void set_input(size_t node_id, const void* data, Precision precision);
+    void set_external_input(size_t node_id, void* data, Precision precision);
+    // Device data owned by the caller (already resident).
+    void set_device_input(size_t node_id, void* device_ptr, Precision precision);
+    // Group scales (fp16 [N, num_groups], host pointer; uploaded once per pointer).
+    void set_grouped_scales(size_t node_id, size_t group_size, size_t num_groups, void* scales_ptr);
+    // Packed INT4 payload for a weight node (uint8 [N, K/2], host pointer): what
+    // MappedFile::load_into_graph sets (graph_io.cpp:470-495), kept packed on the device.
+    void set_packed_int4(size_t node_id, const void* packed, size_t packed_bytes);
+
+    void execute();
+    void* get_output(size_t node_id);          // host copy, synchronises
+    void* get_device_output(size_t node_id);   // device pointer, no synchronisation
+    const BufferDesc& get_output_buffer(size_t node_id) const;
+    size_t get_node_count() const { return nodes_.size(); }
+    void hard_reset();
+    void soft_reset();   // drops every node that is not a weight (external) input
+
+    size_t add_node(OpType op_type, const std::vector<size_t>& inputs,
+                    const std::vector<size_t>& output_shape, const OpParams& params = {});
+
+private:
+    GraphNode& node(size_t id);
+    const GraphNode& node(size_t id) const;
+    void ensure_device(BufferDesc& b);
+    void* resident_copy(const void* host, size_t bytes);
+    void compute_matmul_node(GraphNode& n);
+    void compute_attention_node(GraphNode& n);
+    void compute_attention_int8_hybrid_node(GraphNode& n);
+    void compute_quantize_activations_node(GraphNode& n);
+
+    std::vector<std::unique_ptr<GraphNode>> nodes_;
+    std::unordered_map<size_t, size_t> node_index_map_;
+    size_t next_node_id_ = 0;
+    std::unordered_map<size_t, bool> is_weight_;   // node id -> bound with set_external_input
+    // host pointer -> resident device copy (weights, scales)
+    struct Resident { void* dev; size_t bytes; };
+    std::unordered_map<const void*, Resident> resident_;
+    // activation quantization shared by the matmuls that read one FP16 node (keyed by node id)
+    struct QuantCache { void* q = nullptr; void* scales = nullptr; size_t M = 0, K = 0; };
+    std::unordered_map<size_t, QuantCache> quant_cache_;
+};
+
+// INT8 KV cache resident in HBM: per layer keys/values int8 [slot, Hkv, D] and fp32 scales
+// [slot, Hkv, ceil(D/128)], slots 0..sink-1 = first tokens, the rest = most recent tokens
+// (engine.h:324-381, engine_cache.cpp:11-51, 101-337).
+struct KVCache {
+    struct LayerCache {
+        int8_t* keys = nullptr;
+        int8_t* values = nullptr;
+        float* key_scales = nullptr;
+        float* value_scales = nullptr;
+        size_t capacity_tokens = 0;   // allocated slots
+        size_t size_tokens = 0;       // logical slots (the reference's keys.size() in tokens)
+    };
+    size_t num_layers = 0, max_seq_len = 0, num_kv_heads = 0, head_dim = 0;
+    size_t window_size = 0, sink_size = 4;
+    size_t current_seq_len = 0;   // tokens held (<= window)
+    size_t total_seq_len = 0;     // tokens seen (RoPE / position offset)
+    std::vector<LayerCache> layer_caches;
+
+    ~KVCache();
+    void init(size_t layers, size_t max_seq, size_t kv_heads, size_t dim);
+    void set_window_size(size_t window, size_t sink);
+    void reset();
+    bool is_empty() const { return current_seq_len == 0; }
+    size_t get_effective_seq_len() const { return current_seq_len; }
+    size_t get_total_seq_len() const { return total_seq_len; }
+    const int8_t* get_keys_int8(size_t layer) const;
+    const int8_t* get_values_int8(size_t layer) const;
+    const float* get_key_scales(size_t layer) const;
+    const float* get_value_scales(size_t layer) const;
+    // Take seq_len new tokens per layer from graph nodes holding FP16 K/V, either the whole
+    // sequence [old+new, Hkv, D] or only the new tokens [seq_len, Hkv, D]
+    // (engine_cache.cpp:101-337).
+    void update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_nodes,
+                           const std::vector<size_t>& v_nodes, size_t seq_len, size_t layers,
+                           size_t kv_heads, size_t dim);
+
+private:
+    void ensure_capacity(LayerCache& c, size_t tokens);
+};
+
+}  // namespace cactus_hip

@@ -45,6 +45,8 @@ hipError_t launch_matmul_generic(bool int4, const int8_t* A, const float* A_scal
 hipError_t launch_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K,
                              size_t N, hipStream_t st);
 
+hipError_t launch_transpose_f16(const uint16_t* src, uint16_t* dst, size_t R, size_t C, hipStream_t st);
+
 // attention.hip
 struct AttnArgs {
     const uint16_t* q;

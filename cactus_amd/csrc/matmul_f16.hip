@@ -78,6 +78,26 @@ __global__ __launch_bounds__(256) void matmul_f16_kernel(const uint16_t* __restr
             }
 }
 
+// dst[c][r] = src[r][c] for a row-major [R, C] half matrix (32x32 tiles through LDS).
+__global__ __launch_bounds__(256) void transpose_f16_kernel(const uint16_t* __restrict__ src,
+                                                           uint16_t* __restrict__ dst, int R, int C) {
+    __shared__ uint16_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(size_t)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+hipError_t launch_transpose_f16(const uint16_t* src, uint16_t* dst, size_t R, size_t C, hipStream_t st) {
+    if (R == 0 || C == 0) return hipSuccess;
+    const dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
+    transpose_f16_kernel<<<grid, dim3(256), 0, st>>>(src, dst, (int)R, (int)C);
+    return hipGetLastError();
+}
+
 hipError_t launch_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K,
                              size_t N, hipStream_t st) {
     const int vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&

@@ -1,0 +1,215 @@
+"""Python view of the C ABI in include/cactus_hip_graph.h: the device-resident mirror of the
+reference's CactusGraph / KVCache for the hot path (cactus_amd/csrc/graph.h).  Host arrays are
+numpy; node ids are the graph's own.  Method names and argument meaning follow
+cactus/graph/graph.h:386-500 and cactus/engine/engine.h:324-381."""
+import ctypes as C
+
+import numpy as np
+
+from .hip import lib, CactusHipError
+
+INT8, FP16, FP32, INT4 = 0, 1, 2, 3
+
+_sz, _vp, _i, _f, _l = C.c_size_t, C.c_void_p, C.c_int, C.c_float, C.c_long
+_szp = C.POINTER(C.c_size_t)
+
+GRAPH_SIGNATURES = {
+    "cactus_hip_graph_create": (_vp, []),
+    "cactus_hip_graph_destroy": (None, [_vp]),
+    "cactus_hip_graph_input": (_l, [_vp, _szp, _sz, _i]),
+    "cactus_hip_graph_matmul": (_l, [_vp, _sz, _sz, _i]),
+    "cactus_hip_graph_quantize_activations": (_l, [_vp, _sz]),
+    "cactus_hip_graph_attention": (_l, [_vp, _sz, _sz, _sz, _f, _sz, _sz, _i]),
+    "cactus_hip_graph_attention_int8_hybrid": (_l, [_vp, _sz, _sz, _sz, _f, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]),
+    "cactus_hip_graph_set_input": (_i, [_vp, _sz, _vp, _i]),
+    "cactus_hip_graph_set_external_input": (_i, [_vp, _sz, _vp, _i]),
+    "cactus_hip_graph_set_grouped_scales": (_i, [_vp, _sz, _sz, _sz, _vp]),
+    "cactus_hip_graph_set_packed_int4": (_i, [_vp, _sz, _vp, _sz]),
+    "cactus_hip_graph_execute": (_i, [_vp]),
+    "cactus_hip_graph_get_output": (_i, [_vp, _sz, _vp, _sz]),
+    "cactus_hip_graph_get_device_output": (_vp, [_vp, _sz]),
+    "cactus_hip_graph_soft_reset": (_i, [_vp]),
+    "cactus_hip_graph_hard_reset": (_i, [_vp]),
+    "cactus_hip_graph_node_count": (_sz, [_vp]),
+    "cactus_hip_kvcache_create": (_vp, [_sz, _sz, _sz, _sz]),
+    "cactus_hip_kvcache_destroy": (None, [_vp]),
+    "cactus_hip_kvcache_set_window": (_i, [_vp, _sz, _sz]),
+    "cactus_hip_kvcache_reset": (None, [_vp]),
+    "cactus_hip_kvcache_update": (_i, [_vp, _vp, _szp, _szp, _sz]),
+    "cactus_hip_kvcache_len": (_sz, [_vp]),
+    "cactus_hip_kvcache_total_len": (_sz, [_vp]),
+    "cactus_hip_kvcache_keys": (_vp, [_vp, _sz]),
+    "cactus_hip_kvcache_values": (_vp, [_vp, _sz]),
+    "cactus_hip_kvcache_key_scales": (_vp, [_vp, _sz]),
+    "cactus_hip_kvcache_value_scales": (_vp, [_vp, _sz]),
+}
+for _name, (_res, _args) in GRAPH_SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+_ITEMSIZE = {INT8: 1, FP16: 2, FP32: 4, INT4: 1}
+_NPTYPE = {INT8: np.int8, FP16: np.float16, FP32: np.float32}
+
+
+def _err():
+    return CactusHipError(lib.cactus_hip_last_error().decode())
+
+
+def _node(rc):
+    if rc < 0:
+        raise _err()
+    return int(rc)
+
+
+def _ok(rc):
+    if rc != 0:
+        raise _err()
+
+
+class CactusGraph:
+    def __init__(self):
+        self._g = lib.cactus_hip_graph_create()
+        self._keep = []      # host arrays whose addresses key resident device copies
+        self._shapes = {}
+
+    def close(self):
+        if self._g:
+            lib.cactus_hip_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        self.close()
+
+    def input(self, shape, precision=INT8):
+        arr = (C.c_size_t * len(shape))(*shape)
+        n = _node(lib.cactus_hip_graph_input(self._g, arr, len(shape), precision))
+        self._shapes[n] = (tuple(shape), precision)
+        return n
+
+    def matmul(self, a, b, pretransposed_rhs=False):
+        n = _node(lib.cactus_hip_graph_matmul(self._g, a, b, int(pretransposed_rhs)))
+        M = self._shapes[a][0][0]
+        N = self._shapes[b][0][0] if pretransposed_rhs else self._shapes[b][0][1]
+        self._shapes[n] = ((M, N), FP16)
+        return n
+
+    def quantize_activations(self, x):
+        n = _node(lib.cactus_hip_graph_quantize_activations(self._g, x))
+        self._shapes[n] = (self._shapes[x][0], INT8)
+        return n
+
+    def attention(self, q, k, v, scale, position_offset=0, window_size=0, is_causal=True):
+        n = _node(lib.cactus_hip_graph_attention(self._g, q, k, v, scale, position_offset, window_size,
+                                                 int(is_causal)))
+        self._shapes[n] = (self._shapes[q][0], FP16)
+        return n
+
+    def attention_int8_hybrid(self, q, key_new, value_new, scale, position_offset, cached_keys, cached_values,
+                              k_scales, v_scales, cache_len, num_kv_heads, head_dim):
+        n = _node(lib.cactus_hip_graph_attention_int8_hybrid(
+            self._g, q, key_new, value_new, scale, position_offset, cached_keys, cached_values, k_scales,
+            v_scales, cache_len, num_kv_heads, head_dim))
+        self._shapes[n] = (self._shapes[q][0], FP16)
+        return n
+
+    def set_input(self, node, data, precision=None):
+        a = np.ascontiguousarray(data)
+        _ok(lib.cactus_hip_graph_set_input(self._g, node, a.ctypes.data_as(C.c_void_p),
+                                           self._shapes[node][1] if precision is None else precision))
+
+    def set_external_input(self, node, data, precision=None):
+        a = np.ascontiguousarray(data)
+        self._keep.append(a)
+        _ok(lib.cactus_hip_graph_set_external_input(self._g, node, a.ctypes.data_as(C.c_void_p),
+                                                    self._shapes[node][1] if precision is None else precision))
+
+    def set_grouped_scales(self, node, group_size, num_groups, scales):
+        a = np.ascontiguousarray(scales)
+        self._keep.append(a)
+        _ok(lib.cactus_hip_graph_set_grouped_scales(self._g, node, group_size, num_groups,
+                                                    a.ctypes.data_as(C.c_void_p)))
+
+    def set_packed_int4(self, node, packed):
+        a = np.ascontiguousarray(packed)
+        self._keep.append(a)
+        _ok(lib.cactus_hip_graph_set_packed_int4(self._g, node, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def execute(self):
+        _ok(lib.cactus_hip_graph_execute(self._g))
+
+    def get_output(self, node):
+        shape, prec = self._shapes[node]
+        out = np.empty(shape, _NPTYPE[prec])
+        _ok(lib.cactus_hip_graph_get_output(self._g, node, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def soft_reset(self):
+        _ok(lib.cactus_hip_graph_soft_reset(self._g))
+
+    def hard_reset(self):
+        _ok(lib.cactus_hip_graph_hard_reset(self._g))
+        self._keep.clear()
+
+    def get_node_count(self):
+        return lib.cactus_hip_graph_node_count(self._g)
+
+
+class KVCache:
+    def __init__(self, num_layers, max_seq, num_kv_heads, head_dim):
+        self._c = lib.cactus_hip_kvcache_create(num_layers, max_seq, num_kv_heads, head_dim)
+        self.num_layers, self.num_kv_heads, self.head_dim = num_layers, num_kv_heads, head_dim
+
+    def close(self):
+        if self._c:
+            lib.cactus_hip_kvcache_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        self.close()
+
+    def set_window_size(self, window, sink=4):
+        _ok(lib.cactus_hip_kvcache_set_window(self._c, window, sink))
+
+    def reset(self):
+        lib.cactus_hip_kvcache_reset(self._c)
+
+    def update_from_graph(self, graph, k_nodes, v_nodes, seq_len):
+        k = (C.c_size_t * len(k_nodes))(*k_nodes)
+        v = (C.c_size_t * len(v_nodes))(*v_nodes)
+        _ok(lib.cactus_hip_kvcache_update(self._c, graph._g, k, v, seq_len))
+
+    def get_effective_seq_len(self):
+        return lib.cactus_hip_kvcache_len(self._c)
+
+    def get_total_seq_len(self):
+        return lib.cactus_hip_kvcache_total_len(self._c)
+
+    def get_keys_int8(self, layer):
+        return lib.cactus_hip_kvcache_keys(self._c, layer)
+
+    def get_values_int8(self, layer):
+        return lib.cactus_hip_kvcache_values(self._c, layer)
+
+    def get_key_scales(self, layer):
+        return lib.cactus_hip_kvcache_key_scales(self._c, layer)
+
+    def get_value_scales(self, layer):
+        return lib.cactus_hip_kvcache_value_scales(self._c, layer)
+
+    def download(self, layer):
+        """(keys int8 [len,Hkv,D], key scales, values, value scales) of one layer as numpy."""
+        L = self.get_effective_seq_len()
+        G = (self.head_dim + 127) // 128
+        out = []
+        for ptr, shape, dt in ((self.get_keys_int8(layer), (L, self.num_kv_heads, self.head_dim), np.int8),
+                               (self.get_key_scales(layer), (L, self.num_kv_heads, G), np.float32),
+                               (self.get_values_int8(layer), (L, self.num_kv_heads, self.head_dim), np.int8),
+                               (self.get_value_scales(layer), (L, self.num_kv_heads, G), np.float32)):
+            a = np.empty(shape, dt)
+            if L:
+                rc = lib.cactus_hip_memcpy_d2h(a.ctypes.data_as(C.c_void_p), ptr, a.nbytes, None)
+                if rc != 0:
+                    raise _err()
+            out.append(a)
+        return tuple(out)

@@ -1,0 +1,76 @@
+/*
+ * cactus_hip_graph.h -- C ABI over the device-resident mirror of the reference's graph layer
+ * for the hot path (cactus_amd/csrc/graph.h).  One call per CactusGraph builder / executor
+ * method a model or test uses on this path; node ids are the graph's own ids.  Calls that the
+ * reference signals with a C++ exception return -1 (or NULL) here and leave the exception's
+ * message in cactus_hip_last_error().
+ *
+ *   CactusGraph::input                 graph.h:396   graph_builder.cpp:7-9
+ *   CactusGraph::matmul                graph.h:420   graph_builder.cpp:61-81
+ *   CactusGraph::quantize_activations  graph.h:398   graph_builder.cpp:560-570
+ *   CactusGraph::attention (x3)        graph.h:451-453  graph_builder.cpp:286-299
+ *   CactusGraph::attention_int8_hybrid graph.h:455-458  graph_builder.cpp:301-316
+ *   CactusGraph::set_input / set_external_input / get_output / execute
+ *                                      graph.h:469-473  graph_execute.cpp:197-253
+ *   CactusGraph::set_grouped_scales    graph.h:437   graph_io.cpp:106-112
+ *   CactusGraph::soft_reset / hard_reset  graph.h:474-475  graph_execute.cpp:629-675
+ *   KVCache::init / set_window_size / reset / update_from_graph / get_*
+ *                                      engine.h:324-381  engine_cache.cpp:11-51, 101-337
+ *
+ * Precision values: 0 INT8, 1 FP16, 2 FP32, 3 INT4 (graph.h:99-104).
+ */
+#ifndef CACTUS_HIP_GRAPH_H
+#define CACTUS_HIP_GRAPH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void*  cactus_hip_graph_create(void);
+void   cactus_hip_graph_destroy(void* graph);
+long   cactus_hip_graph_input(void* graph, const size_t* shape, size_t ndim, int precision);
+long   cactus_hip_graph_matmul(void* graph, size_t a, size_t b, int pretransposed_rhs);
+long   cactus_hip_graph_quantize_activations(void* graph, size_t input);
+long   cactus_hip_graph_attention(void* graph, size_t q, size_t k, size_t v, float scale,
+                                  size_t position_offset, size_t window_size, int is_causal);
+/* cached_* are DEVICE pointers (e.g. from cactus_hip_kvcache_keys). */
+long   cactus_hip_graph_attention_int8_hybrid(void* graph, size_t q, size_t key_new, size_t value_new,
+                                              float scale, size_t position_offset,
+                                              const int8_t* cached_keys, const int8_t* cached_values,
+                                              const float* k_scales, const float* v_scales,
+                                              size_t cache_len, size_t num_kv_heads, size_t head_dim);
+int    cactus_hip_graph_set_input(void* graph, size_t node, const void* host_data, int precision);
+int    cactus_hip_graph_set_external_input(void* graph, size_t node, void* host_data, int precision);
+int    cactus_hip_graph_set_grouped_scales(void* graph, size_t node, size_t group_size, size_t num_groups,
+                                           void* host_scales);
+/* Packed INT4 payload uint8[N, K/2] of a weight node (what MappedFile::load_into_graph sets,
+ * graph_io.cpp:470-495); it stays packed in HBM. */
+int    cactus_hip_graph_set_packed_int4(void* graph, size_t node, const void* host_packed, size_t bytes);
+int    cactus_hip_graph_execute(void* graph);
+int    cactus_hip_graph_get_output(void* graph, size_t node, void* host_dst, size_t bytes);
+void*  cactus_hip_graph_get_device_output(void* graph, size_t node);
+int    cactus_hip_graph_soft_reset(void* graph);
+int    cactus_hip_graph_hard_reset(void* graph);
+size_t cactus_hip_graph_node_count(void* graph);
+
+void*  cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim);
+void   cactus_hip_kvcache_destroy(void* cache);
+int    cactus_hip_kvcache_set_window(void* cache, size_t window, size_t sink);
+void   cactus_hip_kvcache_reset(void* cache);
+/* k_nodes / v_nodes: one node id per layer holding the new FP16 K/V [seq_len, Hkv, D]. */
+int    cactus_hip_kvcache_update(void* cache, void* graph, const size_t* k_nodes, const size_t* v_nodes,
+                                 size_t seq_len);
+size_t cactus_hip_kvcache_len(void* cache);
+size_t cactus_hip_kvcache_total_len(void* cache);
+const int8_t* cactus_hip_kvcache_keys(void* cache, size_t layer);
+const int8_t* cactus_hip_kvcache_values(void* cache, size_t layer);
+const float*  cactus_hip_kvcache_key_scales(void* cache, size_t layer);
+const float*  cactus_hip_kvcache_value_scales(void* cache, size_t layer);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CACTUS_HIP_GRAPH_H */

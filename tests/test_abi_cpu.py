@@ -6,8 +6,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "cactus_hip.h")).read()
+def _declared(header="cactus_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(cactus_hip_\w+)\s*\(", text)))
 
@@ -20,6 +20,36 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(H.lib, n), f"{n} declared in include/cactus_hip.h but not exported"
         assert n in H.SIGNATURES, f"{n} has no ctypes signature in cactus_amd/hip.py"
     assert sorted(H.SIGNATURES) == names
+
+
+def test_graph_library_exports_every_declared_symbol():
+    import cactus_amd.hip as H
+    import cactus_amd.graph as G
+    names = _declared("cactus_hip_graph.h")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(H.lib, n), f"{n} declared in include/cactus_hip_graph.h but not exported"
+    assert sorted(G.GRAPH_SIGNATURES) == names
+
+
+def test_graph_builder_errors_without_gpu():
+    """Shape validation happens at build time on the host (graph_builder.cpp:65-76): same
+    conditions, same messages, no GPU involved."""
+    import pytest
+    import cactus_amd.graph as G
+    g = G.CactusGraph()
+    a = g.input((2, 3), G.FP16)
+    b = g.input((4, 2), G.FP16)
+    with pytest.raises(Exception, match="Matrix dimensions incompatible"):
+        g.matmul(a, b, False)
+    c = g.input((2, 3, 1), G.FP16)
+    with pytest.raises(Exception, match="requires 2D tensors"):
+        g.matmul(c, a, False)
+    i8 = g.input((2, 3), G.INT8)
+    with pytest.raises(Exception, match="quantize_activations requires FP16 input"):
+        g.quantize_activations(i8)
+    assert g.get_node_count() == 4
+    g.close()
 
 
 def test_runtime_queries_work_without_gpu():

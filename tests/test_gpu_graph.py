@@ -1,0 +1,407 @@
+"""GPU tests of the graph / KV-cache mirror (cactus_amd/csrc/graph.cpp through the C ABI of
+include/cactus_hip_graph.h): the reference's own graph and KV-cache tests restated
+(tests/test_graph.cpp:75-90, 220-240; tests/test_kv_cache.cpp:21-254) plus parity of every
+dispatch branch of the matmul node (graph_ops_nn.cpp:129-231) against the CPU oracle.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import rand_weights_int8, rand_weights_int4, rand_act_f16
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def G():
+    import cactus_amd.hip as hip
+    hip.init(0)
+    import cactus_amd.graph as graph
+    return graph
+
+
+def u16(a):
+    return np.ascontiguousarray(a).view(np.uint16)
+
+
+# ---------------------------------------------------------------------------- matmul node
+def test_matrix_multiplication_kat(G):
+    """tests/test_graph.cpp:75-90: [2,3] x [3,2], rhs not pretransposed."""
+    g = G.CactusGraph()
+    a = g.input((2, 3), G.FP16)
+    b = g.input((3, 2), G.FP16)
+    c = g.matmul(a, b, False)
+    g.set_input(a, np.array([1, 2, 3, 4, 5, 6], np.float16))
+    g.set_input(b, np.array([1, 2, 3, 4, 5, 6], np.float16))
+    g.execute()
+    assert g.get_output(c).ravel().tolist() == [22, 28, 49, 64]
+    g.close()
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 1024), (4, 2048, 512), (16, 1024, 3072), (33, 512, 256)])
+@pytest.mark.parametrize("int4", [False, True])
+def test_matmul_node_quantized_weights_fp16_activations(G, M, K, N, int4):
+    """FP16 activations are quantized per row on the fly, then the grouped kernel runs
+    (graph_ops_nn.cpp:139-155, 169-185); fp16 outputs bit-exact with the oracle doing the same."""
+    rng = np.random.default_rng(M + K + N + int4)
+    x = rand_act_f16(rng, M, K)
+    g = G.CactusGraph()
+    xin = g.input((M, K), G.FP16)
+    w = g.input((N, K), G.INT8)
+    if int4:
+        Bp, Bs = rand_weights_int4(rng, N, K)
+        g.set_packed_int4(w, Bp)
+    else:
+        B, Bs = rand_weights_int8(rng, N, K)
+        g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, K // 128, Bs)
+    y = g.matmul(xin, w, True)
+    g.set_input(xin, x)
+    g.execute()
+    got = u16(g.get_output(y))
+    q, s = O.quantize_activations(x)
+    ref = O.matmul_int4(q, s, Bp, Bs, 128) if int4 else O.matmul_int8(q, s, B, Bs, 128)
+    assert (got == ref).all()
+    g.close()
+
+
+def test_matmul_node_prequantized_activations_shared_by_three_weights(G):
+    """quantize_activations once, q/k/v projections read the INT8 node and its row scales
+    (graph_ops_nn.cpp:78-127, 141-144)."""
+    rng = np.random.default_rng(7)
+    M, K = 3, 1024
+    x = rand_act_f16(rng, M, K)
+    g = G.CactusGraph()
+    xin = g.input((M, K), G.FP16)
+    xq = g.quantize_activations(xin)
+    outs, refs = [], []
+    q, s = O.quantize_activations(x)
+    for N in (1024, 256, 256):
+        B, Bs = rand_weights_int8(rng, N, K)
+        w = g.input((N, K), G.INT8)
+        g.set_external_input(w, B)
+        g.set_grouped_scales(w, 128, K // 128, Bs)
+        outs.append(g.matmul(xq, w, True))
+        refs.append(O.matmul_int8(q, s, B, Bs, 128))
+    g.set_input(xin, x)
+    g.execute()
+    assert (g.get_output(xq) == q).all()
+    for o, r in zip(outs, refs):
+        assert (u16(g.get_output(o)) == r).all()
+    g.close()
+
+
+def test_matmul_node_soft_reset_keeps_weights_and_requantizes(G):
+    """Decode loop shape: weights stay resident over soft_reset(); the activation-quantization
+    cache must not outlive a step (new activations at the same address give new results)."""
+    rng = np.random.default_rng(11)
+    K, N = 1024, 512
+    B, Bs = rand_weights_int8(rng, N, K)
+    g = G.CactusGraph()
+    w = g.input((N, K), G.INT8)
+    g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, K // 128, Bs)
+    x = np.empty((1, K), np.float16)
+    for step in range(3):
+        x[:] = rand_act_f16(rng, 1, K)          # same host buffer, new contents
+        xin = g.input((1, K), G.FP16)
+        y = g.matmul(xin, w, True)
+        g.set_input(xin, x)
+        g.execute()
+        q, s = O.quantize_activations(x)
+        assert (u16(g.get_output(y)) == O.matmul_int8(q, s, B, Bs, 128)).all()
+        g.soft_reset()
+        assert g.get_node_count() == 1
+    g.hard_reset()
+    assert g.get_node_count() == 0
+    g.close()
+
+
+def test_matmul_node_fp16_pretransposed(G):
+    rng = np.random.default_rng(5)
+    M, K, N = 7, 200, 50
+    a = rand_act_f16(rng, M, K)
+    bt = rand_act_f16(rng, N, K)
+    g = G.CactusGraph()
+    an = g.input((M, K), G.FP16)
+    bn = g.input((N, K), G.FP16)
+    c = g.matmul(an, bn, True)
+    g.set_input(an, a)
+    g.set_input(bn, bt)
+    g.execute()
+    got = g.get_output(c).astype(np.float64)
+    ref = a.astype(np.float64) @ bt.astype(np.float64).T
+    # fp32 accumulation, one fp16 rounding of the result
+    assert np.abs(got - ref).max() <= 2.0 ** -10 * np.abs(ref).max() + 1e-3
+    g.close()
+
+
+def test_matmul_node_errors(G):
+    """Messages of graph_ops_nn.cpp:160-167, 190-197."""
+    rng = np.random.default_rng(3)
+    B, Bs = rand_weights_int8(rng, 128, 128)
+    g = G.CactusGraph()
+    x = g.input((1, 128), G.FP16)
+    w = g.input((128, 128), G.INT8)
+    g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, 1, Bs)
+    g.matmul(x, w, False)
+    g.set_input(x, np.zeros((1, 128), np.float16))
+    with pytest.raises(Exception, match="Group-wise INT8 matmul requires pretransposed weights"):
+        g.execute()
+    g.hard_reset()
+    x = g.input((1, 128), G.FP32)
+    w = g.input((128, 128), G.INT8)
+    g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, 1, Bs)
+    g.matmul(x, w, True)
+    g.set_input(x, np.zeros((1, 128), np.float32))
+    with pytest.raises(Exception, match="INT8 matmul requires INT8 .pre-quantized. or FP16 activations"):
+        g.execute()
+    g.hard_reset()
+    x = g.input((1, 128), G.FP16)
+    y = g.input((1, 128), G.FP16)
+    g.matmul(x, y, True)
+    with pytest.raises(Exception, match="has no data"):
+        g.execute()
+    g.close()
+
+
+# ------------------------------------------------------------------------- attention nodes
+def test_attention_node_kat(G):
+    """tests/test_graph.cpp:220-240 (the reference only runs it; here the values are checked
+    against the oracle too)."""
+    g = G.CactusGraph()
+    q = g.input((1, 2, 1, 4), G.FP16)
+    k = g.input((1, 2, 1, 4), G.FP16)
+    v = g.input((1, 2, 1, 4), G.FP16)
+    o = g.attention(q, k, v, 0.5)
+    qd = np.array([1, 0, 0, 0, 0, 1, 0, 0], np.float16).reshape(1, 2, 1, 4)
+    vd = np.array([1, 2, 3, 4, 5, 6, 7, 8], np.float16).reshape(1, 2, 1, 4)
+    g.set_input(q, qd)
+    g.set_input(k, qd)
+    g.set_input(v, vd)
+    g.execute()
+    got = g.get_output(o).astype(np.float64)
+    ref = O.attention_f16(qd, qd, vd, 0.5).view(np.float16).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2e-3 + 4e-3 * np.abs(ref).max()
+    assert np.allclose(got[0, 0, 0], [1, 2, 3, 4])      # first query sees only the first key
+    g.close()
+
+
+def _fill_cache(G, g, cache, k, v, seq_len=None):
+    """Append FP16 [S, Hkv, D] per layer through graph input nodes, as Model::forward does."""
+    kn, vn = [], []
+    for l in range(cache.num_layers):
+        a = g.input(k[l].shape, G.FP16)
+        b = g.input(v[l].shape, G.FP16)
+        g.set_input(a, k[l])
+        g.set_input(b, v[l])
+        kn.append(a)
+        vn.append(b)
+    g.execute()
+    cache.update_from_graph(g, kn, vn, k[0].shape[0] if seq_len is None else seq_len)
+
+
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_hybrid_attention_node_over_kv_cache(G, D):
+    """Prefill into the INT8 cache, then one decode step with attention_int8_hybrid reading the
+    cache's device pointers (model_qwen.cpp:106-116 shape of the call)."""
+    rng = np.random.default_rng(D)
+    Hq, Hkv, S = 8, 2, 77
+    cache = G.KVCache(1, 2048, Hkv, D)
+    g = G.CactusGraph()
+    k = rng.normal(0, 1, (S, Hkv, D)).astype(np.float16)
+    v = rng.normal(0, 1, (S, Hkv, D)).astype(np.float16)
+    _fill_cache(G, g, cache, [k], [v])
+    assert cache.get_effective_seq_len() == S and cache.get_total_seq_len() == S
+    kq, ks, vq, vs = cache.download(0)
+    okq, oks = O.quantize_kv(k)
+    ovq, ovs = O.quantize_kv(v)
+    assert (kq == okq).all() and (vq == ovq).all()
+    assert (ks.view(np.uint32) == oks.view(np.uint32)).all() and (vs.view(np.uint32) == ovs.view(np.uint32)).all()
+
+    g.soft_reset()
+    qd = rng.normal(0, 1, (1, 1, Hq, D)).astype(np.float16)
+    knew = rng.normal(0, 1, (1, 1, Hkv, D)).astype(np.float16)
+    vnew = rng.normal(0, 1, (1, 1, Hkv, D)).astype(np.float16)
+    qn = g.input(qd.shape, G.FP16)
+    kn = g.input(knew.shape, G.FP16)
+    vn = g.input(vnew.shape, G.FP16)
+    scale = 1.0 / np.sqrt(D)
+    o = g.attention_int8_hybrid(qn, kn, vn, scale, S, cache.get_keys_int8(0), cache.get_values_int8(0),
+                                cache.get_key_scales(0), cache.get_value_scales(0), S, Hkv, D)
+    g.set_input(qn, qd)
+    g.set_input(kn, knew)
+    g.set_input(vn, vnew)
+    g.execute()
+    got = g.get_output(o).astype(np.float64)
+    ref = O.attention_hybrid(qd, okq[None], ovq[None], oks[None], ovs[None], knew, vnew, scale,
+                             position_offset=S).view(np.float16).astype(np.float64)
+    assert np.abs(got - ref).max() <= 2e-3 + 4e-3 * np.abs(ref).max()
+    g.close()
+    cache.close()
+
+
+# ------------------------------------------------------------------------------- KV cache
+def _const(S, H, D, val):
+    return np.full((S, H, D), val, np.float16)
+
+
+def test_sliding_window_basic(G):
+    """tests/test_kv_cache.cpp:21-130."""
+    L, Hkv, D, W, sink = 2, 8, 64, 16, 4
+    cache = G.KVCache(L, 2048, Hkv, D)
+    cache.set_window_size(W, sink)
+    g = G.CactusGraph()
+    _fill_cache(G, g, cache, [_const(10, Hkv, D, l + 1.0) for l in range(L)],
+                [_const(10, Hkv, D, l + 2.0) for l in range(L)])
+    assert cache.get_effective_seq_len() == 10
+    _fill_cache(G, g, cache, [_const(6, Hkv, D, l + 10.0) for l in range(L)],
+                [_const(6, Hkv, D, l + 20.0) for l in range(L)])
+    assert cache.get_effective_seq_len() == W
+    _fill_cache(G, g, cache, [_const(10, Hkv, D, 100.0)] * L, [_const(10, Hkv, D, 100.0)] * L)
+    assert cache.get_effective_seq_len() == W
+    assert cache.get_total_seq_len() == 26
+    kq, ks, vq, vs = cache.download(0)
+    expected_sink_q = int(round(1.0 / ks[0, 0, 0]))
+    assert (np.abs(kq[:sink].astype(int) - expected_sink_q) <= 2).all()
+    # what the slots hold after the slide: 4 sink tokens, 2 tokens of the second chunk, 10 new ones
+    deq = kq.astype(np.float64) * ks          # one scale group per head at D = 64
+    assert np.allclose(deq[:sink], 1.0, atol=0.02)
+    assert np.allclose(deq[sink:sink + 2], 10.0, atol=0.1)
+    assert np.allclose(deq[sink + 2:], 100.0, atol=1.0)
+    g.close()
+    cache.close()
+
+
+def test_sliding_window_matches_host_model(G):
+    """Token-by-token and chunked appends against a plain list model of the same policy
+    (keep the first `sink` tokens and the most recent window - sink)."""
+    rng = np.random.default_rng(0)
+    Hkv, D, W, sink = 2, 128, 12, 3
+    cache = G.KVCache(1, 2048, Hkv, D)
+    cache.set_window_size(W, sink)
+    g = G.CactusGraph()
+    held = []
+    for step, n in enumerate([5, 1, 4, 4, 1, 1, 7, 1, 9, 1]):
+        k = rng.normal(0, 1, (n, Hkv, D)).astype(np.float16)
+        v = rng.normal(0, 1, (n, Hkv, D)).astype(np.float16)
+        _fill_cache(G, g, cache, [k], [v])
+        held += [(k[i], v[i]) for i in range(n)]
+        if len(held) > W:
+            held = held[:sink] + held[len(held) - (W - sink):]
+        assert cache.get_effective_seq_len() == len(held)
+        kq, ks, vq, vs = cache.download(0)
+        okq, oks = O.quantize_kv(np.stack([h[0] for h in held]))
+        ovq, ovs = O.quantize_kv(np.stack([h[1] for h in held]))
+        assert (kq == okq).all() and (vq == ovq).all(), f"step {step}"
+        assert (ks == oks).all() and (vs == ovs).all(), f"step {step}"
+        g.soft_reset()
+    assert cache.get_total_seq_len() == 34
+    g.close()
+    cache.close()
+
+
+def test_incremental_updates(G):
+    """tests/test_kv_cache.cpp:132-178."""
+    Hkv, D, W = 4, 32, 8
+    cache = G.KVCache(1, 2048, Hkv, D)
+    cache.set_window_size(W, 2)
+    g = G.CactusGraph()
+    for token in range(12):
+        _fill_cache(G, g, cache, [_const(1, Hkv, D, token + 1.0)], [_const(1, Hkv, D, token + 101.0)])
+        assert cache.get_effective_seq_len() == min(token + 1, W)
+    assert cache.get_total_seq_len() == 12
+    assert cache.get_keys_int8(0) and cache.get_key_scales(0)
+    kq, ks, _, _ = cache.download(0)
+    deq = kq[:, 0, 0] * ks[:, 0, 0]
+    assert np.allclose(deq, [1, 2, 7, 8, 9, 10, 11, 12], rtol=0.01)
+    g.close()
+    cache.close()
+
+
+def test_reset_functionality(G):
+    """tests/test_kv_cache.cpp:180-215."""
+    cache = G.KVCache(2, 1024, 8, 64)
+    cache.set_window_size(16, 4)
+    g = G.CactusGraph()
+    _fill_cache(G, g, cache, [_const(10, 8, 64, 1.0)] * 2, [_const(10, 8, 64, 1.0)] * 2)
+    assert cache.get_effective_seq_len() == 10 and cache.get_total_seq_len() == 10
+    cache.reset()
+    assert cache.get_effective_seq_len() == 0 and cache.get_total_seq_len() == 0
+    assert not cache.get_keys_int8(0) and not cache.get_values_int8(0)
+    g.close()
+    cache.close()
+
+
+def test_large_window(G):
+    """tests/test_kv_cache.cpp:217-254: 600 tokens into a fresh 512-token window in one update
+    (the whole-sequence branch).  The reference has sized the layer to the window in
+    set_window_size, so it does not take this for the first slide and leaves the sink slots at
+    their initial zeros with scale 1.0 (engine_cache.cpp:35-43, 169-198); same here."""
+    L, Hkv, D, W, S = 4, 8, 64, 512, 600
+    cache = G.KVCache(L, 2048, Hkv, D)
+    cache.set_window_size(W, 4)
+    g = G.CactusGraph()
+    rng = np.random.default_rng(1)
+    ks_in = [rng.normal(0, 1, (S, Hkv, D)).astype(np.float16) for _ in range(L)]
+    vs_in = [rng.normal(0, 1, (S, Hkv, D)).astype(np.float16) for _ in range(L)]
+    _fill_cache(G, g, cache, ks_in, vs_in)
+    assert cache.get_effective_seq_len() == W
+    assert cache.get_total_seq_len() == S
+    for l in (0, L - 1):
+        kq, ks, vq, vs = cache.download(l)
+        assert (kq[:4] == 0).all() and (ks[:4] == 1.0).all()
+        okq, oks = O.quantize_kv(ks_in[l][S - (W - 4):])
+        ovq, ovs = O.quantize_kv(vs_in[l][S - (W - 4):])
+        assert (kq[4:] == okq).all() and (ks[4:] == oks).all()
+        assert (vq[4:] == ovq).all() and (vs[4:] == ovs).all()
+    g.close()
+    cache.close()
+
+
+def test_whole_sequence_updates(G):
+    """K/V nodes that hold every token so far (engine_cache.cpp:136-233): plain append without a
+    window, and a first slide that writes the sink tokens and the most recent window - sink."""
+    Hkv, D, W, S, sink = 2, 64, 64, 100, 4
+    g = G.CactusGraph()
+    rng = np.random.default_rng(2)
+    k = rng.normal(0, 1, (S, Hkv, D)).astype(np.float16)
+    v = rng.normal(0, 1, (S, Hkv, D)).astype(np.float16)
+    okq, oks = O.quantize_kv(k)
+    ovq, ovs = O.quantize_kv(v)
+
+    plain = G.KVCache(1, 2048, Hkv, D)             # no window
+    _fill_cache(G, g, plain, [k[:30]], [v[:30]])
+    _fill_cache(G, g, plain, [k], [v], seq_len=S - 30)
+    assert plain.get_effective_seq_len() == S and plain.get_total_seq_len() == S
+    kq, ks, vq, vs = plain.download(0)
+    assert (kq == okq).all() and (ks == oks).all() and (vq == ovq).all() and (vs == ovs).all()
+
+    cache = G.KVCache(1, 2048, Hkv, D)
+    cache.set_window_size(W, sink)
+    _fill_cache(G, g, cache, [k[:10]], [v[:10]])   # logical size 10: the next update is a first slide
+    _fill_cache(G, g, cache, [k], [v], seq_len=S - 10)
+    assert cache.get_effective_seq_len() == W and cache.get_total_seq_len() == S
+    kq, ks, vq, vs = cache.download(0)
+    keep = np.r_[0:sink, S - (W - sink):S]
+    assert (kq == okq[keep]).all() and (ks == oks[keep]).all()
+    assert (vq == ovq[keep]).all() and (vs == ovs[keep]).all()
+    g.close()
+    cache.close()
+    plain.close()
+
+
+def test_appended_chunk_larger_than_window_is_rejected(G):
+    cache = G.KVCache(1, 2048, 2, 64)
+    cache.set_window_size(8, 2)
+    g = G.CactusGraph()
+    _fill_cache(G, g, cache, [_const(4, 2, 64, 1.0)], [_const(4, 2, 64, 1.0)])
+    with pytest.raises(Exception, match="does not fit the window"):
+        _fill_cache(G, g, cache, [_const(7, 2, 64, 1.0)], [_const(7, 2, 64, 1.0)])
+    assert cache.get_effective_seq_len() == 4 and cache.get_total_seq_len() == 4
+    g.close()
+    cache.close()
