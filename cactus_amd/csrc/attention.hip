@@ -327,6 +327,148 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     }
 }
 
+// Any head_dim / any KV group size: one wave per (sequence, query head, query position), lanes
+// 0..31 each own one key of the 32-key block and walk its D dims serially; the output row
+// lives in LDS.  Same block structure and weights as attn_kernel; used for shapes the tiled
+// kernel does not take (head_dim not a multiple of 8 or above 256, odd group sizes), which
+// are test-sized in practice.  The reference works in 8-wide vectors and treats the
+// head_dim % 8 tail dims unevenly; that is kept: f16 mode adds them to the scores with a scalar
+// loop but writes zeros to those output dims (kernel_attention.cpp:138-140, 245-247), hybrid
+// mode ignores them in the scores and leaves those output dims unwritten (:355-390, :464-474).
+template <bool F16MODE>
+__global__ __launch_bounds__(64) void attn_generic_kernel(const AttnParams p) {
+    extern __shared__ float g_lds[];
+    const AttnArgs& a = p.a;
+    const int D = (int)a.D, Hkv = (int)a.Hkv, Hq = (int)a.Hq, S = (int)a.S;
+    float* qs = g_lds;            // [D]
+    float* os = g_lds + D;        // [D]
+    float* wl = g_lds + 2 * D;    // [32] weights, [32] key positions as int bits
+    const int lane = threadIdx.x, j = lane & 31;
+    size_t item = blockIdx.x;
+    const int qp = (int)(item % S); item /= S;
+    const int h = (int)(item % Hq);
+    const int b = (int)(item / Hq);
+    const int kvh = h / p.gq;
+
+    const int cl = F16MODE ? 0 : (a.cache_lens ? a.cache_lens[b] : (int)a.cache_len);
+    const int new_len = (int)a.new_len;
+    const int KV = cl + new_len;
+    const long long qabs = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset) + qp;
+    long long kv_start = 0, kv_end = KV;
+    if (F16MODE) {
+        if (a.window_size > 0 && a.window_size < (size_t)KV) {
+            if (qabs > (long long)a.window_size) kv_start = qabs - (long long)a.window_size;
+            if (a.is_causal) kv_end = min(kv_end, qabs + 1);
+        } else if (a.is_causal) {
+            kv_end = min(kv_end, qabs + 1);
+        }
+    } else {
+        if (a.is_causal) kv_end = min(kv_end, qabs + 1);
+    }
+    const int kv_lim = F16MODE ? KV : (int)kv_end;
+    const int nblk = kv_end > kv_start ? (int)((kv_end - kv_start + AT_BLOCK - 1) / AT_BLOCK) : 0;
+    float scale = a.scale;
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);
+    const int qgs = F16MODE ? D : (int)a.qgs;
+    const int Da = (D / 8) * 8;
+
+    const size_t orow = ((size_t)b * S + qp) * Hq + h;
+    for (int d = lane; d < D; d += 64) {
+        qs[d] = h2f(a.q[orow * D + d]);
+        os[d] = 0.0f;
+    }
+    __syncthreads();
+
+    const int8_t* Kc = a.k_cached + (size_t)b * a.cache_batch_stride;
+    const int8_t* Vc = a.v_cached + (size_t)b * a.cache_batch_stride;
+    const float* Ks = a.k_scales + (size_t)b * a.scale_batch_stride;
+    const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride;
+    const uint16_t* Kn = a.k_new + (size_t)b * new_len * Hkv * D;
+    const uint16_t* Vn = a.v_new + (size_t)b * new_len * Hkv * D;
+    const uint16_t* Mk = (F16MODE && a.mask) ? a.mask + ((size_t)b * S + qp) * KV : nullptr;
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    for (int blk = 0; blk < nblk; blk++) {
+        const long long kb = kv_start + (long long)blk * AT_BLOCK;
+        const int ke = (int)min((long long)kv_lim, kb + AT_BLOCK);
+        const int bsz = ke - (int)kb;
+        const int vec = (bsz / 4) * 4;
+        const int kp = (int)kb + j;
+        const bool valid = lane < 32 && kp < ke;
+        float s = -INFINITY;
+        if (valid) {
+            float dot = 0.0f;
+            if (!F16MODE && kp < cl) {
+                const int8_t* kr = Kc + ((size_t)kp * Hkv + kvh) * D;
+                const float* sr = Ks + ((size_t)kp * Hkv + kvh) * p.G;
+                for (int g0 = 0, g = 0; g0 < Da; g0 += qgs, g++) {
+                    float part = 0.0f;
+                    const int ge = min(Da, g0 + qgs);
+                    for (int d = g0; d < ge; d++) part = fmaf(qs[d], (float)kr[d], part);
+                    dot = fmaf(part, sr[g], dot);
+                }
+            } else {
+                const uint16_t* kr = Kn + ((size_t)(kp - cl) * Hkv + kvh) * D;
+                const int de = F16MODE ? D : Da;
+                for (int d = 0; d < de; d++) dot = fmaf(qs[d], h2f(kr[d]), dot);
+            }
+            bool masked = false;
+            if (F16MODE) {
+                if (a.is_causal && kp > qabs) masked = true;
+                else if (a.window_size > 0 && kp < qabs && (qabs - kp) > (long long)a.window_size) masked = true;
+                else if (Mk && h2f(Mk[kp]) == 0.0f) masked = true;
+            }
+            if (!masked) s = dot * scale;
+        }
+        const float bm = wave_max(s);
+        float wgt;
+        if (F16MODE) {
+            if (bm > -INFINITY) {
+                const float corr = __expf(m_run - bm);
+                l_run *= corr;
+                for (int d = lane; d < D; d += 64) os[d] *= corr;
+                m_run = bm;
+            }
+            wgt = f16mode_weight(s, bm, j < vec);
+        } else {
+            const float mn = fmaxf(m_run, bm);
+            if (mn > -INFINITY) {
+                const float corr = __expf(m_run - mn);
+                l_run *= corr;
+                for (int d = lane; d < D; d += 64) os[d] *= corr;
+                m_run = mn;
+            }
+            wgt = (s == -INFINITY) ? 0.0f : __expf(s - mn);
+        }
+        if (lane >= 32) wgt = 0.0f;
+        l_run += wave_sum(wgt);
+        __syncthreads();
+        if (lane < 32) wl[lane] = wgt;
+        __syncthreads();
+        for (int d = lane; d < Da; d += 64) {
+            float acc = os[d];
+            for (int jj = 0; jj < bsz; jj++) {
+                const int kq = (int)kb + jj;
+                float v;
+                if (!F16MODE && kq < cl)
+                    v = (float)Vc[((size_t)kq * Hkv + kvh) * D + d] * Vs[((size_t)kq * Hkv + kvh) * p.G + d / qgs];
+                else
+                    v = h2f(Vn[((size_t)(kq - cl) * Hkv + kvh) * D + d]);
+                acc = fmaf(v, wl[jj], acc);
+            }
+            os[d] = acc;
+        }
+    }
+    for (int d = lane; d < D; d += 64) {
+        if (l_run > 0.0f) {
+            if (d < Da) a.out[orow * D + d] = f2h_mul(os[d], 1.0f / l_run);
+            else if (F16MODE) a.out[orow * D + d] = 0;
+        } else {
+            a.out[orow * D + d] = 0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws,
                                                         uint16_t* __restrict__ out, int nsplit, int D) {
     const size_t row = blockIdx.x;
@@ -354,8 +496,17 @@ struct Plan {
     size_t items;
 };
 
+bool tiled_ok(const AttnArgs& a) {
+    return a.D % 8 == 0 && a.D <= 256 && (a.f16_mode || (a.qgs != 0 && a.qgs % 32 == 0));
+}
+
 Plan make_plan(const AttnArgs& a) {
     Plan pl;
+    if (!tiled_ok(a)) {
+        pl.dpl = 0; pl.nq = 1; pl.nsplit = 1;
+        pl.items = a.B * a.Hq * a.S;
+        return pl;
+    }
     pl.dpl = a.D <= 64 ? 8 : (a.D <= 128 ? 16 : 32);
     const int gq = (int)(a.Hq / a.Hkv);
     const int maxnq = pl.dpl == 32 ? 2 : 4;
@@ -400,6 +551,15 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) 
     p.G = (int)((a.D + a.qgs - 1) / a.qgs);
     p.ws = reinterpret_cast<float*>(workspace);
     if (pl.items > 0x7FFFFFFFull / 2) return hipErrorInvalidValue;
+    if (pl.dpl == 0) {
+        const size_t lds = (2 * a.D + 32) * sizeof(float);
+        if (lds > 64 * 1024) return hipErrorInvalidValue;
+        if (a.f16_mode)
+            attn_generic_kernel<true><<<dim3((unsigned)pl.items), dim3(64), lds, st>>>(p);
+        else
+            attn_generic_kernel<false><<<dim3((unsigned)pl.items), dim3(64), lds, st>>>(p);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)pl.items, (unsigned)pl.nsplit);
     switch (pl.dpl * 10 + pl.nq) {
         case 81: launch_t<8, 1>(p, grid, st); break;

@@ -10,7 +10,7 @@
  * Two families:
  *   cactus_hip_<op>_dev(...)  operands are DEVICE pointers already resident in
  *                             HBM; work is enqueued on `stream` (a hipStream_t,
- *                             or NULL for the library's own stream) and the call
+ *                             or NULL for HIP's null stream) and the call
  *                             returns without synchronising.  This is the hot
  *                             path.
  *   cactus_hip_<op>(...)      operands are HOST pointers with exactly the

@@ -171,8 +171,9 @@ def test_matmul_node_errors(G):
 
 # ------------------------------------------------------------------------- attention nodes
 def test_attention_node_kat(G):
-    """tests/test_graph.cpp:220-240 (the reference only runs it; here the values are checked
-    against the oracle too)."""
+    """tests/test_graph.cpp:220-240.  The reference only runs it: with head_dim 4 its 8-wide
+    output loop never executes and the scalar tail stores zeros (kernel_attention.cpp:233-247),
+    so the result is all zeros, here as there."""
     g = G.CactusGraph()
     q = g.input((1, 2, 1, 4), G.FP16)
     k = g.input((1, 2, 1, 4), G.FP16)
@@ -184,11 +185,33 @@ def test_attention_node_kat(G):
     g.set_input(k, qd)
     g.set_input(v, vd)
     g.execute()
-    got = g.get_output(o).astype(np.float64)
-    ref = O.attention_f16(qd, qd, vd, 0.5).view(np.float16).astype(np.float64)
-    assert np.abs(got - ref).max() <= 2e-3 + 4e-3 * np.abs(ref).max()
-    assert np.allclose(got[0, 0, 0], [1, 2, 3, 4])      # first query sees only the first key
+    got = g.get_output(o)
+    ref = O.attention_f16(qd, qd, vd, 0.5).view(np.float16)
+    assert (ref == 0).all() and (got == 0).all()
     g.close()
+
+
+def test_attention_node_prefill(G):
+    """Causal FP16 attention node with offset and window overloads (graph_ops_nn.cpp:302-338)."""
+    rng = np.random.default_rng(9)
+    B, S, Hq, Hkv, D = 1, 40, 4, 2, 64
+    qd = rng.uniform(-1, 1, (B, S, Hq, D)).astype(np.float16)
+    kd = rng.uniform(-1, 1, (B, S, Hkv, D)).astype(np.float16)
+    vd = rng.uniform(-1, 1, (B, S, Hkv, D)).astype(np.float16)
+    for kwargs in ({}, {"window_size": 16}, {"is_causal": False}):
+        g = G.CactusGraph()
+        q = g.input(qd.shape, G.FP16)
+        k = g.input(kd.shape, G.FP16)
+        v = g.input(vd.shape, G.FP16)
+        o = g.attention(q, k, v, 0.125, **kwargs)
+        g.set_input(q, qd)
+        g.set_input(k, kd)
+        g.set_input(v, vd)
+        g.execute()
+        got = g.get_output(o).astype(np.float64)
+        ref = O.attention_f16(qd, kd, vd, 0.125, **kwargs).view(np.float16).astype(np.float64)
+        assert np.abs(got - ref).max() <= 2e-3 + 4e-3 * np.abs(ref).max()
+        g.close()
 
 
 def _fill_cache(G, g, cache, k, v, seq_len=None):
