@@ -6,11 +6,15 @@
 
 Workload (BASELINE.json configs[1]): the synthetic INT8-weight x FP16-activation matmul sweep,
 K, N in {1024, 2048, 4096, 8192}.  One *step* is one pass of the decode-shaped (M = 1) sweep:
-for each of the 16 (K, N) shapes, quantize the FP16 activation row (graph_ops_nn.cpp:35-66) and
-run the grouped INT8 matmul (kernel_gemm.cpp:128-327), FP16 in / FP16 out, on weights already
-resident in HBM.  Two complete weight sets (450 MB) alternate between steps so that no weight is
-served from the 256 MiB Infinity Cache.  `value` is algorithmic bytes of a step (weights + scales
-+ activations + outputs) times ranks, divided by the slowest rank's time per step.
+for each of the 16 (K, N) shapes the FP16-activation matmul of compute_matmul_node
+(graph_ops_nn.cpp:166-177: row quantization + grouped INT8 matmul, kernel_gemm.cpp:128-327),
+FP16 in / FP16 out, on weights already resident in HBM.  The 16 matmuls of a step are
+independent, and the library takes them as one batch (cactus_hip_matmul_int8_f16act_batch_dev):
+one launch whose workgroups each quantize their activation row and stream a 16-row weight tile
+of one of the shapes.  Two complete weight sets (450 MB) alternate
+between steps so that no weight is served from the 256 MiB Infinity Cache.  `value` is
+algorithmic bytes of a step (weights + scales + activations + outputs) times ranks, divided by
+the slowest rank's time per step.
 
 Ranks are independent replicas (independent sequences): no collective on the data path, weak
 scaling.  The same JSON line carries
@@ -131,33 +135,40 @@ def main():
     for _ in range(2):
         sets.append({(K, N): make_weights(K, N, False, gen) for K in SIZES for N in SIZES})
     acts = {K: (torch.rand((1, K), device="cuda", generator=gen) * 2 - 1).half() for K in SIZES}
-    outs = {N: torch.empty((1, N), dtype=torch.float16, device="cuda") for N in SIZES}
+    outs = {(K, N): torch.empty((1, N), dtype=torch.float16, device="cuda") for K in SIZES for N in SIZES}
     step_bytes = sum(gemv_bytes(1, K, N) for K in SIZES for N in SIZES)
+    # big shapes first: their workgroups start streaming while the small ones fill the gaps
+    order = sorted(((K, N) for K in SIZES for N in SIZES), key=lambda kn: -kn[0] * kn[1])
+    batches = [H.MatmulBatch([(acts[K], ws[(K, N)][0], ws[(K, N)][1], outs[(K, N)]) for K, N in order], 128)
+               for ws in sets]
 
-    def step(i):
-        ws = sets[i & 1]
-        for K in SIZES:
-            x = acts[K]
-            for N in SIZES:
-                q, s = H.quantize_activations(x)
-                B, Bs = ws[(K, N)]
-                H.matmul_int8(q, s, B, Bs, 128, out=outs[N])
+    def step(i, batched=True):
+        if batched:
+            batches[i & 1].run()
+        else:
+            ws = sets[i & 1]
+            for K, N in order:
+                H.matmul_f16act(acts[K], ws[(K, N)][0], ws[(K, N)][1], 128, out=outs[(K, N)])
 
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    # The 32 launches of a step are captured once per weight set into a HIP graph (the kernels
-    # allocate nothing and run on the capturing stream); a timed step is one graph replay.
+    # A step is captured once per weight set into a HIP graph (the kernels allocate nothing and
+    # run on the capturing stream); a timed step is one graph replay.
     step(0); step(1)
     torch.cuda.synchronize()
-    graphs = []
-    for which in (0, 1):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step(which)
-        graphs.append(g)
+
+    def capture(batched):
+        gs = []
+        for which in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step(which, batched)
+            gs.append(g)
+        return gs
+    graphs = capture(True)
 
     def run_step(i):
         graphs[i & 1].replay()
@@ -182,16 +193,20 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = step_bytes * world / (dt / args.steps) / 1e9
 
+    # the same step as 16 separate launches (one fused call per shape, same stream)
+    seq_graphs = capture(False)
+    seq_ms = time_events(lambda i: seq_graphs[i & 1].replay(), max(args.steps, 10), warm=4)
+
     # ---- roofline: dominant kernel alone (8192 x 8192 INT8, M = 1), 8 distinct weight buffers
     # (512 MB > Infinity Cache) visited round robin.
     K = N = 8192
     big = [sets[0][(K, N)], sets[1][(K, N)]] + [make_weights(K, N, False, gen) for _ in range(6)]
-    q, s = H.quantize_activations(acts[K])
-    o = outs[N]
-    ms = time_events(lambda i: H.matmul_int8(q, s, big[i % 8][0], big[i % 8][1], 128, out=o), 80, warm=8)
-    kbytes = gemv_bytes(1, K, N, fused_quant=False)
+    o = outs[(K, N)]
+    x8 = acts[K]
+    ms = time_events(lambda i: H.matmul_f16act(x8, big[i % 8][0], big[i % 8][1], 128, out=o), 80, warm=8)
+    kbytes = gemv_bytes(1, K, N)
     achieved = kbytes / (ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "skinny_kernel<false> (INT8 GEMV, M=1, K=N=8192)",
+    roofline = {"bound": "hbm", "kernel": "skinny_kernel<INT8, 8 waves, fused row quant> (GEMV, M=1, K=N=8192)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                 "bytes_per_launch": kbytes, "us_per_launch": round(ms * 1e3, 2)}
@@ -210,9 +225,12 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "INT8-weight x FP16-activation matmul sweep, M=1, K,N in {1024,2048,4096,8192} "
-                                   "(16 shapes/step: activation quant + grouped INT8 GEMV, group 128); "
-                                   "two alternating weight sets (450 MB); one step = one HIP-graph replay",
-                       "bytes_per_step": step_bytes, "parallelism": f"replicas x{world} (independent sequences)"},
+                                   "(16 shapes/step: fused row quant + grouped INT8 GEMV, group 128); "
+                                   "two alternating weight sets (450 MB); one step = one HIP-graph replay of "
+                                   "one batched launch",
+                       "bytes_per_step": step_bytes,
+                       "separate_launches_ms_per_step": round(seq_ms, 4),
+                       "parallelism": f"replicas x{world} (independent sequences)"},
             "roofline": roofline,
         }
         if cpu is not None:

@@ -105,6 +105,55 @@ int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const c
     return CACTUS_HIP_OK;
 }
 
+// FP16 activations: one fused launch when the skinny kernel can quantize in place, otherwise
+// row quantization into the device workspace followed by the INT8-activation path.
+int matmul_q_f16act(bool int4, const cactus_half_t* X, const void* B, const cactus_half_t* Bs,
+                    cactus_half_t* C, size_t M, size_t K, size_t N, size_t gs, void* stream) {
+    if (M == 0 || K == 0 || N == 0) return CACTUS_HIP_OK;
+    if (!X || !B || !Bs || !C) return fail(CACTUS_HIP_EINVAL, "matmul_f16act: null operand");
+    if (gs == 128 && K % 128 == 0 && aligned(X, 16) && aligned(B, 16) && aligned(Bs, 2) &&
+        K < (size_t(1) << 30) && N < (size_t(1) << 30) && skinny_fused_quant_ok(int4, M, K)) {
+        hipError_t e = launch_matmul_skinny_fq(int4, X, nullptr, B, Bs, C, M, K, N, S(stream));
+        if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_f16act launch", e);
+        return CACTUS_HIP_OK;
+    }
+    void* ws = nullptr;
+    const size_t qbytes = (M * K + 255) & ~size_t(255);
+    int rc = workspace(qbytes + M * sizeof(float), &ws);
+    if (rc != CACTUS_HIP_OK) return rc;
+    int8_t* q = static_cast<int8_t*>(ws);
+    float* qs = reinterpret_cast<float*>(static_cast<char*>(ws) + qbytes);
+    hipError_t e = launch_act_quant(X, q, qs, M, K, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "act_quant launch", e);
+    return matmul_q(int4, q, qs, B, Bs, C, nullptr, M, K, N, gs, stream);
+}
+
+int matmul_q_f16act_batch(bool int4, const cactus_hip_matmul_problem* pr, size_t count, size_t gs, void* stream) {
+    if (count == 0) return CACTUS_HIP_OK;
+    if (!pr) return fail(CACTUS_HIP_EINVAL, "matmul_f16act_batch: null problem list");
+    std::vector<SkinnyProblem> fused;
+    fused.reserve(count);
+    for (size_t i = 0; i < count; i++) {
+        const cactus_hip_matmul_problem& q = pr[i];
+        if (q.M == 0 || q.K == 0 || q.N == 0) continue;
+        if (!q.X || !q.B || !q.B_scales || !q.C) return fail(CACTUS_HIP_EINVAL, "matmul_f16act_batch: null operand");
+        const bool ok = gs == 128 && q.K % 128 == 0 && aligned(q.X, 16) && aligned(q.B, 16) &&
+                        q.K < (size_t(1) << 30) && q.N < (size_t(1) << 30) && skinny_fused_quant_ok(int4, q.M, q.K);
+        if (ok) {
+            fused.push_back(SkinnyProblem{q.X, q.B, q.B_scales, q.C, q.M, q.K, q.N});
+        } else {
+            int rc = matmul_q_f16act(int4, q.X, q.B, q.B_scales, q.C, q.M, q.K, q.N, gs, stream);
+            if (rc != CACTUS_HIP_OK) return rc;
+        }
+    }
+    for (size_t i = 0; i < fused.size(); i += 16) {
+        const size_t n = fused.size() - i < 16 ? fused.size() - i : 16;
+        hipError_t e = launch_matmul_skinny_fq_batch(int4, fused.data() + i, n, S(stream));
+        if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_f16act_batch launch", e);
+    }
+    return CACTUS_HIP_OK;
+}
+
 int attention(const AttnArgs& a, void* stream) {
     if (a.B == 0 || a.S == 0 || a.Hq == 0 || a.D == 0) return CACTUS_HIP_OK;
     if (a.Hkv == 0 || a.Hq % a.Hkv != 0) return fail(CACTUS_HIP_EINVAL, "attention: Hq must be a multiple of Hkv");
@@ -184,6 +233,26 @@ int cactus_hip_matmul_int4_group_sums_dev(const int8_t* A, const uint8_t* B_pack
                                           size_t M, size_t K, size_t N, size_t group_size, void* stream) {
     if (!sums && M && K && N) return fail(CACTUS_HIP_EINVAL, "group_sums: null output");
     return matmul_q(true, A, nullptr, B_packed, nullptr, nullptr, sums, M, K, N, group_size, stream);
+}
+
+int cactus_hip_matmul_int8_f16act_dev(const cactus_half_t* X, const int8_t* B, const cactus_half_t* B_scales,
+                                      cactus_half_t* C, size_t M, size_t K, size_t N, size_t group_size,
+                                      void* stream) {
+    return matmul_q_f16act(false, X, B, B_scales, C, M, K, N, group_size, stream);
+}
+int cactus_hip_matmul_int4_f16act_dev(const cactus_half_t* X, const uint8_t* B_packed,
+                                      const cactus_half_t* B_scales, cactus_half_t* C, size_t M, size_t K,
+                                      size_t N, size_t group_size, void* stream) {
+    return matmul_q_f16act(true, X, B_packed, B_scales, C, M, K, N, group_size, stream);
+}
+
+int cactus_hip_matmul_int8_f16act_batch_dev(const cactus_hip_matmul_problem* problems, size_t count,
+                                            size_t group_size, void* stream) {
+    return matmul_q_f16act_batch(false, problems, count, group_size, stream);
+}
+int cactus_hip_matmul_int4_f16act_batch_dev(const cactus_hip_matmul_problem* problems, size_t count,
+                                            size_t group_size, void* stream) {
+    return matmul_q_f16act_batch(true, problems, count, group_size, stream);
 }
 
 int cactus_hip_matmul_f16_dev(const cactus_half_t* a, const cactus_half_t* bT, cactus_half_t* c,

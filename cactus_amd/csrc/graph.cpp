@@ -228,6 +228,18 @@ void CactusGraph::compute_matmul_node(GraphNode& n) {
         if (lhs_prequant) {
             a8 = static_cast<const int8_t*>(lhs.device_data);
             as = static_cast<const float*>(lhs.activation_scales_device);
+        } else if (lhs.precision == Precision::FP16 && M <= 4) {
+            // decode rows: the GEMV kernel quantizes the activations itself (one launch, and
+            // cheaper than a shared quantization pass even when q/k/v read the same node)
+            const auto* x = static_cast<const cactus_half_t*>(lhs.device_data);
+            const auto* bs = static_cast<const cactus_half_t*>(rhs.scales_device);
+            if (int4)
+                abi_check(cactus_hip_matmul_int4_f16act_dev(x, static_cast<const uint8_t*>(rhs.packed_int4_device),
+                                                            bs, out, M, K, N, rhs.group_size, nullptr));
+            else
+                abi_check(cactus_hip_matmul_int8_f16act_dev(x, static_cast<const int8_t*>(rhs.device_data), bs,
+                                                            out, M, K, N, rhs.group_size, nullptr));
+            return;
         } else if (lhs.precision == Precision::FP16) {
             // quantize once per FP16 node and step; q/k/v (and gate/up) share one input node
             QuantCache& qc = quant_cache_[n.input_ids[0]];

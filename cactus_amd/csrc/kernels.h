@@ -25,7 +25,25 @@ hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scale
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                                 size_t K, size_t N, hipStream_t st);
 
+// FP16 activations quantized inside the GEMV kernel (one launch).  Only for shapes
+// skinny_fused_quant_ok accepts (M <= 4, activations + group sums fit LDS); scales_out may be null.
+bool skinny_fused_quant_ok(bool int4, size_t M, size_t K);
+hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
+                                   const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
+                                   hipStream_t st);
+
+// One launch for up to 16 independent FP16-activation matmuls (each skinny_fused_quant_ok).
+struct SkinnyProblem {
+    const uint16_t* X;
+    const void* B;
+    const uint16_t* Bs;
+    uint16_t* C;
+    size_t M, K, N;
+};
+hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* problems, size_t count, hipStream_t st);
+
 extern int g_skinny_ablate;
+hipError_t skinny_read_trace(unsigned long long* out512);
 // Benchmark hook: variant = waves_per_workgroup*100 + ring_depth (0 = the default choice).
 hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A, const float* A_scales,
                                         const void* B, const uint16_t* B_scales, uint16_t* C, int32_t* gsums,

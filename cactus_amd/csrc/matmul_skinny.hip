@@ -31,9 +31,19 @@
 #include "common.hip.h"
 #include "kernels.h"
 
+#include <cstring>
+
 namespace cactus_hip {
 
 constexpr int SK_TN = 16;  // weight rows per workgroup
+
+// Benchmarks only (ablate bit 4): shader-clock stamps of the phases of the first 64 tiles.
+__device__ unsigned long long g_sk_trace[64 * 8];
+#define SK_STAMP(ph)                                                                   \
+    do {                                                                               \
+        if ((ablate & 16) && threadIdx.x == 0 && tile < 64)                            \
+            g_sk_trace[tile * 8 + (ph)] = __builtin_readcyclecounter();                \
+    } while (0)
 
 __device__ __forceinline__ v4i ldg(const void* p) { return *reinterpret_cast<const v4i*>(p); }
 
@@ -58,12 +68,16 @@ struct UnitRegs {
 // ALDS:  activations (M*K bytes) are staged in LDS once per workgroup and the MFMA row operand
 //        is read from there; otherwise it is loaded from global memory (L2) with the ring.
 // GS:    also write the INT32 group sums (parity checks); C may then be null.
-template <bool INT4, int W, int P, bool ALDS, bool GS>
-__global__ __launch_bounds__(W * 64) void skinny_kernel(
-    const int8_t* __restrict__ A, const float* __restrict__ A_scales,
+// FQ:    (with ALDS) A is the FP16 activation matrix; every workgroup quantizes it per row on
+//        its way into LDS -- absmax, scale = max(absmax/127, 1e-10), q = rne(clamp(x * (1/scale)))
+//        exactly as act_quant_rowwise_kernel does -- so a matmul node with FP16 activations
+//        (graph_ops_nn.cpp:166-177) is one launch.  A_scales is then an optional OUTPUT.
+template <bool INT4, int W, int P, bool ALDS, bool GS, bool FQ>
+__device__ __forceinline__ void skinny_body(
+    const int8_t* __restrict__ A, float* __restrict__ A_scales,
     const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
     uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
-    int ablate) {
+    int ablate, int tile) {
     constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
     extern __shared__ __attribute__((aligned(16))) float sk_lds[];
     // Rows are padded by 4 floats: 16-byte aligned for the chain's ds_read_b128, and the 16
@@ -72,18 +86,20 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
     float* gbuf = sk_lds;                                                        // [M*16][SCP] group sums
     float* scl = sk_lds + (size_t)M * 16 * SCP;                                  // [16][GP] fp32 scales
     int8_t* lds_a = reinterpret_cast<int8_t*>(scl + SK_TN * GP);                 // [M][K] (ALDS)
+    float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4] (FQ)
 
+    SK_STAMP(0);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15;   // MFMA row (activation row m) for A, column (weight row) for B
     const int q = lane >> 4;   // k block of the MFMA operand
-    const int n0 = blockIdx.x * SK_TN;
+    const int n0 = tile * SK_TN;
     const unsigned row_bytes = INT4 ? (unsigned)K / 2 : (unsigned)K;
     const __amdgpu_buffer_rsrc_t brsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t arsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(A), 0, M * K, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(A), 0, FQ ? 2 * M * K : M * K, 0x00020000);
     // per-lane byte offsets; rows past the end are pushed out of range and read as zero
     const unsigned boff = (n0 + r < N) ? (unsigned)(n0 + r) * row_bytes + q * 16 : SK_OOB;
     const unsigned aoff = (r < M) ? (unsigned)r * K + (INT4 ? q * 32 : q * 16) : SK_OOB;
@@ -192,14 +208,13 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
 
         // activations -> LDS (ALDS runs as a single chunk): requested first, written to LDS
         // after the first weight loads have been issued
-        constexpr int AST = 4;   // 16-byte pieces per thread held in registers
+        constexpr int AST = FQ ? 2 : 4;   // 16-byte pieces per thread held in registers (FQ: M = 1 rows fit)
+        const int npieces = FQ ? M * K / 8 : M * K / 16;
         v4i a_stage[AST];
         if constexpr (ALDS) {
 #pragma unroll
-            for (int j = 0; j < AST; j++) {
-                const int i16 = t + j * W * 64;
-                a_stage[j] = (i16 < M * K / 16) ? ldg(A + (size_t)i16 * 16) : zero4;
-            }
+            for (int j = 0; j < AST; j++)   // pieces past the end read as zeros (no branch)
+                a_stage[j] = buf_load<0>(arsrc, (unsigned)(t + j * W * 64) * 16u, 0);
         }
         // every wave runs the same number of rounds; units past the chunk read as zeros
         const int nu_end = ubase + nu;               // one past the chunk's last unit
@@ -212,9 +227,10 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
         // to LDS (as fp32, x 1/16 for INT4) only after the stream, so no wait sits in the ring
         const bool sc_fast = (n0 + SK_TN <= N) && ((G & 7) == 0) && (SK_TN * G / 8 <= W * 64) &&
                              ((reinterpret_cast<uintptr_t>(B_scales) & 15) == 0);
-        v4i sc_regs = zero4;
         const bool sc_mine = g0 == 0 && want_c && !(ablate & 4) && sc_fast && t < SK_TN * G / 8;
-        if (sc_mine) sc_regs = ldg(B_scales + (size_t)n0 * G + (size_t)t * 8);
+        const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(B_scales), 0, (int)min((size_t)N * G * 2, (size_t)0x7FFFFFFF), 0x00020000);
+        const v4i sc_regs = buf_load<0>(srsrc, sc_mine ? (unsigned)(((size_t)n0 * G + (size_t)t * 8) * 2) : SK_OOB, 0);
         if (g0 == 0 && want_c && !(ablate & 4) && !sc_fast) {
             for (int idx = t; idx < SK_TN * G; idx += W * 64) {
                 const int row = idx / G, g = idx - row * G;
@@ -222,19 +238,77 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
                 scl[row * GP + g] = INT4 ? s * 0.0625f : s;
             }
         }
-        if constexpr (ALDS) {   // LDS writes visible, weight loads stay in flight
+        if constexpr (ALDS && FQ) {
+            // per-row absmax: wave partials -> LDS -> every thread reduces the W partials
+            float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            auto row_of = [&](int i16) {   // M <= 4: compares instead of a division
+                const int e = i16 * 8;
+                return min((M > 1 && e >= K) + (M > 2 && e >= 2 * K) + (M > 3 && e >= 3 * K), 3);
+            };
+            auto fold = [&](int i16, v4i x) {
+                const int row = row_of(i16);
+                const float v = absmax8_bits(x);
+#pragma unroll
+                for (int m = 0; m < 4; m++) mx[m] = (row == m) ? fmaxf(mx[m], v) : mx[m];
+            };
+#pragma unroll
+            for (int j = 0; j < AST; j++) fold(t + j * W * 64, a_stage[j]);
+#pragma unroll 1
+            for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) fold(i16, ldg(A + (size_t)i16 * 16));
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+                if (m < M) mx[m] = wave_max(mx[m]);
+            if (lane == 0) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) wmax[w * 4 + m] = mx[m];
+            }
+            SK_STAMP(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            SK_STAMP(2);
+            float inv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                if (m < M) {
+                    float r = wmax[m];
+#pragma unroll
+                    for (int ww = 1; ww < W; ww++) r = fmaxf(r, wmax[ww * 4 + m]);
+                    float sc = r / 127.0f;
+                    if (sc < 1e-10f) sc = 1e-10f;
+                    inv[m] = 1.0f / sc;
+                }
+            }
+            auto quant_piece = [&](int i16, v4i x) {
+                const int row = row_of(i16);
+                const float iv = row == 0 ? inv[0] : (row == 1 ? inv[1] : (row == 2 ? inv[2] : inv[3]));
+                *reinterpret_cast<uint2*>(lds_a + (size_t)i16 * 8) = quant8_bits(x, iv);
+            };
 #pragma unroll
             for (int j = 0; j < AST; j++) {
                 const int i16 = t + j * W * 64;
-                if (i16 < M * K / 16) *reinterpret_cast<v4i*>(lds_a + (size_t)i16 * 16) = a_stage[j];
+                if (i16 < npieces) quant_piece(i16, a_stage[j]);
             }
-            for (int i16 = t + AST * W * 64; i16 < M * K / 16; i16 += W * 64)
+#pragma unroll 1
+            for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64)
+                quant_piece(i16, ldg(A + (size_t)i16 * 16));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else if constexpr (ALDS) {   // LDS writes visible, weight loads stay in flight
+#pragma unroll
+            for (int j = 0; j < AST; j++) {
+                const int i16 = t + j * W * 64;
+                if (i16 < npieces) *reinterpret_cast<v4i*>(lds_a + (size_t)i16 * 16) = a_stage[j];
+            }
+            for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64)
                 *reinterpret_cast<v4i*>(lds_a + (size_t)i16 * 16) = ldg(A + (size_t)i16 * 16);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
 
+        SK_STAMP(3);
         const int rounds = (nu + W * P - 1) / (W * P);
         for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
 #pragma unroll
@@ -258,7 +332,9 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
                 dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
             }
         }
+        SK_STAMP(4);
         __syncthreads();
+        SK_STAMP(5);
         if (want_c && !(ablate & 1)) {
 #pragma unroll
             for (int k = 0; k < NR; k++) {
@@ -285,23 +361,83 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
         if (g0 + SC < G) __syncthreads();
     }
 
+    SK_STAMP(6);
     if (want_c) {
 #pragma unroll
         for (int k = 0; k < NR; k++) {
             const int e = t + k * W * 64;
             const int cm = e >> 4, cn = e & 15;
-            if (e < M * 16 && n0 + cn < N) C[(size_t)cm * N + n0 + cn] = f2h_mul(run[k], A_scales[cm]);
+            if (e < M * 16 && n0 + cn < N) {
+                float as;
+                if constexpr (FQ) {
+                    float r = wmax[cm];
+#pragma unroll
+                    for (int ww = 1; ww < W; ww++) r = fmaxf(r, wmax[ww * 4 + cm]);
+                    as = r / 127.0f;
+                    if (as < 1e-10f) as = 1e-10f;
+                    if (A_scales != nullptr && tile == 0 && cn == 0) A_scales[cm] = as;
+                } else {
+                    as = A_scales[cm];
+                }
+                C[(size_t)cm * N + n0 + cn] = f2h_mul(run[k], as);
+            }
         }
     }
 }
 
-int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging
+template <bool INT4, int W, int P, bool ALDS, bool GS, bool FQ = false>
+__global__ __launch_bounds__(W * 64) void skinny_kernel(
+    const int8_t* __restrict__ A, float* __restrict__ A_scales,
+    const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
+    uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
+    int ablate) {
+    skinny_body<INT4, W, P, ALDS, GS, FQ>(A, A_scales, B, B_scales, C, gsums, M, K, N, G, SC, ablate,
+                                          (int)blockIdx.x);
+}
+
+// Several independent FP16-activation matmuls (M <= 4 each) in one launch: the projections
+// that read one activation row (q/k/v, gate/up), or any set of small decode matmuls whose
+// individual launches would each be latency-bound.  Workgroup -> (problem, 16-row tile) through
+// the running tile counts in the argument block; every problem runs the fused-quantization
+// body with its own K.
+constexpr int SK_MAXB = 16;
+struct SkinnyBatch {
+    int count;
+    int tile_end[SK_MAXB];          // running sum of ceil(N / 16)
+    const void* X[SK_MAXB];
+    const void* B[SK_MAXB];
+    const uint16_t* Bs[SK_MAXB];
+    uint16_t* C[SK_MAXB];
+    int M[SK_MAXB], K[SK_MAXB], N[SK_MAXB];
+};
+
+template <bool INT4, int W, int P>
+__global__ __launch_bounds__(W * 64) void skinny_batch_kernel(const SkinnyBatch bt) {
+    const int blk = (int)blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
+    const int tile = blk - (pi ? bt.tile_end[pi - 1] : 0);
+    const int K = bt.K[pi];
+    const int G = K / 128;
+    constexpr int step = W * (INT4 ? 2 : 1);
+    const int SC = ((G + step - 1) / step) * step;     // one chunk (checked on the host)
+    skinny_body<INT4, W, P, true, false, true>(reinterpret_cast<const int8_t*>(bt.X[pi]), nullptr,
+                                               reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi],
+                                               nullptr, bt.M[pi], K, bt.N[pi], G, SC, 0, tile);
+}
+
+int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
+                           // bit4 record phase stamps (read back with skinny_read_trace)
+hipError_t skinny_read_trace(unsigned long long* out512) {
+    return hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_sk_trace), sizeof(unsigned long long) * 512);
+}
 
 namespace {
 
-template <bool INT4, int W, int P, bool ALDS>
-hipError_t launch_cfg(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
+template <bool INT4, int W, int P, bool ALDS, bool FQ = false>
+hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, const uint16_t* B_scales,
                       uint16_t* C, int32_t* gsums, size_t M, size_t K, size_t N, hipStream_t st) {
+    float* A_scales = const_cast<float*>(A_scales_c);   // written only by the FQ kernels
     const int G = (int)(K / 128);
     constexpr int GPU_ = INT4 ? 2 : 1;
     if (INT4 && (G & 1)) return hipErrorInvalidValue;   // packed units hold two groups
@@ -315,9 +451,15 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales, const void* B, con
     const int Gr = ((G + step - 1) / step) * step;
     if (SC > Gr) SC = Gr;
     size_t lds = ((size_t)M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~3) + 4)) * sizeof(float);
-    if (ALDS) lds += M * K;
+    if (ALDS) lds += ((M * K + 15) & ~(size_t)15) + (FQ ? W * 4 * sizeof(float) : 0);
     if (ALDS && (SC < Gr || lds > 64 * 1024)) return hipErrorInvalidValue;   // single chunk only
     const dim3 grid((unsigned)((N + SK_TN - 1) / SK_TN)), block(W * 64);
+    if constexpr (FQ) {
+        if (M > 4 || gsums != nullptr) return hipErrorInvalidValue;
+        skinny_kernel<INT4, W, P, true, false, true><<<grid, block, lds, st>>>(
+            A, A_scales, (const uint8_t*)B, B_scales, C, nullptr, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
+        return hipGetLastError();
+    }
     if (gsums != nullptr)
         skinny_kernel<INT4, W, P, ALDS, true><<<grid, block, lds, st>>>(
             A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
@@ -340,13 +482,93 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
     case 10000 + WW * 100 + PP:                                                                         \
         return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
                     : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
+#define SK_FQ(WW)                                                                                          \
+    case 20000 + WW * 100 + 4:   /* A holds FP16 activations */                                             \
+        return int4 ? launch_cfg<true, WW, 4, true, true>(A, A_scales, B, B_scales, C, nullptr, M, K, N, st) \
+                    : launch_cfg<false, WW, 4, true, true>(A, A_scales, B, B_scales, C, nullptr, M, K, N, st);
     switch (variant) {
+        SK_FQ(1) SK_FQ(2) SK_FQ(4) SK_FQ(8)
         SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
         SK_CASE(16, 2) SK_CASE(16, 4) SK_CASE(2, 4) SK_CASE(2, 8) SK_CASE(8, 1) SK_CASE(4, 1) SK_CASE(2, 2)
         SK_CASE(16, 1) SK_CASE(1, 4) SK_CASE(1, 8)
         default: return hipErrorInvalidValue;
     }
 #undef SK_CASE
+#undef SK_FQ
+}
+
+static int skinny_waves(bool int4, size_t K) {
+    const size_t nu = K / (int4 ? 256 : 128);
+    int W = 1;
+    while (W < 8 && (size_t)W * 8 <= nu) W *= 2;
+    return W;
+}
+
+bool skinny_fused_quant_ok(bool int4, size_t M, size_t K) {
+    const size_t G = K / 128;
+    const size_t lds = (M * 16 * (G + 8 + 4) + 16 * (G + 8)) * sizeof(float) + M * K + 256;
+    return M >= 1 && M <= 4 && K % 128 == 0 && (!int4 || K % 256 == 0) && lds <= 60 * 1024;
+}
+
+// FP16 activations in, quantized inside the kernel (M <= 4 and skinny_fused_quant_ok only).
+hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
+                                   const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
+                                   hipStream_t st) {
+    if (!skinny_fused_quant_ok(int4, M, K)) return hipErrorInvalidValue;
+    const int8_t* A = reinterpret_cast<const int8_t*>(X);
+#define FQ_CASE(WW)                                                                                        \
+    case WW:                                                                                                \
+        return int4 ? launch_cfg<true, WW, 4, true, true>(A, scales_out, B, B_scales, C, nullptr, M, K, N, st) \
+                    : launch_cfg<false, WW, 4, true, true>(A, scales_out, B, B_scales, C, nullptr, M, K, N, st);
+    switch (skinny_waves(int4, K)) {
+        FQ_CASE(1) FQ_CASE(2) FQ_CASE(4) FQ_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef FQ_CASE
+}
+
+// Batched fused launch: every problem must satisfy skinny_fused_quant_ok and the alignment the
+// single launch needs; count <= SK_MAXB (the caller splits longer lists).
+hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, size_t count, hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    if (count > (size_t)SK_MAXB) return hipErrorInvalidValue;
+    SkinnyBatch bt;
+    memset(&bt, 0, sizeof bt);
+    bt.count = (int)count;
+    size_t tiles = 0, lds = 0, kmax = 0;
+    for (size_t i = 0; i < count; i++)
+        if (pr[i].K > kmax) kmax = pr[i].K;
+    const int W = skinny_waves(int4, kmax);
+    const int step = W * (int4 ? 2 : 1);
+    for (size_t i = 0; i < count; i++) {
+        const SkinnyProblem& q = pr[i];
+        if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
+        if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+        const size_t G = q.K / 128;
+        const size_t SC = ((G + step - 1) / step) * step;
+        size_t l = (q.M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~(size_t)3) + 4)) * sizeof(float);
+        l += ((q.M * q.K + 15) & ~(size_t)15) + W * 4 * sizeof(float);
+        if (l > 64 * 1024) return hipErrorInvalidValue;
+        if (l > lds) lds = l;
+        tiles += (q.N + SK_TN - 1) / SK_TN;
+        if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        bt.tile_end[i] = (int)tiles;
+        bt.X[i] = q.X; bt.B[i] = q.B; bt.Bs[i] = q.Bs; bt.C[i] = q.C;
+        bt.M[i] = (int)q.M; bt.K[i] = (int)q.K; bt.N[i] = (int)q.N;
+    }
+    if (tiles == 0) return hipSuccess;
+    const dim3 grid((unsigned)tiles), block(W * 64);
+#define FQB_CASE(WW)                                                                  \
+    case WW:                                                                           \
+        if (int4) skinny_batch_kernel<true, WW, 4><<<grid, block, lds, st>>>(bt);      \
+        else skinny_batch_kernel<false, WW, 4><<<grid, block, lds, st>>>(bt);          \
+        break;
+    switch (W) {
+        FQB_CASE(1) FQB_CASE(2) FQB_CASE(4) FQB_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef FQB_CASE
+    return hipGetLastError();
 }
 
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,

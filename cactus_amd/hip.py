@@ -34,6 +34,10 @@ SIGNATURES = {
     "cactus_hip_release_weights": (None, [_vp]),
     "cactus_hip_matmul_int8_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_f16act_batch_dev": (_i, [_vp, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_f16act_batch_dev": (_i, [_vp, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_group_sums_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_group_sums_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp]),
@@ -120,6 +124,45 @@ def matmul_int4(A, A_scales, B_packed, B_scales, group_size=128, out=None):
     _check(lib.cactus_hip_matmul_int4_dev(_p(A), _p(A_scales), _p(B_packed), _p(B_scales), _p(Cc), M, K, N,
                                           group_size, _stream()))
     return Cc
+
+
+def matmul_f16act(X, B, B_scales, group_size=128, int4=False, out=None):
+    """FP16 activations [M, K] x INT8 / packed-INT4 weights: row quantization + grouped matmul
+    (one fused launch for M <= 4)."""
+    _dev(X, torch.float16); _dev(B, torch.uint8 if int4 else torch.int8); _dev(B_scales, torch.float16)
+    M, K = X.shape
+    N = B.shape[0]
+    Cc = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=X.device)
+    fn = lib.cactus_hip_matmul_int4_f16act_dev if int4 else lib.cactus_hip_matmul_int8_f16act_dev
+    _check(fn(_p(X), _p(B), _p(B_scales), _p(Cc), M, K, N, group_size, _stream()))
+    return Cc
+
+
+class MatmulProblem(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("B", C.c_void_p), ("B_scales", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_size_t), ("K", C.c_size_t), ("N", C.c_size_t)]
+
+
+class MatmulBatch:
+    """A fixed list of FP16-activation matmuls (X, B, B_scales, out) prepared once and enqueued
+    with one call per step (cactus_hip_matmul_int{8,4}_f16act_batch_dev)."""
+
+    def __init__(self, entries, group_size=128, int4=False):
+        self._keep = list(entries)
+        self._arr = (MatmulProblem * len(self._keep))()
+        for i, (X, B, Bs, out) in enumerate(self._keep):
+            _dev(X, torch.float16); _dev(B, torch.uint8 if int4 else torch.int8)
+            _dev(Bs, torch.float16); _dev(out, torch.float16)
+            M, K = X.shape
+            N = B.shape[0]
+            assert tuple(out.shape) == (M, N)
+            self._arr[i] = MatmulProblem(X.data_ptr(), B.data_ptr(), Bs.data_ptr(), out.data_ptr(), M, K, N)
+        self._fn = lib.cactus_hip_matmul_int4_f16act_batch_dev if int4 else lib.cactus_hip_matmul_int8_f16act_batch_dev
+        self._gs = group_size
+
+    def run(self):
+        _check(self._fn(C.cast(self._arr, C.c_void_p), len(self._keep), self._gs, _stream()))
+        return [e[3] for e in self._keep]
 
 
 def matmul_group_sums(A, B, group_size=128, int4=False):

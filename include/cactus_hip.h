@@ -92,6 +92,37 @@ int cactus_hip_matmul_int4_group_sums_dev(const int8_t* A, const uint8_t* B_pack
                                           size_t M, size_t K, size_t N, size_t group_size,
                                           void* stream);
 
+/* The FP16-activation branch of compute_matmul_node (graph_ops_nn.cpp:166-177 for
+ * INT8 weights, :196-207 for INT4): quantize_activations_fp16_to_int8 on X
+ * half[M,K] followed by cactus_matmul_int8 / cactus_matmul_int4, same results bit
+ * for bit.  For M <= 4 (decode) the row quantization happens inside the GEMV kernel
+ * and the call is a single launch; otherwise the quantized rows go through the
+ * library's device workspace (calls on one device that need it must share a stream). */
+int cactus_hip_matmul_int8_f16act_dev(const cactus_half_t* X, const int8_t* B,
+                                      const cactus_half_t* B_scales, cactus_half_t* C,
+                                      size_t M, size_t K, size_t N, size_t group_size, void* stream);
+int cactus_hip_matmul_int4_f16act_dev(const cactus_half_t* X, const uint8_t* B_packed,
+                                      const cactus_half_t* B_scales, cactus_half_t* C,
+                                      size_t M, size_t K, size_t N, size_t group_size, void* stream);
+
+/* Several independent FP16-activation matmuls enqueued together: what a decoder
+ * block issues back to back on one activation row (q/k/v: model_qwen.cpp:63-65,
+ * gate/up: :139-141), or any list of small decode matmuls.  Results are those of
+ * one cactus_hip_matmul_int{8,4}_f16act_dev call per entry; entries with M <= 4 are
+ * merged into single launches (up to 16 per launch), which removes the per-launch
+ * latency that bounds small GEMVs.  Outputs must not alias other entries' inputs. */
+typedef struct cactus_hip_matmul_problem {
+    const cactus_half_t* X;        /* half[M, K] activations                          */
+    const void* B;                 /* int8[N, K] or packed uint8[N, K/2] weights      */
+    const cactus_half_t* B_scales; /* half[N, K/group_size]                           */
+    cactus_half_t* C;              /* half[M, N] output                               */
+    size_t M, K, N;
+} cactus_hip_matmul_problem;
+int cactus_hip_matmul_int8_f16act_batch_dev(const cactus_hip_matmul_problem* problems, size_t count,
+                                            size_t group_size, void* stream);
+int cactus_hip_matmul_int4_f16act_batch_dev(const cactus_hip_matmul_problem* problems, size_t count,
+                                            size_t group_size, void* stream);
+
 /* cactus_matmul_f16 (kernel.h:49-50; kernel_gemm.cpp:102-126): C = A * B^T,
  * a half[M,K], b_transposed half[N,K].  Accumulates in fp32 (the reference
  * accumulates in fp16 lanes), so it is compared by tolerance. */

@@ -80,6 +80,14 @@ int main(int argc, char** argv) {
     fill_scales<<<(unsigned)((N * (K / 128) + 255) / 256), 256>>>(Bs, N * (K / 128));
     int8_t* A; CK(hipMalloc(&A, M * K));
     fill_kernel<<<64, 256>>>((uint32_t*)A, M * K / 4, 12345u);
+    // FP16 activations for the fused-quantization variants (2xxxx): halves in [-1, 1)
+    int8_t* X; CK(hipMalloc(&X, 2 * M * K));
+    {
+        std::vector<uint16_t> hx(M * K);
+        uint32_t st = 99u;
+        for (auto& h : hx) { st = st * 1664525u + 1013904223u; h = (uint16_t)(0x3000u + ((st >> 9) & 0x0BFFu)) | (uint16_t)((st >> 1) & 0x8000u); }
+        CK(hipMemcpy(X, hx.data(), 2 * M * K, hipMemcpyHostToDevice));
+    }
     float* As; CK(hipMalloc(&As, M * 4));
     std::vector<float> has(M, 0.01f);
     CK(hipMemcpy(As, has.data(), M * 4, hipMemcpyHostToDevice));
@@ -114,19 +122,30 @@ int main(int argc, char** argv) {
             printf("calibration %d: %.2f us  %.1f GB/s (weights only)\n", variant, us, (double)wbytes / us / 1e3);
             continue;
         }
-        CK(cactus_hip::launch_matmul_skinny_variant(variant, int4, A, As, W[0], Bs, C, nullptr, M, K, N, 0));
+        const bool fq = variant >= 20000 && variant < 30000;
+        const int8_t* Ain = fq ? X : A;
+        CK(cactus_hip::launch_matmul_skinny_variant(variant, int4, Ain, As, W[0], Bs, C, nullptr, M, K, N, 0));
         CK(hipMemcpy(got.data(), C, M * N * 2, hipMemcpyDeviceToHost));
         if (!have_ref) { ref = got; have_ref = true; }
         const bool same = memcmp(ref.data(), got.data(), M * N * 2) == 0;
         for (int i = 0; i < 5; i++)
-            CK(cactus_hip::launch_matmul_skinny_variant(variant, int4, A, As, W[i % nbuf], Bs, C, nullptr, M, K, N, 0));
+            CK(cactus_hip::launch_matmul_skinny_variant(variant, int4, Ain, As, W[i % nbuf], Bs, C, nullptr, M, K, N, 0));
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; i++)
-            CK(cactus_hip::launch_matmul_skinny_variant(variant, int4, A, As, W[(i + 5) % nbuf], Bs, C, nullptr, M, K, N, 0));
+            CK(cactus_hip::launch_matmul_skinny_variant(variant, int4, Ain, As, W[(i + 5) % nbuf], Bs, C, nullptr, M, K, N, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters;
+        if (cactus_hip::g_skinny_ablate & 16) {
+            std::vector<unsigned long long> tr(512);
+            CK(cactus_hip::skinny_read_trace(tr.data()));
+            for (int tl : {0, 1, 31, 63}) {
+                printf("  tile %2d phases (cycles from entry):", tl);
+                for (int ph = 1; ph < 7; ph++) printf(" %lld", (long long)(tr[tl * 8 + ph] - tr[tl * 8]));
+                printf("   entry-rel-to-tile0 %lld\n", (long long)(tr[tl * 8] - tr[0]));
+            }
+        }
         printf("M=%zu K=%zu N=%zu %s variant=%d ablate=%d  %.2f us  %.1f GB/s  (%.1f%% of 8 TB/s)  %s\n", M, K, N,
                int4 ? "int4" : "int8", variant, cactus_hip::g_skinny_ablate, us, bytes / us / 1e3, bytes / us / 1e3 / 80.0,
                same ? "same" : "DIFFERENT");

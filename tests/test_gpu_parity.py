@@ -40,6 +40,53 @@ def bits(t):
     return t.cpu().view(torch.int16).numpy().view(np.uint16)
 
 
+# ------------------------------------------------- FP16 activations, quantized in the GEMV
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 1024), (1, 8192, 512), (2, 2048, 100), (3, 4096, 48), (4, 8192, 256),
+                                   (4, 1024, 3072), (1, 256, 16), (1, 768, 33), (5, 1024, 64), (16, 2048, 128),
+                                   (40, 512, 64), (1, 12288, 64)])
+def test_matmul_f16_activations_fused_quant_bit_exact(H, M, K, N, int4):
+    """graph_ops_nn.cpp:166-177 / :196-207: quantize rows, then the grouped matmul.  The fused
+    kernel (M <= 4) and the two-launch fallback both equal the oracle doing the two steps."""
+    if int4 and K % 256:
+        pytest.skip("packed units hold two groups")
+    rng = np.random.default_rng(M * 31 + K + N + int4)
+    x = rand_act_f16(rng, M, K)
+    x[0, :8] = np.array([0.25, -0.25, 0.125, 0.375, -0.375, 0.5, -0.5, 1.0], np.float16)
+    if M > 1:
+        x[1] = 0          # all-zero row: scale floor
+    if M > 2:
+        x[2] *= 30.0      # rows with very different scales
+    B, Bs = (rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K)
+    q, s = O.quantize_activations(x)
+    want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
+    got = bits(H.matmul_f16act(dev(x), dev(B), dev(Bs), 128, int4=int4))
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("int4", [False, True])
+def test_matmul_f16_activations_batch_equals_single_calls(H, int4):
+    """One batched launch of mixed shapes (shared and distinct activation rows, ragged N, one
+    entry that is not fusable and runs on its own) == one call per entry == the oracle."""
+    rng = np.random.default_rng(77 + int4)
+    shapes = [(1, 1024, 1024), (1, 1024, 2048), (1, 1024, 40), (2, 2048, 512), (4, 4096, 128), (1, 8192, 272),
+              (1, 512, 16), (3, 1024, 1000), (1, 2048, 8192), (1, 256, 7), (16, 1024, 64)] + [(1, 1024, 64)] * 8
+    mk = rand_weights_int4 if int4 else rand_weights_int8
+    xs = {}
+    entries, wants = [], []
+    for (M, K, N) in shapes:
+        if (M, K) not in xs:
+            xs[(M, K)] = rand_act_f16(rng, M, K)
+        x = xs[(M, K)]
+        B, Bs = mk(rng, N, K)
+        q, s_ = O.quantize_activations(x)
+        wants.append((O.matmul_int4 if int4 else O.matmul_int8)(q, s_, B, Bs, 128))
+        entries.append((dev(x), dev(B), dev(Bs), torch.zeros((M, N), dtype=torch.float16, device="cuda")))
+    outs = H.MatmulBatch(entries, 128, int4=int4).run()
+    for o, w, shp in zip(outs, wants, shapes):
+        assert (bits(o) == w).all(), shp
+
+
 # ------------------------------------------------------------------ quantization
 @pytest.mark.parametrize("M,K", [(1, 1024), (3, 3072), (16, 4096), (5, 264), (2, 100), (1, 12288), (40, 128)])
 def test_quantize_activations_bit_exact(H, M, K):
