@@ -71,6 +71,27 @@ def time_events(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
+def time_graph(fn, n_calls, replays=6):
+    """Average milliseconds per call of fn(i), i in range(n_calls), with the n_calls launches
+    captured into one HIP graph (no host launch cost between them) and replayed."""
+    for i in range(min(n_calls, 3)):
+        fn(i)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(n_calls):
+            fn(i)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (replays * n_calls)
+
+
 def cpu_baseline(steps=5):
     """The oracle (CPU restatement of the reference kernel -- its NEON sources do not build on
     x86) on the same M=1 sweep, with the reference's thread policy for M <= 1: 4 GEMM threads
@@ -197,23 +218,30 @@ def main():
     seq_graphs = capture(False)
     seq_ms = time_events(lambda i: seq_graphs[i & 1].replay(), max(args.steps, 10), warm=4)
 
-    # ---- roofline: dominant kernel alone (8192 x 8192 INT8, M = 1), 8 distinct weight buffers
-    # (512 MB > Infinity Cache) visited round robin.
+    # ---- roofline: the timed region holds one kernel, the batched GEMV launch (one per step):
+    # its average duration from HIP events on the launching stream around K graph replays.
+    ev_ms = time_events(run_step, args.steps, warm=2)
+    achieved = step_bytes / (ev_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "skinny_batch_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "bytes_per_launch": step_bytes, "us_per_launch": round(ev_ms * 1e3, 2)}
+    # the largest single shape launched alone (8 rotating weight buffers, 512 MB > Infinity Cache)
     K = N = 8192
     big = [sets[0][(K, N)], sets[1][(K, N)]] + [make_weights(K, N, False, gen) for _ in range(6)]
     o = outs[(K, N)]
     x8 = acts[K]
     ms = time_events(lambda i: H.matmul_f16act(x8, big[i % 8][0], big[i % 8][1], 128, out=o), 80, warm=8)
     kbytes = gemv_bytes(1, K, N)
-    achieved = kbytes / (ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "skinny_kernel<INT8, 8 waves, fused row quant> (GEMV, M=1, K=N=8192)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                "bytes_per_launch": kbytes, "us_per_launch": round(ms * 1e3, 2)}
+    single = {"kernel": "skinny_kernel<INT8, 8 waves, fused row quant> (GEMV, M=1, K=N=8192, one launch)",
+              "us_per_launch": round(ms * 1e3, 2), "GBps": round(kbytes / (ms * 1e-3) / 1e9, 1),
+              "frac_hbm": round(kbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": kbytes}
 
     extra = {}
     if not args.no_extra and rank == 0:
         extra = extra_table(H, gen, big)
+    if rank == 0:
+        extra = dict(extra, single_launch_8192=single)
 
     if rank == 0:
         cpu = None
@@ -244,7 +272,8 @@ def main():
 
 
 def extra_table(H, gen, big):
-    """Secondary measurements (HIP-event timed, rotating buffers where the operand is big)."""
+    """Secondary measurements: launches captured in a HIP graph and event timed, rotating weight
+    buffers (> 256 MiB in total) so that weights come from HBM."""
     ex = {}
     # per-shape GEMV, INT8 and packed INT4, M = 1 and M = 16
     for int4 in (False, True):
@@ -256,11 +285,10 @@ def extra_table(H, gen, big):
                 nb = min(nb, 64)
                 ws = [make_weights(K, N, int4, gen) for _ in range(nb)]
                 x = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
-                q, s = H.quantize_activations(x)
                 o = torch.empty((M, N), dtype=torch.float16, device="cuda")
-                fn = H.matmul_int4 if int4 else H.matmul_int8
-                ms = time_events(lambda i: fn(q, s, ws[i % nb][0], ws[i % nb][1], 128, out=o), 60, warm=6)
-                gb = gemv_bytes(M, K, N, int4, fused_quant=False) / (ms * 1e-3) / 1e9
+                ms = time_graph(lambda i: H.matmul_f16act(x, ws[i % nb][0], ws[i % nb][1], 128, int4=int4, out=o),
+                                max(nb, 16))
+                gb = gemv_bytes(M, K, N, int4) / (ms * 1e-3) / 1e9
                 rows[f"K{K}_N{N}"] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1),
                                       "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
                 del ws
@@ -291,7 +319,7 @@ def extra_table(H, gen, big):
         kn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
         vn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
         lens = torch.full((Bn,), cache, dtype=torch.int32, device="cuda")
-        ms = time_events(lambda i: H.attention_hybrid_batched(qh, kq, vq, ks, vs, kn, vn, 0.0, lens, lens), 30, warm=3)
+        ms = time_graph(lambda i: H.attention_hybrid_batched(qh, kq, vq, ks, vs, kn, vn, 0.0, lens, lens), 8)
         byts = Bn * (2 * cache * Hkv * (D + 4) + 2 * Hkv * D * 2 + 2 * Hq * D * 2)
         gb = byts / (ms * 1e-3) / 1e9
         rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}

@@ -412,7 +412,18 @@ struct SkinnyBatch {
 };
 
 template <bool INT4, int W, int P>
-__global__ __launch_bounds__(W * 64) void skinny_batch_kernel(const SkinnyBatch bt) {
+#ifndef SK_WPE
+#define SK_WPE 0
+#endif
+#ifndef SK_BATCH_P
+#define SK_BATCH_P 4
+#endif
+#if SK_WPE
+#define SK_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SK_WPE, SK_WPE)))
+#else
+#define SK_WPE_ATTR
+#endif
+__global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const SkinnyBatch bt) {
     const int blk = (int)blockIdx.x;
     int pi = 0;
     while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
@@ -538,7 +549,18 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     size_t tiles = 0, lds = 0, kmax = 0;
     for (size_t i = 0; i < count; i++)
         if (pr[i].K > kmax) kmax = pr[i].K;
-    const int W = skinny_waves(int4, kmax);
+    // Waves per tile: as many as the longest row can feed, but no more than it takes to fill the
+    // chip (about 16K waves over the launch).  With plenty of tiles, fewer waves per tile means
+    // more independent tiles in flight and shorter waits at the tile's barriers (measured on
+    // the 16-shape sweep, 3840 tiles: 8 waves 3.5 TB/s, 4 waves 4.1, 2 waves 4.0, 1 wave 3.4).
+    size_t total_tiles = 0;
+    for (size_t i = 0; i < count; i++) total_tiles += (pr[i].N + SK_TN - 1) / SK_TN;
+    int W = skinny_waves(int4, kmax);
+#ifdef SK_BATCH_W
+    W = SK_BATCH_W;
+#else
+    while (W > 1 && total_tiles * (size_t)W > 16384) W /= 2;
+#endif
     const int step = W * (int4 ? 2 : 1);
     for (size_t i = 0; i < count; i++) {
         const SkinnyProblem& q = pr[i];
@@ -560,8 +582,8 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     const dim3 grid((unsigned)tiles), block(W * 64);
 #define FQB_CASE(WW)                                                                  \
     case WW:                                                                           \
-        if (int4) skinny_batch_kernel<true, WW, 4><<<grid, block, lds, st>>>(bt);      \
-        else skinny_batch_kernel<false, WW, 4><<<grid, block, lds, st>>>(bt);          \
+        if (int4) skinny_batch_kernel<true, WW, SK_BATCH_P><<<grid, block, lds, st>>>(bt);      \
+        else skinny_batch_kernel<false, WW, SK_BATCH_P><<<grid, block, lds, st>>>(bt);          \
         break;
     switch (W) {
         FQB_CASE(1) FQB_CASE(2) FQB_CASE(4) FQB_CASE(8)

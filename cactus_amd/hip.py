@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libcactus_hip.so")
+SO_PATH = os.environ.get("CACTUS_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libcactus_hip.so")
 
 if not os.path.exists(SO_PATH):
     raise ImportError(
