@@ -176,32 +176,37 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    # A step is captured once per weight set into a HIP graph (the kernels allocate nothing and
-    # run on the capturing stream); a timed step is one graph replay.
+    # Steps are captured into HIP graphs (the kernels allocate nothing and run on the capturing
+    # stream): CHUNK consecutive steps per graph, as a decode loop captures a whole token's
+    # launches, plus single-step graphs for the remainder.  Weight sets alternate step by step.
+    CHUNK = 10
     step(0); step(1)
     torch.cuda.synchronize()
 
-    def capture(batched):
-        gs = []
-        for which in (0, 1):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step(which, batched)
-            gs.append(g)
-        return gs
-    graphs = capture(True)
+    def capture(batched, nsteps=1, first=0):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for j in range(nsteps):
+                step(first + j, batched)
+        return g
+    graphs = [capture(True, 1, 0), capture(True, 1, 1)]
+    chunk_graph = capture(True, CHUNK, 0)        # CHUNK is even: every chunk starts on set 0
 
     def run_step(i):
         graphs[i & 1].replay()
 
-    for i in range(args.warmup):
-        run_step(i)
+    def run_steps(n):
+        for _ in range(n // CHUNK):
+            chunk_graph.replay()
+        for i in range(n % CHUNK):
+            run_step(i)
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(i)
+    run_steps(args.steps)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -215,16 +220,27 @@ def main():
     value = step_bytes * world / (dt / args.steps) / 1e9
 
     # the same step as 16 separate launches (one fused call per shape, same stream)
-    seq_graphs = capture(False)
-    seq_ms = time_events(lambda i: seq_graphs[i & 1].replay(), max(args.steps, 10), warm=4)
+    seq_graph = capture(False, 2, 0)
+    seq_ms = time_events(lambda i: seq_graph.replay(), 6, warm=2) / 2
 
     # ---- roofline: the timed region holds one kernel, the batched GEMV launch (one per step):
-    # its average duration from HIP events on the launching stream around K graph replays.
-    ev_ms = time_events(run_step, args.steps, warm=2)
+    # its average duration from HIP events on the launching stream around replays of the
+    # CHUNK-step graph (kernels back to back).
+    ev_ms = time_events(lambda i: chunk_graph.replay(), 4, warm=1) / CHUNK
     achieved = step_bytes / (ev_ms * 1e-3) / 1e9
+    # HBM bytes per launch of this kernel from the PMC pass of this same command (collected in
+    # its own rocprofv3 run, summarised by scripts/pmc_traffic.py); null when no summary exists.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pm = json.load(f)
+        if pm.get("kernel") == "skinny_batch_kernel" and pm.get("algorithmic_bytes_per_launch") == step_bytes:
+            traffic = pm.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": "skinny_batch_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "bytes_per_launch": step_bytes, "us_per_launch": round(ev_ms * 1e3, 2)}
     # the largest single shape launched alone (8 rotating weight buffers, 512 MB > Infinity Cache)
     K = N = 8192
@@ -254,8 +270,8 @@ def main():
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "INT8-weight x FP16-activation matmul sweep, M=1, K,N in {1024,2048,4096,8192} "
                                    "(16 shapes/step: fused row quant + grouped INT8 GEMV, group 128); "
-                                   "two alternating weight sets (450 MB); one step = one HIP-graph replay of "
-                                   "one batched launch",
+                                   "two alternating weight sets (450 MB); one step = one batched launch, "
+                                   f"{CHUNK} steps per HIP graph",
                        "bytes_per_step": step_bytes,
                        "separate_launches_ms_per_step": round(seq_ms, 4),
                        "parallelism": f"replicas x{world} (independent sequences)"},
