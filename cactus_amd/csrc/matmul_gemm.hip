@@ -195,10 +195,237 @@ __global__ __launch_bounds__(256) void gemm_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// Pipelined kernel (the one used for outputs; the kernel above remains for the INT32 group-sum
+// output and for K so long that the scale panel does not fit LDS).
+//
+// 512 threads = 8 waves as 2 (m) x 4 (n); each wave owns 64 x 32 outputs = 4 x 2 MFMA tiles, so
+// every SIMD hosts two waves and one wave's fp32 rescale (VALU) overlaps the other's MFMAs.
+// Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging) into a ring of
+// three stages; tile t+2 is requested while tile t is consumed, a counted s_waitcnt vmcnt and
+// ONE raw s_barrier per K step order the hand-off (no vmcnt(0) in the loop).  The LDS image of
+// a tile is lane-linear per load instruction, so the bank swizzle (16-byte slot XOR (row>>1)&7
+// for 128-byte rows, XOR (row>>2)&3 for the 64-byte rows of packed INT4) is applied to the
+// per-lane SOURCE address and again when fragments are read.  The B-scale panel of the tile
+// (128 columns x G groups, fp16) is staged once, transposed to [group][column].
+// INT4 stays packed through LDS: a lane's 16 packed bytes give the low-nibble operand of the
+// first MFMA and the high-nibble operand of the second (nibbles moved to the top of the byte),
+// with the activation fragment split into even / odd bytes by v_perm.
+// Workgroup ids are remapped so that the m-tiles sharing one weight panel run on one XCD (one
+// L2) back to back.
+constexpr int G2_STAGE = 32768;     // bytes per ring stage (A 16 KB + B up to 16 KB)
+constexpr int G2_STAGES = 3;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool INT4>
+__global__ __launch_bounds__(512) void gemm2_kernel(
+    const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B,
+    const uint16_t* __restrict__ B_scales, uint16_t* __restrict__ C, int M, int K, int N, int G, int nbm,
+    int nwg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t g2_lds[];
+    uint16_t* sc16 = reinterpret_cast<uint16_t*>(g2_lds + G2_STAGES * G2_STAGE);   // [G][128]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 2, wn = w & 3;
+    const int r = lane & 15, q = lane >> 4;
+
+    // XCD-aware, bijective remap of the workgroup id (ids congruent mod 8 share an XCD)
+    const int orig = blockIdx.x, xcd = orig & 7, qn = nwg >> 3, rn = nwg & 7;
+    const int wg = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
+    const int bm = wg % nbm, bn = wg / nbm;
+    const int m0 = bm * GM_BM, n0 = bn * GM_BN;
+    const size_t brow_bytes = INT4 ? (size_t)K / 2 : (size_t)K;
+
+    // scale panel -> LDS, transposed (plain loads, finished before the first LDS-DMA is issued)
+    for (int idx = t; idx < GM_BN * G; idx += 512) {
+        const int n = idx / G, g = idx - n * G;
+        sc16[g * GM_BN + n] = B_scales[(size_t)min(n0 + n, N - 1) * G + g];
+    }
+
+    // per-lane source offsets of this thread's pieces (a piece = one wave instruction = 1 KB)
+    size_t a_src[2], b_src[2];
+    int a_dst[2], b_dst[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int pi = w + 8 * j;
+        const int row = pi * 8 + (lane >> 3), slot = lane & 7, ch = slot ^ ((row >> 1) & 7);
+        a_src[j] = (size_t)min(m0 + row, M - 1) * K + ch * 16;
+        a_dst[j] = pi * 1024;
+        if constexpr (!INT4) {
+            b_src[j] = (size_t)min(n0 + row, N - 1) * brow_bytes + ch * 16;
+            b_dst[j] = 16384 + pi * 1024;
+        }
+    }
+    if constexpr (INT4) {
+        const int row = w * 16 + (lane >> 2), slot = lane & 3, ch = slot ^ ((row >> 2) & 3);
+        b_src[0] = (size_t)min(n0 + row, N - 1) * brow_bytes + ch * 16;
+        b_dst[0] = 16384 + w * 1024;
+        b_src[1] = 0; b_dst[1] = 0;
+    }
+    auto issue_tile = [&](int kt) {
+        uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(A + a_src[j] + (size_t)kt * 128), (lptr_t)(st + a_dst[j]), 16, 0, 0);
+        if constexpr (INT4) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(B + b_src[0] + (size_t)kt * 64), (lptr_t)(st + b_dst[0]), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                __builtin_amdgcn_global_load_lds((gptr_t)(B + b_src[j] + (size_t)kt * 128), (lptr_t)(st + b_dst[j]), 16, 0, 0);
+        }
+    };
+
+    float run[4][2][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) run[i][j][e] = 0.0f;
+
+    // fragment read offsets inside a stage
+    int fa_off[4][2], fb_off[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = wm * 64 + i * 16 + r;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int ch = INT4 ? 2 * q + s : 4 * s + q;
+            fa_off[i][s] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int row = wn * 32 + j * 16 + r;
+        if constexpr (INT4) {
+            fb_off[j][0] = 16384 + row * 64 + ((q ^ ((row >> 2) & 3)) << 4);
+            fb_off[j][1] = fb_off[j][0];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; s++) fb_off[j][s] = 16384 + row * 128 + (((4 * s + q) ^ ((row >> 1) & 7)) << 4);
+        }
+    }
+
+    __syncthreads();   // scale panel visible; no LDS-DMA outstanding yet
+    issue_tile(0);
+    if (G > 1) issue_tile(1);
+
+    for (int kt = 0; kt < G; kt++) {
+        // tile kt has landed for this wave's own pieces; the barrier extends that to all waves
+        // and also says that every wave is done reading the stage tile kt+2 will overwrite
+        if (kt + 1 < G) {
+            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < G) issue_tile(kt + 2);
+
+        const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
+        v4i fa[4][2], fb[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if constexpr (INT4) {
+                const v4i x = *reinterpret_cast<const v4i*>(st + fb_off[j][0]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    fb[j][0][e] = (int)(((uint32_t)x[e] & 0x0F0F0F0Fu) << 4);
+                    fb[j][1][e] = (int)((uint32_t)x[e] & 0xF0F0F0F0u);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; s++) fb[j][s] = *reinterpret_cast<const v4i*>(st + fb_off[j][s]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const v4i c0 = *reinterpret_cast<const v4i*>(st + fa_off[i][0]);
+            const v4i c1 = *reinterpret_cast<const v4i*>(st + fa_off[i][1]);
+            if constexpr (INT4) {   // bytes 32q..32q+31 of the group: even bytes -> s = 0, odd -> s = 1
+                fa[i][0] = v4i{(int)__builtin_amdgcn_perm((uint32_t)c0[1], (uint32_t)c0[0], 0x06040200u),
+                               (int)__builtin_amdgcn_perm((uint32_t)c0[3], (uint32_t)c0[2], 0x06040200u),
+                               (int)__builtin_amdgcn_perm((uint32_t)c1[1], (uint32_t)c1[0], 0x06040200u),
+                               (int)__builtin_amdgcn_perm((uint32_t)c1[3], (uint32_t)c1[2], 0x06040200u)};
+                fa[i][1] = v4i{(int)__builtin_amdgcn_perm((uint32_t)c0[1], (uint32_t)c0[0], 0x07050301u),
+                               (int)__builtin_amdgcn_perm((uint32_t)c0[3], (uint32_t)c0[2], 0x07050301u),
+                               (int)__builtin_amdgcn_perm((uint32_t)c1[1], (uint32_t)c1[0], 0x07050301u),
+                               (int)__builtin_amdgcn_perm((uint32_t)c1[3], (uint32_t)c1[2], 0x07050301u)};
+            } else {
+                fa[i][0] = c0;
+                fa[i][1] = c1;
+            }
+        }
+        float sc[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float sv = h2f(sc16[kt * GM_BN + wn * 32 + j * 16 + r]);
+            sc[j] = INT4 ? sv * 0.0625f : sv;
+        }
+
+        v4i acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i][0], fb[j][0], v4i{0, 0, 0, 0}, 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) run[i][j][e] = fmaf((float)acc[i][j][e], sc[j], run[i][j][e]);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int m = m0 + wm * 64 + i * 16 + q * 4 + e;
+            if (m >= M) continue;
+            const float as = A_scales[m];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int n = n0 + wn * 32 + j * 16 + r;
+                if (n < N) C[(size_t)m * N + n] = f2h_mul(run[i][j][e], as);
+            }
+        }
+}
+
+template <bool INT4>
+static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
+                               uint16_t* C, size_t M, size_t K, size_t N, int G, hipStream_t st) {
+    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
+    static bool attr_set = false;   // per template instance; setting it again is harmless
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<INT4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nbm = (int)((M + GM_BM - 1) / GM_BM), nbn = (int)((N + GM_BN - 1) / GM_BN);
+    const int nwg = nbm * nbn;
+    gemm2_kernel<INT4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C,
+                                                                   (int)M, (int)K, (int)N, G, nbm, nwg);
+    return hipGetLastError();
+}
+
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
                               const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                               size_t K, size_t N, hipStream_t st) {
     const int G = (int)(K / 128);
+    if (gsums == nullptr && C != nullptr && (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * 2 <= 160 * 1024 &&
+        ((M + GM_BM - 1) / GM_BM) * ((N + GM_BN - 1) / GM_BN) < (size_t(1) << 30)) {
+        return int4 ? launch_gemm2<true>(A, A_scales, B, B_scales, C, M, K, N, G, st)
+                    : launch_gemm2<false>(A, A_scales, B, B_scales, C, M, K, N, G, st);
+    }
     const dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)((M + GM_BM - 1) / GM_BM)), block(256);
     if (int4)
         gemm_kernel<true><<<grid, block, 0, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M,
