@@ -202,10 +202,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // 512 threads = 8 waves as 2 (m) x 4 (n); each wave owns 64 x 32 outputs = 4 x 2 MFMA tiles, so
 // every SIMD hosts two waves and one wave's fp32 rescale (VALU) overlaps the other's MFMAs.
 // Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging) into a ring of
-// three stages; tile t+2 is requested while tile t is consumed, a counted s_waitcnt vmcnt and
+// four stages; tile t+3 is requested while tile t is consumed (96 KB in flight per CU), a counted s_waitcnt vmcnt and
 // ONE raw s_barrier per K step order the hand-off (no vmcnt(0) in the loop).  The LDS image of
 // a tile is lane-linear per load instruction, so the bank swizzle (16-byte slot XOR (row>>1)&7
-// for 128-byte rows, XOR (row>>2)&3 for the 64-byte rows of packed INT4) is applied to the
+// for 128-byte rows, XOR {0,2,3,1}[(row>>2)&3] for the 64-byte rows of packed INT4: both are
+// conflict-free for ds_read_b128's lane groups) is applied to the
 // per-lane SOURCE address and again when fragments are read.  The B-scale panel of the tile
 // (128 columns x G groups, fp16) is staged once, transposed to [group][column].
 // INT4 stays packed through LDS: a lane's 16 packed bytes give the low-nibble operand of the
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // Workgroup ids are remapped so that the m-tiles sharing one weight panel run on one XCD (one
 // L2) back to back.
 constexpr int G2_STAGE = 32768;     // bytes per ring stage (A 16 KB + B up to 16 KB)
-constexpr int G2_STAGES = 3;
+constexpr int G2_STAGES = 4;
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         }
     }
     if constexpr (INT4) {
-        const int row = w * 16 + (lane >> 2), slot = lane & 3, ch = slot ^ ((row >> 2) & 3);
+        const int row = w * 16 + (lane >> 2), slot = lane & 3, ch = slot ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
         b_src[0] = (size_t)min(n0 + row, N - 1) * brow_bytes + ch * 16;
         b_dst[0] = 16384 + w * 1024;
         b_src[1] = 0; b_dst[1] = 0;
@@ -279,13 +280,14 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         }
     };
 
-    float run[4][2][4];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f run[4][2][2];   // [..][e / 2] holds elements e, e + 1: folded with v_pk_fma_f32 (two exact fmas)
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) run[i][j][e] = 0.0f;
+            for (int e = 0; e < 2; e++) run[i][j][e] = v2f{0.0f, 0.0f};
 
     // fragment read offsets inside a stage
     int fa_off[4][2], fb_off[2][2];
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     for (int j = 0; j < 2; j++) {
         const int row = wn * 32 + j * 16 + r;
         if constexpr (INT4) {
-            fb_off[j][0] = 16384 + row * 64 + ((q ^ ((row >> 2) & 3)) << 4);
+            fb_off[j][0] = 16384 + row * 64 + ((q ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3)) << 4);
             fb_off[j][1] = fb_off[j][0];
         } else {
 #pragma unroll
@@ -313,11 +315,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     __syncthreads();   // scale panel visible; no LDS-DMA outstanding yet
     issue_tile(0);
     if (G > 1) issue_tile(1);
+    if (G > 2) issue_tile(2);
 
     for (int kt = 0; kt < G; kt++) {
         // tile kt has landed for this wave's own pieces; the barrier extends that to all waves
-        // and also says that every wave is done reading the stage tile kt+2 will overwrite
-        if (kt + 1 < G) {
+        // and also says that every wave is done reading the stage tile kt+3 will overwrite
+        if (kt + 2 < G) {          // tiles kt+1 and kt+2 stay in flight
+            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (kt + 1 < G) {
             if constexpr (INT4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + 2 < G) issue_tile(kt + 2);
+        if (kt + 3 < G) issue_tile(kt + 3);
 
         const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
         v4i fa[4][2], fb[2][2];
@@ -381,7 +387,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int e = 0; e < 4; e++) run[i][j][e] = fmaf((float)acc[i][j][e], sc[j], run[i][j][e]);
+                for (int e = 0; e < 2; e++) {
+                    const v2f a2 = v2f{(float)acc[i][j][2 * e], (float)acc[i][j][2 * e + 1]};
+                    run[i][j][e] = __builtin_elementwise_fma(a2, v2f{sc[j], sc[j]}, run[i][j][e]);
+                }
     }
 
 #pragma unroll
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int n = n0 + wn * 32 + j * 16 + r;
-                if (n < N) C[(size_t)m * N + n] = f2h_mul(run[i][j][e], as);
+                if (n < N) C[(size_t)m * N + n] = f2h_mul(run[i][j][e >> 1][e & 1], as);
             }
         }
 }
