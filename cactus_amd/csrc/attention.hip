@@ -21,6 +21,8 @@
 
 #include <math.h>
 
+#include <type_traits>
+
 namespace cactus_hip {
 
 constexpr int AT_WAVES = 4;
@@ -105,11 +107,60 @@ __device__ __forceinline__ float f16mode_weight(float s, float bmax, bool poly) 
     return y * __uint_as_float(e);
 }
 
+// NB bytes (8, 16, 32 or 64) of one K/V row slice into dwords
+template <int NB>
+__device__ __forceinline__ void load_raw(const void* p, uint32_t* out) {
+    if constexpr (NB == 8) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        out[0] = v.x; out[1] = v.y;
+    } else {
+#pragma unroll
+        for (int u = 0; u < NB / 16; u++) {
+            const uint4 v = *(reinterpret_cast<const uint4*>(p) + u);
+            out[4 * u] = v.x; out[4 * u + 1] = v.y; out[4 * u + 2] = v.z; out[4 * u + 3] = v.w;
+        }
+    }
+}
+// first nd (a multiple of 8, < DPL) elements of a slice, the rest zero
+template <int DPL, bool I8>
+__device__ __forceinline__ void load_raw_partial(const void* p, int nd, uint32_t* out) {
+    constexpr int DW8 = I8 ? 2 : 4;   // dwords per 8 elements
+#pragma unroll
+    for (int u = 0; u < DPL / 8; u++) {
+        if (8 * u < nd) {
+            load_raw<DW8 * 4>(reinterpret_cast<const char*>(p) + u * DW8 * 4, out + u * DW8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < DW8; e++) out[u * DW8 + e] = 0;
+        }
+    }
+}
+template <int DPL, bool I8>
+__device__ __forceinline__ void raw_to_float(const uint32_t* raw, float* out) {
+    if constexpr (I8) {
+#pragma unroll
+        for (int i = 0; i < DPL; i++) out[i] = (float)(int8_t)((raw[i >> 2] >> (8 * (i & 3))) & 0xFF);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DPL / 2; i++) {
+            out[2 * i] = h2f((uint16_t)(raw[i] & 0xFFFFu));
+            out[2 * i + 1] = h2f((uint16_t)(raw[i] >> 16));
+        }
+    }
+}
+// sum over the 8 lanes that share a token slot (DPP: quad swaps, then half-row mirror)
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    return v;
+}
+
 template <int DPL, int NQ, bool F16MODE>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     __shared__ float s_m[AT_WAVES][NQ];
-    __shared__ float s_l[AT_WAVES][NQ];
-    __shared__ float s_o[AT_WAVES][NQ][8 * DPL];
+    __shared__ float s_l[AT_WAVES][NQ][4];
+    __shared__ float s_o[AT_WAVES][NQ][4][8 * DPL];   // [wave][head][16-lane row][dim]
 
     const AttnArgs& a = p.a;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -130,7 +181,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
     long long kv_start = 0, kv_end = KV;
     if (F16MODE) {
-        if (a.window_size > 0 && a.window_size < (size_t)KV) {  // :81-87
+        if (a.window_size > 0 && a.window_size < (size_t)KV) {  // kernel_attention.cpp:81-87
             if (qabs > (long long)a.window_size) kv_start = qabs - (long long)a.window_size;
             if (a.is_causal) kv_end = min(kv_end, qabs + 1);
         } else if (a.is_causal) {
@@ -139,8 +190,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     } else {
         if (a.is_causal) kv_end = min(kv_end, qabs + 1);      // :331-332
     }
-    const int kv_lim = F16MODE ? KV : (int)kv_end;             // :93 vs :335
-    const int nblk = kv_end > kv_start ? (int)((kv_end - kv_start + AT_BLOCK - 1) / AT_BLOCK) : 0;
+    // Blocks of 32 keys.  f16 mode: the reference's blocks, from kv_start, the last one clamped to
+    // KV rather than kv_end (:93).  Hybrid mode: the cached tokens [0, min(cl, kv_end)) in blocks
+    // from 0, then the FP16 tokens [cl, kv_end) in blocks of their own -- the online softmax does
+    // not depend on where block borders fall beyond rounding.
+    const int c_cnt = F16MODE ? 0 : (int)min((long long)cl, kv_end);
+    const int nbc = (c_cnt + AT_BLOCK - 1) / AT_BLOCK;
+    const long long n_first = F16MODE ? kv_start : cl;
+    const long long n_lim = F16MODE ? (long long)KV : kv_end;
+    const int nbn = kv_end > n_first ? (int)((kv_end - n_first + AT_BLOCK - 1) / AT_BLOCK) : 0;
+    const int nblk = nbc + nbn;
     const int bps = (nblk + p.nsplit - 1) / p.nsplit;
     const int blk_first = split * bps;
     const int blk_last = min(nblk, blk_first + bps);
@@ -171,47 +230,69 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const uint16_t* Kn = a.k_new + (size_t)b * new_len * Hkv * D;
     const uint16_t* Vn = a.v_new + (size_t)b * new_len * Hkv * D;
     const uint16_t* Mk = (F16MODE && a.mask) ? a.mask + ((size_t)b * S + qp) * KV : nullptr;
-    const int sgrp = d0 / (int)a.qgs;
+    const int sgrp = F16MODE ? 0 : d0 / (int)a.qgs;
 
-    for (int blk = blk_first + w; blk < blk_last; blk += AT_WAVES) {
-        const long long kb = kv_start + (long long)blk * AT_BLOCK;
-        const int ke = (int)min((long long)kv_lim, kb + AT_BLOCK);
+    // One block: kb = first key (absolute position), ke = one past its last key.  Every K and V
+    // row slice and scale of the block is requested before anything is consumed, so one HBM
+    // round trip covers the block; keys past ke re-read the last valid row and are masked.
+    auto do_block = [&](auto i8_tag, long long kb, int ke) {
+        constexpr bool I8 = decltype(i8_tag)::value;
+        constexpr int RW = I8 ? DPL / 4 : DPL / 2;   // dwords per row slice
         const int bsz = ke - (int)kb;
         const int vec = (bsz / 4) * 4;
+        // FP16 rows (the few new tokens of a decode step, or f16 mode) are fetched pass by pass
+        // instead: holding a whole FP16 block would double the register footprint
+        constexpr int NP = I8 ? 4 : 1;
+        uint32_t rk[NP][RW], rv[NP][RW];
+        float ksc[4], vsc[4];
+        auto fetch_f16 = [&](const uint16_t* base, int ps, uint32_t* dst) {
+            const int kp = min((int)kb + ps * 8 + t, ke - 1);
+            const size_t row = (size_t)(kp - cl) * Hkv + kvh;
+            if (nd == DPL) load_raw<2 * DPL>(base + row * D + d0, dst);
+            else load_raw_partial<DPL, false>(base + row * D + d0, nd, dst);
+        };
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            const int kp = min((int)kb + ps * 8 + t, ke - 1);
+            ksc[ps] = 1.0f;
+            vsc[ps] = 1.0f;
+            if constexpr (I8) {
+                const size_t row = (size_t)kp * Hkv + kvh;
+                if (nd == DPL) {
+                    load_raw<DPL>(Kc + row * D + d0, rk[ps]);
+                    load_raw<DPL>(Vc + row * D + d0, rv[ps]);
+                } else {
+                    load_raw_partial<DPL, true>(Kc + row * D + d0, nd, rk[ps]);
+                    load_raw_partial<DPL, true>(Vc + row * D + d0, nd, rv[ps]);
+                }
+                if (nd > 0) {
+                    ksc[ps] = Ks[row * p.G + sgrp];
+                    vsc[ps] = Vs[row * p.G + sgrp];
+                }
+            } else {
+                (void)kp;
+            }
+        }
 
         float sc[NQ][4];
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
             const int kp = (int)kb + ps * 8 + t;
-            const bool valid = kp < ke;
-            float kf[DPL];
-            float ksc = 1.0f;
-            if (valid && nd > 0) {
-                if (!F16MODE && kp < cl) {
-                    load_row_i8<DPL>(Kc + ((size_t)kp * Hkv + kvh) * D + d0, nd, kf);
-                    ksc = Ks[((size_t)kp * Hkv + kvh) * p.G + sgrp];
-                } else {
-                    load_row_f16<DPL>(Kn + ((size_t)(kp - cl) * Hkv + kvh) * D + d0, nd, kf);
-                }
-            } else {
-#pragma unroll
-                for (int d = 0; d < DPL; d++) kf[d] = 0.0f;
-            }
-            bool masked = !valid;
-            if (F16MODE && valid) {
+            bool masked = kp >= ke;
+            if (F16MODE && !masked) {
                 if (a.is_causal && kp > qabs) masked = true;                                   // :146
                 else if (a.window_size > 0 && kp < qabs && (qabs - kp) > (long long)a.window_size) masked = true;
                 else if (Mk && h2f(Mk[kp]) == 0.0f) masked = true;                             // :152
             }
+            float kf[DPL];
+            if constexpr (!I8) fetch_f16(Kn, ps, rk[0]);
+            raw_to_float<DPL, I8>(rk[I8 ? ps : 0], kf);
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
                 float part = 0.0f;
 #pragma unroll
                 for (int d = 0; d < DPL; d++) part = fmaf(qf[i][d], kf[d], part);
-                part *= ksc;
-                part += __shfl_xor(part, 1, 64);
-                part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64);
+                part = sum8(part * ksc[ps]);
                 sc[i][ps] = masked ? -INFINITY : part * scale;
             }
         }
@@ -219,10 +300,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
         float wgt[NQ][4];
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
-            float bm = fmaxf(fmaxf(sc[i][0], sc[i][1]), fmaxf(sc[i][2], sc[i][3]));
-            bm = fmaxf(bm, __shfl_xor(bm, 8, 64));
-            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+            const float bm = wave_max(fmaxf(fmaxf(sc[i][0], sc[i][1]), fmaxf(sc[i][2], sc[i][3])));
             float bsum = 0.0f;
             if (F16MODE) {
                 if (bm > -INFINITY) {                                   // :160-169 (max is replaced)
@@ -257,47 +335,49 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
-            if (ps * 8 >= bsz) continue;
-            const int kp = (int)kb + ps * 8 + t;
-            const bool valid = kp < ke;
             float vf[DPL];
-            float vsc = 1.0f;
-            if (valid && nd > 0) {
-                if (!F16MODE && kp < cl) {
-                    load_row_i8<DPL>(Vc + ((size_t)kp * Hkv + kvh) * D + d0, nd, vf);
-                    vsc = Vs[((size_t)kp * Hkv + kvh) * p.G + sgrp];
-                } else {
-                    load_row_f16<DPL>(Vn + ((size_t)(kp - cl) * Hkv + kvh) * D + d0, nd, vf);
-                }
-            } else {
-#pragma unroll
-                for (int d = 0; d < DPL; d++) vf[d] = 0.0f;
+            if constexpr (!I8) {
+                if (ps * 8 >= bsz) continue;
+                fetch_f16(Vn, ps, rv[0]);
             }
+            raw_to_float<DPL, I8>(rv[I8 ? ps : 0], vf);
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
-                const float ww = wgt[i][ps] * vsc;
+                const float ww = wgt[i][ps] * vsc[ps];   // masked keys carry weight 0
 #pragma unroll
                 for (int d = 0; d < DPL; d++) o[i][d] = fmaf(vf[d], ww, o[i][d]);
             }
         }
-    }
+    };
 
-    // fold the 8 token slots of the wave (lanes with equal c)
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-#pragma unroll
-        for (int off = 8; off < 64; off <<= 1) {
-            l_run[i] += __shfl_xor(l_run[i], off, 64);
-#pragma unroll
-            for (int d = 0; d < DPL; d++) o[i][d] += __shfl_xor(o[i][d], off, 64);
+    for (int blk = blk_first + w; blk < blk_last; blk += AT_WAVES) {
+        if (!F16MODE && blk < nbc) {
+            const long long kb = (long long)blk * AT_BLOCK;
+            do_block(std::true_type{}, kb, (int)min((long long)c_cnt, kb + AT_BLOCK));
+        } else {
+            const long long kb = n_first + (long long)(blk - nbc) * AT_BLOCK;
+            do_block(std::false_type{}, kb, (int)min(n_lim, kb + AT_BLOCK));
         }
     }
-    if (t == 0) {
+
+    // fold the 8 token slots of the wave: slots t and t^1 by DPP (rotate by 8 inside a 16-lane
+    // row), the four rows through LDS together with the other waves' states
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        l_run[i] += dpp_mov<0x128>(l_run[i]);
+#pragma unroll
+        for (int d = 0; d < DPL; d++) o[i][d] += dpp_mov<0x128>(o[i][d]);
+    }
+    if ((t & 1) == 0) {
+        const int row = t >> 1;
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
-            if (c == 0) { s_m[w][i] = m_run[i]; s_l[w][i] = l_run[i]; }
+            if (c == 0) {
+                s_l[w][i][row] = l_run[i];
+                if (row == 0) s_m[w][i] = m_run[i];
+            }
 #pragma unroll
-            for (int d = 0; d < DPL; d++) s_o[w][i][d0 + d] = o[i][d];
+            for (int d = 0; d < DPL; d++) s_o[w][i][row][d0 + d] = o[i][d];
         }
     }
     __syncthreads();
@@ -312,8 +392,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
             for (int ww = 0; ww < AT_WAVES; ww++) {
                 const float f = __expf(s_m[ww][i] - M);
-                L += s_l[ww][i] * f;
-                O += s_o[ww][i][d] * f;
+                L += ((s_l[ww][i][0] + s_l[ww][i][1]) + (s_l[ww][i][2] + s_l[ww][i][3])) * f;
+                O += ((s_o[ww][i][0][d] + s_o[ww][i][1][d]) + (s_o[ww][i][2][d] + s_o[ww][i][3][d])) * f;
             }
         }
         const size_t orow = ((size_t)b * S + qp) * Hq + h0 + i;
@@ -471,20 +551,29 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnParams p) {
 
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws,
                                                         uint16_t* __restrict__ out, int nsplit, int D) {
+    // one workgroup per output row; the per-split factors exp(m_s - M) go through LDS once,
+    // then each thread sums its dims over the splits with independent (pipelined) loads
+    __shared__ float s_f[256];
+    __shared__ float s_red[8];
     const size_t row = blockIdx.x;
     const float* base = ws + row * nsplit * (size_t)(D + 2);
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; s++) M = fmaxf(M, base[(size_t)s * (D + 2)]);
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float L = 0.0f, O = 0.0f;
-        if (M > -INFINITY) {
-            for (int s = 0; s < nsplit; s++) {
-                const float* rec = base + (size_t)s * (D + 2);
-                const float f = __expf(rec[0] - M);
-                L += rec[1] * f;
-                O += rec[2 + d] * f;
-            }
-        }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float ms = tid < nsplit ? base[(size_t)tid * (D + 2)] : -INFINITY;
+    const float ls = tid < nsplit ? base[(size_t)tid * (D + 2) + 1] : 0.0f;
+    float M = wave_max(ms);
+    if (lane == 0) s_red[wv] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float f = (M > -INFINITY && tid < nsplit) ? __expf(ms - M) : 0.0f;
+    s_f[tid] = f;
+    float L = wave_sum(ls * f);
+    if (lane == 0) s_red[4 + wv] = L;
+    __syncthreads();
+    L = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    for (int d = tid; d < D; d += 256) {
+        float O = 0.0f;
+#pragma unroll 8
+        for (int s = 0; s < nsplit; s++) O = fmaf(base[(size_t)s * (D + 2) + 2 + d], s_f[s], O);
         out[row * D + d] = (L > 0.0f) ? f2h_mul(O, 1.0f / L) : (uint16_t)0;
     }
 }
@@ -509,15 +598,17 @@ Plan make_plan(const AttnArgs& a) {
     }
     pl.dpl = a.D <= 64 ? 8 : (a.D <= 128 ? 16 : 32);
     const int gq = (int)(a.Hq / a.Hkv);
-    const int maxnq = pl.dpl == 32 ? 2 : 4;
+    const int maxnq = pl.dpl == 32 ? 1 : (pl.dpl == 16 ? 2 : 4);   // register budget: NQ * DPL <= 32
     pl.nq = 1;
     for (int cand = maxnq; cand >= 1; cand >>= 1)
         if (gq % cand == 0) { pl.nq = cand; break; }
     pl.items = a.B * a.Hkv * (size_t)(gq / pl.nq) * a.S;
     const size_t kvmax = (a.f16_mode ? 0 : a.cache_len) + a.new_len;
     const size_t maxblk = (kvmax + AT_BLOCK - 1) / AT_BLOCK;
-    size_t ns = pl.items ? 1024 / pl.items : 1;
-    const size_t cap = maxblk / 8 ? maxblk / 8 : 1;
+    // enough workgroups to fill the chip (about 2048 of 4 waves), but at least one 32-key block
+    // per wave; at most 256 splits (the merge kernel keeps one factor per split in LDS)
+    size_t ns = pl.items ? (2048 + pl.items - 1) / pl.items : 1;
+    const size_t cap = maxblk / AT_WAVES ? maxblk / AT_WAVES : 1;
     if (ns > cap) ns = cap;
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
@@ -567,9 +658,7 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) 
         case 84: launch_t<8, 4>(p, grid, st); break;
         case 161: launch_t<16, 1>(p, grid, st); break;
         case 162: launch_t<16, 2>(p, grid, st); break;
-        case 164: launch_t<16, 4>(p, grid, st); break;
         case 321: launch_t<32, 1>(p, grid, st); break;
-        case 322: launch_t<32, 2>(p, grid, st); break;
         default: return hipErrorInvalidValue;
     }
     hipError_t e = hipGetLastError();
