@@ -167,11 +167,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int t = lane >> 3, c = lane & 7;
     const int D = (int)a.D, Hkv = (int)a.Hkv, Hq = (int)a.Hq, S = (int)a.S;
     const int split = blockIdx.y;
+    // query-head groups that read the same kv head are the slowest index: with a multiple of 8
+    // (sequence, kv head, position) triples they land on the same XCD and share its L2
     int item = blockIdx.x;
     const int qp = item % S; item /= S;
-    const int qsub = item % p.qsubs; item /= p.qsubs;
-    const int kvh = item % Hkv;
-    const int b = item / Hkv;
+    const int kvh = item % Hkv; item /= Hkv;
+    const int b = item % (int)a.B;
+    const int qsub = item / (int)a.B;
     const int h0 = kvh * p.gq + qsub * NQ;
 
     const int cl = F16MODE ? 0 : (a.cache_lens ? a.cache_lens[b] : (int)a.cache_len);
@@ -235,44 +237,44 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     // One block: kb = first key (absolute position), ke = one past its last key.  Every K and V
     // row slice and scale of the block is requested before anything is consumed, so one HBM
     // round trip covers the block; keys past ke re-read the last valid row and are masked.
-    auto do_block = [&](auto i8_tag, long long kb, int ke) {
+    struct CachedBlock {   // raw INT8 row slices and scales of one 32-key block of the cache
+        uint32_t rk[4][DPL / 4], rv[4][DPL / 4];
+        float ksc[4], vsc[4];
+    };
+    auto fetch_cached = [&](long long kb, int ke, CachedBlock& cb) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ps++) {
+            const int kp = min((int)kb + ps * 8 + t, ke - 1);
+            const size_t row = (size_t)kp * Hkv + kvh;
+            cb.ksc[ps] = 1.0f;
+            cb.vsc[ps] = 1.0f;
+            if (nd == DPL) {
+                load_raw<DPL>(Kc + row * D + d0, cb.rk[ps]);
+                load_raw<DPL>(Vc + row * D + d0, cb.rv[ps]);
+            } else {
+                load_raw_partial<DPL, true>(Kc + row * D + d0, nd, cb.rk[ps]);
+                load_raw_partial<DPL, true>(Vc + row * D + d0, nd, cb.rv[ps]);
+            }
+            if (nd > 0) {
+                cb.ksc[ps] = Ks[row * p.G + sgrp];
+                cb.vsc[ps] = Vs[row * p.G + sgrp];
+            }
+        }
+    };
+    auto do_block = [&](auto i8_tag, long long kb, int ke, const CachedBlock& cb) {
         constexpr bool I8 = decltype(i8_tag)::value;
-        constexpr int RW = I8 ? DPL / 4 : DPL / 2;   // dwords per row slice
+        constexpr int RW = DPL / 2;   // dwords per FP16 row slice
         const int bsz = ke - (int)kb;
         const int vec = (bsz / 4) * 4;
-        // FP16 rows (the few new tokens of a decode step, or f16 mode) are fetched pass by pass
-        // instead: holding a whole FP16 block would double the register footprint
-        constexpr int NP = I8 ? 4 : 1;
-        uint32_t rk[NP][RW], rv[NP][RW];
-        float ksc[4], vsc[4];
+        // FP16 rows (the few new tokens of a decode step, or f16 mode) are fetched pass by pass:
+        // holding a whole FP16 block would double the register footprint
+        uint32_t fk[RW], fv[RW];
         auto fetch_f16 = [&](const uint16_t* base, int ps, uint32_t* dst) {
             const int kp = min((int)kb + ps * 8 + t, ke - 1);
             const size_t row = (size_t)(kp - cl) * Hkv + kvh;
             if (nd == DPL) load_raw<2 * DPL>(base + row * D + d0, dst);
             else load_raw_partial<DPL, false>(base + row * D + d0, nd, dst);
         };
-#pragma unroll
-        for (int ps = 0; ps < 4; ps++) {
-            const int kp = min((int)kb + ps * 8 + t, ke - 1);
-            ksc[ps] = 1.0f;
-            vsc[ps] = 1.0f;
-            if constexpr (I8) {
-                const size_t row = (size_t)kp * Hkv + kvh;
-                if (nd == DPL) {
-                    load_raw<DPL>(Kc + row * D + d0, rk[ps]);
-                    load_raw<DPL>(Vc + row * D + d0, rv[ps]);
-                } else {
-                    load_raw_partial<DPL, true>(Kc + row * D + d0, nd, rk[ps]);
-                    load_raw_partial<DPL, true>(Vc + row * D + d0, nd, rv[ps]);
-                }
-                if (nd > 0) {
-                    ksc[ps] = Ks[row * p.G + sgrp];
-                    vsc[ps] = Vs[row * p.G + sgrp];
-                }
-            } else {
-                (void)kp;
-            }
-        }
 
         float sc[NQ][4];
 #pragma unroll
@@ -285,14 +287,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
                 else if (Mk && h2f(Mk[kp]) == 0.0f) masked = true;                             // :152
             }
             float kf[DPL];
-            if constexpr (!I8) fetch_f16(Kn, ps, rk[0]);
-            raw_to_float<DPL, I8>(rk[I8 ? ps : 0], kf);
+            if constexpr (I8) {
+                raw_to_float<DPL, true>(cb.rk[ps], kf);
+            } else {
+                fetch_f16(Kn, ps, fk);
+                raw_to_float<DPL, false>(fk, kf);
+            }
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
                 float part = 0.0f;
 #pragma unroll
                 for (int d = 0; d < DPL; d++) part = fmaf(qf[i][d], kf[d], part);
-                part = sum8(part * ksc[ps]);
+                part = sum8(I8 ? part * cb.ksc[ps] : part);
                 sc[i][ps] = masked ? -INFINITY : part * scale;
             }
         }
@@ -336,28 +342,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
 #pragma unroll
         for (int ps = 0; ps < 4; ps++) {
             float vf[DPL];
-            if constexpr (!I8) {
+            if constexpr (I8) {
+                raw_to_float<DPL, true>(cb.rv[ps], vf);
+            } else {
                 if (ps * 8 >= bsz) continue;
-                fetch_f16(Vn, ps, rv[0]);
+                fetch_f16(Vn, ps, fv);
+                raw_to_float<DPL, false>(fv, vf);
             }
-            raw_to_float<DPL, I8>(rv[I8 ? ps : 0], vf);
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
-                const float ww = wgt[i][ps] * vsc[ps];   // masked keys carry weight 0
+                const float ww = I8 ? wgt[i][ps] * cb.vsc[ps] : wgt[i][ps];   // masked keys carry weight 0
 #pragma unroll
                 for (int d = 0; d < DPL; d++) o[i][d] = fmaf(vf[d], ww, o[i][d]);
             }
         }
     };
 
-    for (int blk = blk_first + w; blk < blk_last; blk += AT_WAVES) {
-        if (!F16MODE && blk < nbc) {
-            const long long kb = (long long)blk * AT_BLOCK;
-            do_block(std::true_type{}, kb, (int)min((long long)c_cnt, kb + AT_BLOCK));
-        } else {
-            const long long kb = n_first + (long long)(blk - nbc) * AT_BLOCK;
-            do_block(std::false_type{}, kb, (int)min(n_lim, kb + AT_BLOCK));
+    // cached blocks of this wave, the next one requested before the current one is consumed
+    int blk = blk_first + w;
+    if constexpr (!F16MODE) {
+        const int c_last = min(blk_last, nbc);
+        CachedBlock cur, nxt;
+        auto range_end = [&](int bk) { return (int)min((long long)c_cnt, (long long)bk * AT_BLOCK + AT_BLOCK); };
+        if (blk < c_last) fetch_cached((long long)blk * AT_BLOCK, range_end(blk), cur);
+        for (; blk < c_last; blk += AT_WAVES) {
+            const bool more = blk + AT_WAVES < c_last;
+            if (more) fetch_cached((long long)(blk + AT_WAVES) * AT_BLOCK, range_end(blk + AT_WAVES), nxt);
+            do_block(std::true_type{}, (long long)blk * AT_BLOCK, range_end(blk), cur);
+            if (more) cur = nxt;
         }
+    }
+    for (; blk < blk_last; blk += AT_WAVES) {
+        const long long kb = n_first + (long long)(blk - nbc) * AT_BLOCK;
+        CachedBlock unused;
+        do_block(std::false_type{}, kb, (int)min(n_lim, kb + AT_BLOCK), unused);
     }
 
     // fold the 8 token slots of the wave: slots t and t^1 by DPP (rotate by 8 inside a 16-lane
