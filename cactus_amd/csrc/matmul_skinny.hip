@@ -395,6 +395,270 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
                                           (int)blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused-quantization body (FP16 activations, M <= 4), several 16-row tiles per workgroup.
+//
+// The workgroup quantizes the activation rows into LDS once -- absmax, scale =
+// max(absmax/127, 1e-10), q = rne(clamp(x * (1/scale))), exactly as act_quant_rowwise_kernel --
+// and then walks `ntile` consecutive 16-row weight tiles.  The first ring of loads of tile i+1
+// (and its scales) is requested right after the last unit of tile i has been consumed, so the
+// memory pipe stays busy while tile i's barrier, fp32 chain and store run: the per-tile
+// latencies that bound a one-tile workgroup overlap with streaming.
+template <bool INT4, int W, int P>
+__device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
+                                        const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
+                                        uint16_t* __restrict__ C, int M, int K, int N, int tile0, int ntile) {
+    constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    const int G = K / 128;
+    constexpr int step = W * GPU_;
+    const int SC = ((G + step - 1) / step) * step;
+    const int SCP = SC + 4, GP = ((G + 3) & ~3) + 4;
+    float* gbuf = sk_lds;                                                        // [M*16][SCP] group sums
+    float* scl = sk_lds + (size_t)M * 16 * SCP;                                  // [16][GP] fp32 scales
+    int8_t* lds_a = reinterpret_cast<int8_t*>(scl + SK_TN * GP);                 // [M][K]
+    float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const unsigned row_bytes = INT4 ? (unsigned)K / 2 : (unsigned)K;
+    const __amdgpu_buffer_rsrc_t brsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X), 0, 2 * M * K, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(B_scales), 0, (int)min((size_t)N * G * 2, (size_t)0x7FFFFFFF), 0x00020000);
+    const int arow = min(r, M - 1);
+    const int8_t* aptr_lds = lds_a + (size_t)arow * K + (INT4 ? q * 32 : q * 16);
+    const bool a_live = r < M;
+    const v4i zero4 = {0, 0, 0, 0};
+    const int nunits = G / GPU_;
+    const bool sc_fast_shape = ((G & 7) == 0) && (SK_TN * G / 8 <= W * 64) &&
+                               ((reinterpret_cast<uintptr_t>(B_scales) & 15) == 0);
+
+    struct Unit { v4i b[2]; };
+    Unit ring[P];
+    auto tile_boff = [&](int tl) {   // tl past the last tile or row past N: out of range, reads zeros
+        const int n = tl * SK_TN + r;
+        return (tl < tile0 + ntile && n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
+    };
+    auto load_unit = [&](int u, unsigned boff, Unit& R) {
+        const unsigned uo = (u < nunits) ? (unsigned)u * 128u : SK_OOB;
+        R.b[0] = buf_load<2>(brsrc, boff + uo, 0);
+        R.b[1] = buf_load<2>(brsrc, boff + uo, 64);
+    };
+    auto scale_off = [&](int tl) {   // this thread's 8 scales of tile tl (fast path), else out of range
+        const bool fast = sc_fast_shape && tl < tile0 + ntile && tl * SK_TN + SK_TN <= N && t < SK_TN * G / 8;
+        return fast ? (unsigned)(((size_t)tl * SK_TN * G + (size_t)t * 8) * 2) : SK_OOB;
+    };
+    auto put_group = [&](int gl, v4i acc) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int m = q * 4 + i;
+            if (m < M && gl < G) gbuf[(m * 16 + r) * SCP + gl] = (float)acc[i];
+        }
+    };
+    auto compute_unit = [&](int u, const Unit& R) {
+        if constexpr (INT4) {
+            const int8_t* ap = aptr_lds + (size_t)min(u, nunits - 1) * 256;
+            v4i a[4] = {ldg(ap), ldg(ap + 16), ldg(ap + 128), ldg(ap + 144)};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                v4i blo, bhi, ae, ao;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t x = (uint32_t)R.b[h][i];
+                    blo[i] = (int)((x & 0x0F0F0F0Fu) << 4);
+                    bhi[i] = (int)(x & 0xF0F0F0F0u);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lo = (uint32_t)a[2 * h + (i >> 1)][(2 * i) & 3];
+                    const uint32_t hi = (uint32_t)a[2 * h + (i >> 1)][((2 * i) & 3) + 1];
+                    ae[i] = a_live ? (int)__builtin_amdgcn_perm(hi, lo, 0x06040200u) : 0;
+                    ao[i] = a_live ? (int)__builtin_amdgcn_perm(hi, lo, 0x07050301u) : 0;
+                }
+                v4i acc = zero4;
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, blo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bhi, acc, 0, 0, 0);
+                put_group(2 * u + h, acc);
+            }
+        } else {
+            const int8_t* ap = aptr_lds + (size_t)min(u, nunits - 1) * 128;
+            v4i a0 = ldg(ap), a1 = ldg(ap + 64);
+            a0 = a_live ? a0 : zero4;
+            a1 = a_live ? a1 : zero4;
+            v4i acc = zero4;
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, R.b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, R.b[1], acc, 0, 0, 0);
+            put_group(u, acc);
+        }
+    };
+
+    // ---- requests of the first tile, then the activation rows -> LDS
+    constexpr int AST = 2;   // 16-byte pieces per thread held in registers (an M = 1 row of K <= 8192 fits)
+    const int npieces = M * K / 8;
+    v4i a_stage[AST];
+#pragma unroll
+    for (int j = 0; j < AST; j++) a_stage[j] = buf_load<0>(xrsrc, (unsigned)(t + j * W * 64) * 16u, 0);
+    unsigned boff = tile_boff(tile0);
+#pragma unroll
+    for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
+    v4i sc_regs = buf_load<0>(srsrc, scale_off(tile0), 0);
+    {
+        float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto row_of = [&](int i16) {   // M <= 4: compares instead of a division
+            const int e = i16 * 8;
+            return min((M > 1 && e >= K) + (M > 2 && e >= 2 * K) + (M > 3 && e >= 3 * K), 3);
+        };
+        auto fold = [&](int i16, v4i x) {
+            const int row = row_of(i16);
+            const float v = absmax8_bits(x);
+#pragma unroll
+            for (int m = 0; m < 4; m++) mx[m] = (row == m) ? fmaxf(mx[m], v) : mx[m];
+        };
+        const char* Xb = reinterpret_cast<const char*>(X);
+#pragma unroll
+        for (int j = 0; j < AST; j++) fold(t + j * W * 64, a_stage[j]);
+#pragma unroll 1
+        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) fold(i16, ldg(Xb + (size_t)i16 * 16));
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+            if (m < M) mx[m] = wave_max(mx[m]);
+        if (lane == 0) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) wmax[w * 4 + m] = mx[m];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float inv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (m < M) {
+                float rmax = wmax[m];
+#pragma unroll
+                for (int ww = 1; ww < W; ww++) rmax = fmaxf(rmax, wmax[ww * 4 + m]);
+                float sc = rmax / 127.0f;
+                if (sc < 1e-10f) sc = 1e-10f;
+                inv[m] = 1.0f / sc;
+            }
+        }
+        auto quant_piece = [&](int i16, v4i x) {
+            const int row = row_of(i16);
+            const float iv = row == 0 ? inv[0] : (row == 1 ? inv[1] : (row == 2 ? inv[2] : inv[3]));
+            *reinterpret_cast<uint2*>(lds_a + (size_t)i16 * 8) = quant8_bits(x, iv);
+        };
+#pragma unroll
+        for (int j = 0; j < AST; j++) {
+            const int i16 = t + j * W * 64;
+            if (i16 < npieces) quant_piece(i16, a_stage[j]);
+        }
+#pragma unroll 1
+        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) quant_piece(i16, ldg(Xb + (size_t)i16 * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    constexpr int NR = (64 + W * 64 - 1) / (W * 64);   // chain elements per thread (M * 16 <= 64)
+    const int rounds = (nunits + W * P - 1) / (W * P);
+    for (int sub = 0; sub < ntile; sub++) {
+        const int tl = tile0 + sub;
+        const int n0 = tl * SK_TN;
+        for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int ul = w + (rd * P + p) * W;
+                compute_unit(ul, ring[p]);
+                load_unit(ul + P * W, boff, ring[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) compute_unit(w + ((rounds - 1) * P + p) * W, ring[p]);
+
+        // next tile's first ring and scales go out now; past the last tile they read nothing
+        boff = tile_boff(tl + 1);
+#pragma unroll
+        for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
+        const v4i sc_next = buf_load<0>(srsrc, scale_off(tl + 1), 0);
+
+        // this tile's scales -> LDS as fp32 (x 1/16 for INT4)
+        const bool fast = sc_fast_shape && n0 + SK_TN <= N;
+        if (fast) {
+            if (t < SK_TN * G / 8) {
+                const int row = (t * 8) / G, g = (t * 8) - row * G;
+                float* dst = scl + row * GP + g;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t x = (uint32_t)sc_regs[i];
+                    const float lo = h2f((uint16_t)(x & 0xFFFFu)), hi = h2f((uint16_t)(x >> 16));
+                    dst[2 * i] = INT4 ? lo * 0.0625f : lo;
+                    dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
+                }
+            }
+        } else {
+            for (int idx = t; idx < SK_TN * G; idx += W * 64) {
+                const int row = idx / G, g = idx - row * G;
+                const float sv = h2f(B_scales[(size_t)min(n0 + row, N - 1) * G + g]);
+                scl[row * GP + g] = INT4 ? sv * 0.0625f : sv;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const int e = t + k * W * 64;
+            if (e < M * 16) {
+                const float* sp = scl + (e & 15) * GP;
+                const float* gp = gbuf + (size_t)e * SCP;
+                float run = 0.0f;
+                int gl = 0;
+                for (; gl + 16 <= G; gl += 16) {   // eight ds_read_b128, then the serial fma chain
+                    v4f gv[4], sv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        gv[u] = *reinterpret_cast<const v4f*>(gp + gl + 4 * u);
+                        sv[u] = *reinterpret_cast<const v4f*>(sp + gl + 4 * u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) run = fmaf(gv[u >> 2][u & 3], sv[u >> 2][u & 3], run);
+                }
+                for (; gl < G; gl++) run = fmaf(gp[gl], sp[gl], run);
+                const int cm = e >> 4, cn = e & 15;
+                float rmax = wmax[cm];
+#pragma unroll
+                for (int ww = 1; ww < W; ww++) rmax = fmaxf(rmax, wmax[ww * 4 + cm]);
+                float as = rmax / 127.0f;
+                if (as < 1e-10f) as = 1e-10f;
+                if (scales_out != nullptr && tl == 0 && cn == 0) scales_out[cm] = as;
+                if (n0 + cn < N) C[(size_t)cm * N + n0 + cn] = f2h_mul(run, as);
+            }
+        }
+        if (sub + 1 < ntile) {   // group sums and scales are rewritten by the next tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        sc_regs = sc_next;
+    }
+}
+
+template <bool INT4, int W, int P>
+__global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __restrict__ X,
+                                                          float* __restrict__ scales_out,
+                                                          const uint8_t* __restrict__ B,
+                                                          const uint16_t* __restrict__ B_scales,
+                                                          uint16_t* __restrict__ C, int M, int K, int N, int tpw) {
+    const int tiles = (N + SK_TN - 1) / SK_TN;
+    const int tile0 = (int)blockIdx.x * tpw;
+    fq_body<INT4, W, P>(X, scales_out, B, B_scales, C, M, K, N, tile0, min(tpw, tiles - tile0));
+}
+
 // Several independent FP16-activation matmuls (M <= 4 each) in one launch: the projections
 // that read one activation row (q/k/v, gate/up), or any set of small decode matmuls whose
 // individual launches would each be latency-bound.  Workgroup -> (problem, 16-row tile) through
@@ -403,7 +667,8 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
 constexpr int SK_MAXB = 16;
 struct SkinnyBatch {
     int count;
-    int tile_end[SK_MAXB];          // running sum of ceil(N / 16)
+    int tpw;                        // 16-row tiles per workgroup
+    int tile_end[SK_MAXB];          // running sum of workgroups: ceil(ceil(N / 16) / tpw) per problem
     const void* X[SK_MAXB];
     const void* B[SK_MAXB];
     const uint16_t* Bs[SK_MAXB];
@@ -427,14 +692,11 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     const int blk = (int)blockIdx.x;
     int pi = 0;
     while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
-    const int tile = blk - (pi ? bt.tile_end[pi - 1] : 0);
-    const int K = bt.K[pi];
-    const int G = K / 128;
-    constexpr int step = W * (INT4 ? 2 : 1);
-    const int SC = ((G + step - 1) / step) * step;     // one chunk (checked on the host)
-    skinny_body<INT4, W, P, true, false, true>(reinterpret_cast<const int8_t*>(bt.X[pi]), nullptr,
-                                               reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi],
-                                               nullptr, bt.M[pi], K, bt.N[pi], G, SC, 0, tile);
+    const int tile0 = (blk - (pi ? bt.tile_end[pi - 1] : 0)) * bt.tpw;
+    const int tiles = (bt.N[pi] + SK_TN - 1) / SK_TN;
+    fq_body<INT4, W, P>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
+                        reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
+                        bt.N[pi], tile0, min(bt.tpw, tiles - tile0));
 }
 
 int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
@@ -445,7 +707,7 @@ hipError_t skinny_read_trace(unsigned long long* out512) {
 
 namespace {
 
-template <bool INT4, int W, int P, bool ALDS, bool FQ = false>
+template <bool INT4, int W, int P, bool ALDS>
 hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, const uint16_t* B_scales,
                       uint16_t* C, int32_t* gsums, size_t M, size_t K, size_t N, hipStream_t st) {
     float* A_scales = const_cast<float*>(A_scales_c);   // written only by the FQ kernels
@@ -462,15 +724,9 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, c
     const int Gr = ((G + step - 1) / step) * step;
     if (SC > Gr) SC = Gr;
     size_t lds = ((size_t)M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~3) + 4)) * sizeof(float);
-    if (ALDS) lds += ((M * K + 15) & ~(size_t)15) + (FQ ? W * 4 * sizeof(float) : 0);
+    if (ALDS) lds += ((M * K + 15) & ~(size_t)15);
     if (ALDS && (SC < Gr || lds > 64 * 1024)) return hipErrorInvalidValue;   // single chunk only
     const dim3 grid((unsigned)((N + SK_TN - 1) / SK_TN)), block(W * 64);
-    if constexpr (FQ) {
-        if (M > 4 || gsums != nullptr) return hipErrorInvalidValue;
-        skinny_kernel<INT4, W, P, true, false, true><<<grid, block, lds, st>>>(
-            A, A_scales, (const uint8_t*)B, B_scales, C, nullptr, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
-        return hipGetLastError();
-    }
     if (gsums != nullptr)
         skinny_kernel<INT4, W, P, ALDS, true><<<grid, block, lds, st>>>(
             A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
@@ -481,32 +737,6 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, c
 }
 
 }  // namespace
-
-// variant: 0 = default choice; otherwise [1 if ALDS]*10000 + W*100 + P (benchmarks only).
-hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A, const float* A_scales,
-                                        const void* B, const uint16_t* B_scales, uint16_t* C, int32_t* gsums,
-                                        size_t M, size_t K, size_t N, hipStream_t st) {
-#define SK_CASE(WW, PP)                                                                                \
-    case WW * 100 + PP:                                                                                 \
-        return int4 ? launch_cfg<true, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)  \
-                    : launch_cfg<false, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st); \
-    case 10000 + WW * 100 + PP:                                                                         \
-        return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
-                    : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
-#define SK_FQ(WW)                                                                                          \
-    case 20000 + WW * 100 + 4:   /* A holds FP16 activations */                                             \
-        return int4 ? launch_cfg<true, WW, 4, true, true>(A, A_scales, B, B_scales, C, nullptr, M, K, N, st) \
-                    : launch_cfg<false, WW, 4, true, true>(A, A_scales, B, B_scales, C, nullptr, M, K, N, st);
-    switch (variant) {
-        SK_FQ(1) SK_FQ(2) SK_FQ(4) SK_FQ(8)
-        SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
-        SK_CASE(16, 2) SK_CASE(16, 4) SK_CASE(2, 4) SK_CASE(2, 8) SK_CASE(8, 1) SK_CASE(4, 1) SK_CASE(2, 2)
-        SK_CASE(16, 1) SK_CASE(1, 4) SK_CASE(1, 8)
-        default: return hipErrorInvalidValue;
-    }
-#undef SK_CASE
-#undef SK_FQ
-}
 
 static int skinny_waves(bool int4, size_t K) {
     const size_t nu = K / (int4 ? 256 : 128);
@@ -521,21 +751,85 @@ bool skinny_fused_quant_ok(bool int4, size_t M, size_t K) {
     return M >= 1 && M <= 4 && K % 128 == 0 && (!int4 || K % 256 == 0) && lds <= 60 * 1024;
 }
 
-// FP16 activations in, quantized inside the kernel (M <= 4 and skinny_fused_quant_ok only).
-hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
-                                   const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
-                                   hipStream_t st) {
-    if (!skinny_fused_quant_ok(int4, M, K)) return hipErrorInvalidValue;
-    const int8_t* A = reinterpret_cast<const int8_t*>(X);
-#define FQ_CASE(WW)                                                                                        \
-    case WW:                                                                                                \
-        return int4 ? launch_cfg<true, WW, 4, true, true>(A, scales_out, B, B_scales, C, nullptr, M, K, N, st) \
-                    : launch_cfg<false, WW, 4, true, true>(A, scales_out, B, B_scales, C, nullptr, M, K, N, st);
-    switch (skinny_waves(int4, K)) {
+static size_t fq_lds_bytes(bool int4, int W, size_t M, size_t K) {
+    const size_t G = K / 128, step = (size_t)W * (int4 ? 2 : 1);
+    const size_t SC = ((G + step - 1) / step) * step;
+    return (M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~(size_t)3) + 4)) * sizeof(float) +
+           ((M * K + 15) & ~(size_t)15) + (size_t)W * 4 * sizeof(float);
+}
+
+// Waves per tile and tiles per workgroup for `tiles` 16-row tiles whose longest row is K.
+// Waves: as many as the row can feed (about 4 units each), but with plenty of tiles fewer waves
+// per tile keep more independent tiles in flight and shorten the waits at the tile barriers
+// (16-shape sweep, 3840 tiles: 8 waves 3.5 TB/s, 4 waves 4.1, 2 waves 4.0, 1 wave 3.4).
+// Tiles per workgroup: the kernel can walk several tiles with the next tile's loads overlapping
+// this tile's epilogue, but on the same sweep that measured slower than one tile per workgroup
+// (4 waves: 4.3 TB/s at 1 tile, 3.9 at 2, 2.8 at 4; 8 waves: 3.8 at 2, 4.0 at 4) -- more
+// independent workgroups hide the per-tile latencies better -- so it stays 1.
+static void fq_shape(bool int4, size_t kmax, size_t tiles, int* W_out, int* tpw_out) {
+    int W = skinny_waves(int4, kmax);
+    while (W > 1 && tiles * (size_t)W > 16384) W /= 2;
+    *W_out = W;
+    *tpw_out = 1;
+}
+
+int g_skinny_tpw = 1;   // benchmarks only: tiles per workgroup of the 2xxxx variants
+
+static hipError_t launch_fq(bool int4, int W, int tpw, const uint16_t* X, float* scales_out, const void* B,
+                            const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N, hipStream_t st) {
+    if (!skinny_fused_quant_ok(int4, M, K) || tpw < 1) return hipErrorInvalidValue;
+    if (N * (int4 ? K / 2 : K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+    const size_t lds = fq_lds_bytes(int4, W, M, K);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const size_t tiles = (N + SK_TN - 1) / SK_TN;
+    const dim3 grid((unsigned)((tiles + tpw - 1) / tpw)), block(W * 64);
+#define FQ_CASE(WW)                                                                                              \
+    case WW:                                                                                                      \
+        if (int4)                                                                                                 \
+            skinny_fq_kernel<true, WW, 4><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C, \
+                                                                  (int)M, (int)K, (int)N, tpw);                   \
+        else                                                                                                      \
+            skinny_fq_kernel<false, WW, 4><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C, \
+                                                                   (int)M, (int)K, (int)N, tpw);                  \
+        break;
+    switch (W) {
         FQ_CASE(1) FQ_CASE(2) FQ_CASE(4) FQ_CASE(8)
         default: return hipErrorInvalidValue;
     }
 #undef FQ_CASE
+    return hipGetLastError();
+}
+
+// variant: 0 = default choice; otherwise [1 if ALDS]*10000 + W*100 + P (benchmarks only).
+hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A, const float* A_scales,
+                                        const void* B, const uint16_t* B_scales, uint16_t* C, int32_t* gsums,
+                                        size_t M, size_t K, size_t N, hipStream_t st) {
+#define SK_CASE(WW, PP)                                                                                \
+    case WW * 100 + PP:                                                                                 \
+        return int4 ? launch_cfg<true, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)  \
+                    : launch_cfg<false, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st); \
+    case 10000 + WW * 100 + PP:                                                                         \
+        return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
+                    : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
+    if (variant >= 20000 && variant < 30000)   // fused quantization: A holds FP16 activations; W from the code
+        return launch_fq(int4, (variant - 20000) / 100, g_skinny_tpw, reinterpret_cast<const uint16_t*>(A), nullptr, B,
+                         B_scales, C, M, K, N, st);
+    switch (variant) {
+        SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
+        SK_CASE(16, 2) SK_CASE(16, 4) SK_CASE(2, 4) SK_CASE(2, 8) SK_CASE(8, 1) SK_CASE(4, 1) SK_CASE(2, 2)
+        SK_CASE(16, 1) SK_CASE(1, 4) SK_CASE(1, 8)
+        default: return hipErrorInvalidValue;
+    }
+#undef SK_CASE
+}
+
+// FP16 activations in, quantized inside the kernel (M <= 4 and skinny_fused_quant_ok only).
+hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
+                                   const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
+                                   hipStream_t st) {
+    int W, tpw;
+    fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &tpw);
+    return launch_fq(int4, W, tpw, X, scales_out, B, B_scales, C, M, K, N, st);
 }
 
 // Batched fused launch: every problem must satisfy skinny_fused_quant_ok and the alignment the
@@ -549,30 +843,26 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     size_t tiles = 0, lds = 0, kmax = 0;
     for (size_t i = 0; i < count; i++)
         if (pr[i].K > kmax) kmax = pr[i].K;
-    // Waves per tile: as many as the longest row can feed, but no more than it takes to fill the
-    // chip (about 16K waves over the launch).  With plenty of tiles, fewer waves per tile means
-    // more independent tiles in flight and shorter waits at the tile's barriers (measured on
-    // the 16-shape sweep, 3840 tiles: 8 waves 3.5 TB/s, 4 waves 4.1, 2 waves 4.0, 1 wave 3.4).
     size_t total_tiles = 0;
     for (size_t i = 0; i < count; i++) total_tiles += (pr[i].N + SK_TN - 1) / SK_TN;
-    int W = skinny_waves(int4, kmax);
+    int W, tpw;
+    fq_shape(int4, kmax, total_tiles, &W, &tpw);
 #ifdef SK_BATCH_W
     W = SK_BATCH_W;
-#else
-    while (W > 1 && total_tiles * (size_t)W > 16384) W /= 2;
 #endif
-    const int step = W * (int4 ? 2 : 1);
+#ifdef SK_BATCH_TPW
+    tpw = SK_BATCH_TPW;
+#endif
+    bt.tpw = tpw;
     for (size_t i = 0; i < count; i++) {
         const SkinnyProblem& q = pr[i];
         if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
         if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
-        const size_t G = q.K / 128;
-        const size_t SC = ((G + step - 1) / step) * step;
-        size_t l = (q.M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~(size_t)3) + 4)) * sizeof(float);
-        l += ((q.M * q.K + 15) & ~(size_t)15) + W * 4 * sizeof(float);
+        const size_t l = fq_lds_bytes(int4, W, q.M, q.K);
         if (l > 64 * 1024) return hipErrorInvalidValue;
         if (l > lds) lds = l;
-        tiles += (q.N + SK_TN - 1) / SK_TN;
+        const size_t ptiles = (q.N + SK_TN - 1) / SK_TN;
+        tiles += (ptiles + tpw - 1) / tpw;   // workgroups
         if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
         bt.tile_end[i] = (int)tiles;
         bt.X[i] = q.X; bt.B[i] = q.B; bt.Bs[i] = q.Bs; bt.C[i] = q.C;
