@@ -340,13 +340,28 @@ void CactusGraph::compute_attention_int8_hybrid_node(GraphNode& n) {
         n.params.head_dim, n.params.scale, n.params.position_offset, 1, CACTUS_KV_QUANT_GROUP_SIZE, nullptr));
 }
 
+// A matmul node the batched decode launch can take: grouped INT8 or packed INT4 weights,
+// pretransposed, FP16 activations with at most 4 rows, inputs already computed.
+bool CactusGraph::batchable_matmul(const GraphNode& n, bool* int4) const {
+    if (n.op_type != OpType::MATMUL || n.params.backend == ComputeBackend::NPU || !n.params.pretransposed_rhs)
+        return false;
+    const BufferDesc& lhs = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& rhs = node(n.input_ids[1]).output_buffer;
+    if (!lhs.device_valid || !rhs.device_valid) return false;
+    if (lhs.precision != Precision::FP16 || lhs.shape.size() != 2 || lhs.shape[0] > 4) return false;
+    if (!rhs.is_packed_int4() && !rhs.is_grouped_int8()) return false;
+    if (rhs.group_size != 128 || rhs.scales_device == nullptr) return false;
+    *int4 = rhs.is_packed_int4();
+    return true;
+}
+
 void CactusGraph::execute() {
     for (auto& kv : quant_cache_) {
         if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
     }
     quant_cache_.clear();
-    for (auto& up : nodes_) {
-        GraphNode& n = *up;
+    for (size_t idx = 0; idx < nodes_.size(); idx++) {
+        GraphNode& n = *nodes_[idx];
         if (n.op_type == OpType::INPUT) {
             if (!n.output_buffer.device_valid)
                 throw std::runtime_error("Input node " + std::to_string(n.id) + " has no data");
@@ -355,6 +370,40 @@ void CactusGraph::execute() {
         for (size_t in : n.input_ids)
             if (!node(in).output_buffer.device_valid)
                 throw std::runtime_error("Node " + std::to_string(n.id) + " reads a node without data");
+
+        // Consecutive decode matmuls that do not depend on each other (q/k/v, gate/up) go out as
+        // one launch; a node that reads a member of the run ends it (its input is not valid yet).
+        bool int4 = false;
+        if (batchable_matmul(n, &int4)) {
+            std::vector<cactus_hip_matmul_problem> run;
+            size_t last = idx;
+            for (size_t j = idx; j < nodes_.size() && run.size() < 16; j++) {
+                GraphNode& m = *nodes_[j];
+                bool m4 = false;
+                if (!batchable_matmul(m, &m4) || m4 != int4) break;
+                BufferDesc& lhs = node(m.input_ids[0]).output_buffer;
+                BufferDesc& rhs = node(m.input_ids[1]).output_buffer;
+                ensure_device(m.output_buffer);
+                cactus_hip_matmul_problem pr;
+                pr.X = static_cast<const cactus_half_t*>(lhs.device_data);
+                pr.B = int4 ? rhs.packed_int4_device : rhs.device_data;
+                pr.B_scales = static_cast<const cactus_half_t*>(rhs.scales_device);
+                pr.C = static_cast<cactus_half_t*>(m.output_buffer.device_data);
+                pr.M = lhs.shape[0];
+                pr.K = lhs.shape[1];
+                pr.N = rhs.shape[0];
+                run.push_back(pr);
+                last = j;
+            }
+            if (run.size() > 1) {
+                abi_check(int4 ? cactus_hip_matmul_int4_f16act_batch_dev(run.data(), run.size(), 128, nullptr)
+                               : cactus_hip_matmul_int8_f16act_batch_dev(run.data(), run.size(), 128, nullptr));
+                for (size_t j = idx; j <= last; j++) nodes_[j]->output_buffer.device_valid = true;
+                idx = last;
+                continue;
+            }
+        }
+
         ensure_device(n.output_buffer);
         switch (n.op_type) {
             case OpType::MATMUL: compute_matmul_node(n); break;

@@ -138,6 +138,7 @@ private:
     const GraphNode& node(size_t id) const;
     void ensure_device(BufferDesc& b);
     void* resident_copy(const void* host, size_t bytes);
+    bool batchable_matmul(const GraphNode& n, bool* int4) const;
     void compute_matmul_node(GraphNode& n);
     void compute_attention_node(GraphNode& n);
     void compute_attention_int8_hybrid_node(GraphNode& n);

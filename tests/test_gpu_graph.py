@@ -93,6 +93,42 @@ def test_matmul_node_prequantized_activations_shared_by_three_weights(G):
     g.close()
 
 
+@pytest.mark.parametrize("int4", [False, True])
+def test_decode_projections_share_one_launch(G, int4):
+    """q/k/v-shaped nodes on one FP16 activation row, then a node that reads one of them: the
+    independent run is batched into a single launch, the dependent node runs after it, and
+    every output equals the oracle's quantize + matmul."""
+    rng = np.random.default_rng(21 + int4)
+    K = 1024
+    x = rand_act_f16(rng, 1, K)
+    g = G.CactusGraph()
+    xin = g.input((1, K), G.FP16)
+    mk = rand_weights_int4 if int4 else rand_weights_int8
+    ws, outs = [], []
+    for N in (2048, 1024, 1024):
+        B, Bs = mk(rng, N, K)
+        w = g.input((N, K), G.INT8)
+        (g.set_packed_int4 if int4 else g.set_external_input)(w, B)
+        g.set_grouped_scales(w, 128, K // 128, Bs)
+        ws.append((B, Bs))
+        outs.append(g.matmul(xin, w, True))
+    Bo, Bso = mk(rng, 512, 2048)                     # o-projection shaped: reads the first output
+    wo = g.input((512, 2048), G.INT8)
+    (g.set_packed_int4 if int4 else g.set_external_input)(wo, Bo)
+    g.set_grouped_scales(wo, 128, 2048 // 128, Bso)
+    y = g.matmul(outs[0], wo, True)
+    g.set_input(xin, x)
+    g.execute()
+    mm = O.matmul_int4 if int4 else O.matmul_int8
+    q, s = O.quantize_activations(x)
+    refs = [mm(q, s, B, Bs, 128) for B, Bs in ws]
+    for o, r in zip(outs, refs):
+        assert (u16(g.get_output(o)) == r).all()
+    q2, s2 = O.quantize_activations(refs[0].view(np.float16))
+    assert (u16(g.get_output(y)) == mm(q2, s2, Bo, Bso, 128)).all()
+    g.close()
+
+
 def test_matmul_node_soft_reset_keeps_weights_and_requantizes(G):
     """Decode loop shape: weights stay resident over soft_reset(); the activation-quantization
     cache must not outlive a step (new activations at the same address give new results)."""
