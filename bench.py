@@ -287,6 +287,90 @@ def main():
         dist.destroy_process_group()
 
 
+def qwen3_hotpath_decode(H, gen, batch, cache_len, layers=28):
+    """One decode step of the Qwen3-0.6B op sequence restricted to this library's ops (hidden
+    1024, 16 q / 8 kv heads of 128, ffn 3072, vocab 151936: cactus/engine/engine.h:44-59; op
+    order model_qwen.cpp:51-129): per layer q/k/v projections, attention over the INT8 cache plus
+    the new FP16 token, KV quantization of the new token, o projection, gate/up, down; then the
+    lm_head.  Norms, RoPE, activations and residual adds are not part of the library yet and are
+    left out, so this is the hot path's share of a token, not a model's tok/s.  Synthetic INT8
+    weights, distinct per layer (596 MB in total, streamed from HBM every step); the whole step
+    is one HIP graph."""
+    Hd, Hq, Hkv, D, F, V = 1024, 16, 8, 128, 3072, 151936
+    mk = lambda N, K: make_weights(K, N, False, gen)
+    Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), gate=mk(F, Hd),
+               up=mk(F, Hd), down=mk(Hd, F)) for _ in range(layers)]
+    head = mk(V, Hd)
+    half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
+    x = (torch.rand((batch, Hd), device="cuda", generator=gen) * 2 - 1).half()
+    kc = torch.randint(-127, 128, (layers, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (layers, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ksc = torch.rand((layers, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
+    vsc = torch.rand((layers, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
+    lens = torch.full((batch,), cache_len, dtype=torch.int32, device="cuda")
+    qo, ko, vo = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hkv * D)
+    oo, go, uo, do, logits = half(batch, Hd), half(batch, F), half(batch, F), half(batch, Hd), half(batch, V)
+    ao = [None]
+    batches = []
+    if batch <= 4:
+        for L in Ls:
+            batches.append((H.MatmulBatch([(x, *L["q"], qo), (x, *L["k"], ko), (x, *L["v"], vo)], 128),
+                            H.MatmulBatch([(oo, *L["gate"], go), (oo, *L["up"], uo)], 128)))
+
+    def proj(inp, w, out):
+        H.matmul_f16act(inp, w[0], w[1], 128, out=out)
+
+    def step():
+        for li, L in enumerate(Ls):
+            if batch <= 4:
+                batches[li][0].run()
+            else:
+                q8, s8 = H.quantize_activations(x)
+                for name, out in (("q", qo), ("k", ko), ("v", vo)):
+                    H.matmul_int8(q8, s8, L[name][0], L[name][1], 128, out=out)
+            a = H.attention_hybrid_batched(qo.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
+                                           ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
+            # the new token's K and V join the cache (slot cache_len of every sequence)
+            for src, dst, dsc in ((ko, kc, ksc), (vo, vc, vsc)):
+                if batch == 1:   # straight into the cache slot
+                    H.quantize_kv(src.view(1, Hkv, D), out=dst[li, 0, cache_len:cache_len + 1],
+                                  out_scales=dsc[li, 0, cache_len:cache_len + 1])
+                else:
+                    qn, sn = H.quantize_kv(src.view(batch, Hkv, D))
+                    dst[li, :, cache_len] = qn
+                    dsc[li, :, cache_len] = sn
+            proj(a.view(batch, Hq * D), L["o"], oo)
+            if batch <= 4:
+                batches[li][1].run()
+            else:
+                q8, s8 = H.quantize_activations(oo)
+                H.matmul_int8(q8, s8, L["gate"][0], L["gate"][1], 128, out=go)
+                H.matmul_int8(q8, s8, L["up"][0], L["up"][1], 128, out=uo)
+            proj(go, L["down"], do)
+        proj(do, head, logits)
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    wbytes = layers * sum(gemv_bytes(batch, K, N) for N, K in ((Hq * D, Hd), (Hkv * D, Hd), (Hkv * D, Hd), (Hd, Hq * D),
+                                                                  (F, Hd), (F, Hd), (Hd, F))) + gemv_bytes(batch, Hd, V)
+    kvbytes = layers * batch * 2 * cache_len * Hkv * (D + 4)
+    return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
+            "cache_len": cache_len, "GBps": round((wbytes + kvbytes) / (ms * 1e-3) / 1e9, 1),
+            "note": "matmul + attention + KV-quant ops of a Qwen3-0.6B token only (no norm/RoPE/activation)"}
+
+
 def extra_table(H, gen, big):
     """Secondary measurements: launches captured in a HIP graph and event timed, rotating weight
     buffers (> 256 MiB in total) so that weights come from HBM."""
@@ -340,6 +424,9 @@ def extra_table(H, gen, big):
         gb = byts / (ms * 1e-3) / 1e9
         rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
     ex["attn_decode_int8kv"] = rows
+    torch.cuda.empty_cache()
+    ex["qwen3_0p6b_hotpath_decode"] = {"b1_c512": qwen3_hotpath_decode(H, gen, 1, 512),
+                                       "b256_c512": qwen3_hotpath_decode(H, gen, 256, 512)}
     return ex
 
 
