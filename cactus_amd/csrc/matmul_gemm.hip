@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 // 512 threads = 8 waves as 2 (m) x 4 (n); each wave owns 64 x 32 outputs = 4 x 2 MFMA tiles, so
 // every SIMD hosts two waves and one wave's fp32 rescale (VALU) overlaps the other's MFMAs.
 // Operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR staging) into a ring of
-// four stages; tile t+3 is requested while tile t is consumed (96 KB in flight per CU), a counted s_waitcnt vmcnt and
-// ONE raw s_barrier per K step order the hand-off (no vmcnt(0) in the loop).  The LDS image of
+// four stages; tile t+3 is requested while tile t is consumed (96 KB in flight per CU), counted s_waitcnt vmcnt
+// and raw s_barriers order the hand-off (no vmcnt(0) in the loop).  The LDS image of
 // a tile is lane-linear per load instruction, so the bank swizzle (16-byte slot XOR (row>>1)&7
 // for 128-byte rows, XOR {0,2,3,1}[(row>>2)&3] for the 64-byte rows of packed INT4: both are
 // conflict-free for ds_read_b128's lane groups) is applied to the
@@ -217,6 +217,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 constexpr int G2_STAGE = 32768;     // bytes per ring stage (A 16 KB + B up to 16 KB)
 constexpr int G2_STAGES = 4;
 
+// Benchmarks only (-DGEMM_TRACE): per-phase shader-clock totals of wave 0 of the first 64 tiles.
+#ifdef GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[64 * 8];
+#define G2_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define G2_T(var)
+#endif
+
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     int nwg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t g2_lds[];
     uint16_t* sc16 = reinterpret_cast<uint16_t*>(g2_lds + G2_STAGES * G2_STAGE);   // [G][128]
+    G2_T(tr_entry);
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -239,12 +248,6 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     const int bm = wg % nbm, bn = wg / nbm;
     const int m0 = bm * GM_BM, n0 = bn * GM_BN;
     const size_t brow_bytes = INT4 ? (size_t)K / 2 : (size_t)K;
-
-    // scale panel -> LDS, transposed (plain loads, finished before the first LDS-DMA is issued)
-    for (int idx = t; idx < GM_BN * G; idx += 512) {
-        const int n = idx / G, g = idx - n * G;
-        sc16[g * GM_BN + n] = B_scales[(size_t)min(n0 + n, N - 1) * G + g];
-    }
 
     // per-lane source offsets of this thread's pieces (a piece = one wave instruction = 1 KB)
     size_t a_src[2], b_src[2];
@@ -312,29 +315,21 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         }
     }
 
-    __syncthreads();   // scale panel visible; no LDS-DMA outstanding yet
-    issue_tile(0);
-    if (G > 1) issue_tile(1);
-    if (G > 2) issue_tile(2);
-
-    for (int kt = 0; kt < G; kt++) {
-        // tile kt has landed for this wave's own pieces; the barrier extends that to all waves
-        // and also says that every wave is done reading the stage tile kt+3 will overwrite
-        if (kt + 2 < G) {          // tiles kt+1 and kt+2 stay in flight
-            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else if (kt + 1 < G) {
-            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + 3 < G) issue_tile(kt + 3);
-
+    // Each K step has two phases separated by barriers: LOAD (read this wave's fragments of tile
+    // kt from LDS into registers) and MATH (16 MFMAs on registers only, the LDS-DMA requests of
+    // tile kt+3 issued under them, then the fp32 rescale).  The two waves that share a SIMD (w and w+4, i.e. the two m-halves)
+    // run one barrier apart, so one is in LOAD while the other is in MATH: the MFMA pipe is fed
+    // by one wave at a time while the other's LDS reads and LDS-DMA requests issue underneath.
+    // Barrier b: half 0 enters LOAD(kt) at b = 2kt and MATH(kt) at 2kt+1, half 1 one later.
+    //  - tile kt is read after barrier 2kt (half 0) / 2kt+1 (half 1); every wave has waited for
+    //    its own pieces of tile kt before it arrives at barrier 2kt (half 0: end of MATH(kt-1),
+    //    half 1: end of LOAD(kt-1));
+    //  - tile kt+3 reuses the stage of tile kt-1, whose last reader (half 1, LOAD(kt-1)) drained
+    //    its reads before barrier 2kt, and is requested in MATH(kt), after barrier 2kt+1.
+    v4i fa[4][2], fb[2][2];
+    float sc[2];
+    auto load_phase = [&](int kt) {
         const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
-        v4i fa[4][2], fb[2][2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             if constexpr (INT4) {
@@ -367,14 +362,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
                 fa[i][1] = c1;
             }
         }
-        float sc[2];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const float sv = h2f(sc16[kt * GM_BN + wn * 32 + j * 16 + r]);
             sc[j] = INT4 ? sv * 0.0625f : sv;
         }
-
+    };
+    auto math_phase = [&](int kt) {
         v4i acc[4][2];
+        __builtin_amdgcn_s_setprio(1);   // the wave feeding the MFMA pipe goes first on its SIMD
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -382,6 +378,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i][0], fb[j][0], v4i{0, 0, 0, 0}, 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i][1], fb[j][1], acc[i][j], 0, 0, 0);
             }
+        // tile kt+3 is requested here, under the MFMAs: its stage (tile kt-1) was released at the
+        // barrier that opened this phase at the latest
+        __builtin_amdgcn_s_setprio(0);
+        if (kt + 3 < G) issue_tile(kt + 3);
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -391,21 +391,131 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
                     const v2f a2 = v2f{(float)acc[i][j][2 * e], (float)acc[i][j][2 * e + 1]};
                     run[i][j][e] = __builtin_elementwise_fma(a2, v2f{sc[j], sc[j]}, run[i][j][e]);
                 }
-    }
-
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int m = m0 + wm * 64 + i * 16 + q * 4 + e;
-            if (m >= M) continue;
-            const float as = A_scales[m];
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int n = n0 + wn * 32 + j * 16 + r;
-                if (n < N) C[(size_t)m * N + n] = f2h_mul(run[i][j][e >> 1][e & 1], as);
-            }
+    };
+    // this wave's pieces of tile j have landed; `ahead` later tiles (as many as exist) stay in flight
+    auto wait_tile = [&](int j, int ahead = 2) {
+        if (j >= G) return;
+        const int later = min(ahead, G - 1 - j);
+        if (later == 2) {
+            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (later == 1) {
+            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+    };
+    auto barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    issue_tile(0);
+    if (G > 1) issue_tile(1);
+    if (G > 2) issue_tile(2);
+    // scale panel -> LDS, transposed to [group][column], behind the first tile requests (its plain
+    // loads make the compiler drain them too, which the wait below would do anyway)
+    if ((G & 7) == 0 && (reinterpret_cast<uintptr_t>(B_scales) & 15) == 0) {
+        for (int idx = t; idx < GM_BN * (G >> 3); idx += 512) {      // 8 consecutive groups of one column
+            const int n = idx / (G >> 3), g8 = (idx - n * (G >> 3)) * 8;
+            const v4i v = *reinterpret_cast<const v4i*>(B_scales + (size_t)min(n0 + n, N - 1) * G + g8);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                sc16[(g8 + e) * GM_BN + n] = (uint16_t)(((uint32_t)v[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+        }
+    } else {
+        for (int idx = t; idx < GM_BN * G; idx += 512) {
+            const int n = idx / G, g = idx - n * G;
+            sc16[g * GM_BN + n] = B_scales[(size_t)min(n0 + n, N - 1) * G + g];
+        }
+    }
+    wait_tile(0);
+    barrier();   // scale panel and tile 0 visible to every wave
+#ifdef GEMM_TRACE
+    unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long tr_start = __builtin_readcyclecounter();
+#endif
+    if (wm == 1) barrier();                 // half 1 runs one barrier behind
+    for (int kt = 0; kt < G; kt++) {
+        G2_T(t0);
+        barrier();
+        G2_T(t1);
+        G2_T(t2);
+        load_phase(kt);
+        if (wm == 1) wait_tile(kt + 1, 1);   // half 1 has requested up to tile kt+2 so far
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G2_T(t3);
+        barrier();
+        G2_T(t4);
+        math_phase(kt);
+        if (wm == 0) wait_tile(kt + 1, 2);
+#ifdef GEMM_TRACE
+        asm volatile("s_nop 0" ::: "memory");
+        const unsigned long long t5 = __builtin_readcyclecounter();
+        tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4;
+#endif
+    }
+#ifdef GEMM_TRACE
+    if (lane == 0 && wg < 8) {
+        const int slot = wg * 8 + w;
+        g_gemm_trace[slot * 8 + 0] = __builtin_readcyclecounter() - tr_start;
+        g_gemm_trace[slot * 8 + 6] = tr_start - tr_entry;
+        g_gemm_trace[slot * 8 + 7] = __builtin_readcyclecounter();   // loop end (absolute)
+        for (int i = 0; i < 5; i++) g_gemm_trace[slot * 8 + 1 + i] = tr[i];
+    }
+#endif
+    if (wm == 0) barrier();                 // same barrier count for both halves
+
+    // Output: half(running * A_scale[m]).  The lane layout of the accumulators (4 consecutive rows
+    // of one column) would give 2-byte stores; the tile goes through LDS (the ring is idle now)
+    // and leaves as 16-byte row segments.
+    const bool vec_store = (N & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    if (vec_store) {
+        constexpr int CS = GM_BN + 8;   // halves per LDS row (16-byte aligned, rows 4 banks apart)
+        uint16_t* ct = reinterpret_cast<uint16_t*>(g2_lds);
+        barrier();                      // every wave is done with the ring
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int lm = wm * 64 + i * 16 + q * 4 + e;
+                const float as = A_scales[min(m0 + lm, M - 1)];
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    ct[lm * CS + wn * 32 + j * 16 + r] = f2h_mul(run[i][j][e >> 1][e & 1], as);
+            }
+        barrier();
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int idx = p * 512 + t, lm = idx >> 4, c8 = (idx & 15) * 8;
+            const int m = m0 + lm, n = n0 + c8;
+            if (m < M && n < N)   // N % 8 == 0: a segment is inside or outside as a whole
+                *reinterpret_cast<v4i*>(C + (size_t)m * N + n) = *reinterpret_cast<const v4i*>(ct + lm * CS + c8);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int m = m0 + wm * 64 + i * 16 + q * 4 + e;
+                if (m >= M) continue;
+                const float as = A_scales[m];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int n = n0 + wn * 32 + j * 16 + r;
+                    if (n < N) C[(size_t)m * N + n] = f2h_mul(run[i][j][e >> 1][e & 1], as);
+                }
+            }
+    }
+#ifdef GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && wg < 8) {
+        const int slot = wg * 8 + w;
+        g_gemm_trace[slot * 8 + 7] = __builtin_readcyclecounter() - g_gemm_trace[slot * 8 + 7];
+    }
+#endif
 }
 
 template <bool INT4>
@@ -425,6 +535,12 @@ static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const voi
                                                                    (int)M, (int)K, (int)N, G, nbm, nwg);
     return hipGetLastError();
 }
+
+#ifdef GEMM_TRACE
+extern "C" int cactus_hip_debug_gemm_trace(unsigned long long* out512) {
+    return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 512);
+}
+#endif
 
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
                               const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
