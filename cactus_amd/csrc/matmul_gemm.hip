@@ -522,12 +522,15 @@ template <bool INT4>
 static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
                                uint16_t* C, size_t M, size_t K, size_t N, int G, hipStream_t st) {
     const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
-    static bool attr_set = false;   // per template instance; setting it again is harmless
-    if (!attr_set) {
+    // more than 64 KB of dynamic LDS has to be allowed once per device
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<INT4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int nbm = (int)((M + GM_BM - 1) / GM_BM), nbn = (int)((N + GM_BN - 1) / GM_BN);
     const int nwg = nbm * nbn;
