@@ -68,13 +68,9 @@ struct UnitRegs {
 // ALDS:  activations (M*K bytes) are staged in LDS once per workgroup and the MFMA row operand
 //        is read from there; otherwise it is loaded from global memory (L2) with the ring.
 // GS:    also write the INT32 group sums (parity checks); C may then be null.
-// FQ:    (with ALDS) A is the FP16 activation matrix; every workgroup quantizes it per row on
-//        its way into LDS -- absmax, scale = max(absmax/127, 1e-10), q = rne(clamp(x * (1/scale)))
-//        exactly as act_quant_rowwise_kernel does -- so a matmul node with FP16 activations
-//        (graph_ops_nn.cpp:166-177) is one launch.  A_scales is then an optional OUTPUT.
-template <bool INT4, int W, int P, bool ALDS, bool GS, bool FQ>
+template <bool INT4, int W, int P, bool ALDS, bool GS>
 __device__ __forceinline__ void skinny_body(
-    const int8_t* __restrict__ A, float* __restrict__ A_scales,
+    const int8_t* __restrict__ A, const float* __restrict__ A_scales,
     const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
     uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
     int ablate, int tile) {
@@ -86,7 +82,6 @@ __device__ __forceinline__ void skinny_body(
     float* gbuf = sk_lds;                                                        // [M*16][SCP] group sums
     float* scl = sk_lds + (size_t)M * 16 * SCP;                                  // [16][GP] fp32 scales
     int8_t* lds_a = reinterpret_cast<int8_t*>(scl + SK_TN * GP);                 // [M][K] (ALDS)
-    float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4] (FQ)
 
     SK_STAMP(0);
     const int t = threadIdx.x;
@@ -99,7 +94,7 @@ __device__ __forceinline__ void skinny_body(
     const __amdgpu_buffer_rsrc_t brsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t arsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(A), 0, FQ ? 2 * M * K : M * K, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(A), 0, M * K, 0x00020000);
     // per-lane byte offsets; rows past the end are pushed out of range and read as zero
     const unsigned boff = (n0 + r < N) ? (unsigned)(n0 + r) * row_bytes + q * 16 : SK_OOB;
     const unsigned aoff = (r < M) ? (unsigned)r * K + (INT4 ? q * 32 : q * 16) : SK_OOB;
@@ -208,8 +203,8 @@ __device__ __forceinline__ void skinny_body(
 
         // activations -> LDS (ALDS runs as a single chunk): requested first, written to LDS
         // after the first weight loads have been issued
-        constexpr int AST = FQ ? 2 : 4;   // 16-byte pieces per thread held in registers (FQ: M = 1 rows fit)
-        const int npieces = FQ ? M * K / 8 : M * K / 16;
+        constexpr int AST = 4;   // 16-byte pieces per thread held in registers
+        const int npieces = M * K / 16;
         v4i a_stage[AST];
         if constexpr (ALDS) {
 #pragma unroll
@@ -238,64 +233,7 @@ __device__ __forceinline__ void skinny_body(
                 scl[row * GP + g] = INT4 ? s * 0.0625f : s;
             }
         }
-        if constexpr (ALDS && FQ) {
-            // per-row absmax: wave partials -> LDS -> every thread reduces the W partials
-            float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            auto row_of = [&](int i16) {   // M <= 4: compares instead of a division
-                const int e = i16 * 8;
-                return min((M > 1 && e >= K) + (M > 2 && e >= 2 * K) + (M > 3 && e >= 3 * K), 3);
-            };
-            auto fold = [&](int i16, v4i x) {
-                const int row = row_of(i16);
-                const float v = absmax8_bits(x);
-#pragma unroll
-                for (int m = 0; m < 4; m++) mx[m] = (row == m) ? fmaxf(mx[m], v) : mx[m];
-            };
-#pragma unroll
-            for (int j = 0; j < AST; j++) fold(t + j * W * 64, a_stage[j]);
-#pragma unroll 1
-            for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) fold(i16, ldg(A + (size_t)i16 * 16));
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-                if (m < M) mx[m] = wave_max(mx[m]);
-            if (lane == 0) {
-#pragma unroll
-                for (int m = 0; m < 4; m++) wmax[w * 4 + m] = mx[m];
-            }
-            SK_STAMP(1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            SK_STAMP(2);
-            float inv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                if (m < M) {
-                    float r = wmax[m];
-#pragma unroll
-                    for (int ww = 1; ww < W; ww++) r = fmaxf(r, wmax[ww * 4 + m]);
-                    float sc = r / 127.0f;
-                    if (sc < 1e-10f) sc = 1e-10f;
-                    inv[m] = 1.0f / sc;
-                }
-            }
-            auto quant_piece = [&](int i16, v4i x) {
-                const int row = row_of(i16);
-                const float iv = row == 0 ? inv[0] : (row == 1 ? inv[1] : (row == 2 ? inv[2] : inv[3]));
-                *reinterpret_cast<uint2*>(lds_a + (size_t)i16 * 8) = quant8_bits(x, iv);
-            };
-#pragma unroll
-            for (int j = 0; j < AST; j++) {
-                const int i16 = t + j * W * 64;
-                if (i16 < npieces) quant_piece(i16, a_stage[j]);
-            }
-#pragma unroll 1
-            for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64)
-                quant_piece(i16, ldg(A + (size_t)i16 * 16));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        } else if constexpr (ALDS) {   // LDS writes visible, weight loads stay in flight
+        if constexpr (ALDS) {   // LDS writes visible, weight loads stay in flight
 #pragma unroll
             for (int j = 0; j < AST; j++) {
                 const int i16 = t + j * W * 64;
@@ -368,30 +306,19 @@ __device__ __forceinline__ void skinny_body(
             const int e = t + k * W * 64;
             const int cm = e >> 4, cn = e & 15;
             if (e < M * 16 && n0 + cn < N) {
-                float as;
-                if constexpr (FQ) {
-                    float r = wmax[cm];
-#pragma unroll
-                    for (int ww = 1; ww < W; ww++) r = fmaxf(r, wmax[ww * 4 + cm]);
-                    as = r / 127.0f;
-                    if (as < 1e-10f) as = 1e-10f;
-                    if (A_scales != nullptr && tile == 0 && cn == 0) A_scales[cm] = as;
-                } else {
-                    as = A_scales[cm];
-                }
-                C[(size_t)cm * N + n0 + cn] = f2h_mul(run[k], as);
+                C[(size_t)cm * N + n0 + cn] = f2h_mul(run[k], A_scales[cm]);
             }
         }
     }
 }
 
-template <bool INT4, int W, int P, bool ALDS, bool GS, bool FQ = false>
+template <bool INT4, int W, int P, bool ALDS, bool GS>
 __global__ __launch_bounds__(W * 64) void skinny_kernel(
-    const int8_t* __restrict__ A, float* __restrict__ A_scales,
+    const int8_t* __restrict__ A, const float* __restrict__ A_scales,
     const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
     uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
     int ablate) {
-    skinny_body<INT4, W, P, ALDS, GS, FQ>(A, A_scales, B, B_scales, C, gsums, M, K, N, G, SC, ablate,
+    skinny_body<INT4, W, P, ALDS, GS>(A, A_scales, B, B_scales, C, gsums, M, K, N, G, SC, ablate,
                                           (int)blockIdx.x);
 }
 
@@ -710,7 +637,7 @@ namespace {
 template <bool INT4, int W, int P, bool ALDS>
 hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, const uint16_t* B_scales,
                       uint16_t* C, int32_t* gsums, size_t M, size_t K, size_t N, hipStream_t st) {
-    float* A_scales = const_cast<float*>(A_scales_c);   // written only by the FQ kernels
+    const float* A_scales = A_scales_c;
     const int G = (int)(K / 128);
     constexpr int GPU_ = INT4 ? 2 : 1;
     if (INT4 && (G & 1)) return hipErrorInvalidValue;   // packed units hold two groups

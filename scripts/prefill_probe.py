@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Times FP16 (prefill) attention and hybrid prefill chunks."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cactus_amd.hip as H
+from bench import time_events
+H.init(0)
+gen = torch.Generator(device="cuda").manual_seed(5)
+for S, Hq, Hkv, D in ((256, 16, 8, 128), (1024, 16, 8, 128), (4096, 16, 8, 128)):
+    q = (torch.rand((1, S, Hq, D), device="cuda", generator=gen) * 2 - 1).half()
+    k = (torch.rand((1, S, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+    v = (torch.rand((1, S, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+    ms = time_events(lambda i: H.attention_f16(q, k, v, 0.0), 5, warm=2)
+    fl = 4.0 * S * S / 2 * Hq * D
+    print(f"f16 causal prefill S={S}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.2f} TFLOP/s (causal half counted)")
