@@ -16,6 +16,9 @@ HEADERS = ["common.hip.h", "kernels.h", "graph.h", os.path.join("..", "..", "inc
 # compiler must not introduce (or break) any -- results are compared bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function"]
+# Per-file additions.  The GEMM's fp32 rescale runs beside MFMAs, where a packed v_pk_fma_f32
+# costs more than the two v_fma_f32 it replaces: keep the SLP vectorizer from packing them.
+EXTRA_FLAGS = {"matmul_gemm.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -38,7 +41,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = ["hipcc"] + FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+            cmd = ["hipcc"] + FLAGS + EXTRA_FLAGS.get(s, []) + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd)))

@@ -18,6 +18,7 @@
 // chunks 0-3 of an LDS row, high nibbles (odd k) chunks 4-7, each nibble moved to the top of
 // its byte (value * 16, sign included); the activation tile is de-interleaved the same way
 // and the factor 16 is folded into the scale.
+#include <type_traits>
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -217,6 +218,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 constexpr int G2_STAGE = 32768;     // bytes per ring stage (A 16 KB + B up to 16 KB)
 constexpr int G2_STAGES = 4;
 
+// Timing experiments only (results are wrong when nonzero): bit 0 no LDS-DMA requests in the loop,
+// bit 1 no rescale, bit 2 one MFMA per slab instead of 8, bit 3 no fragment reads, bit 4 no barrier.
+#ifndef G2_TIMING
+#define G2_TIMING 0
+#endif
+
 // Benchmarks only (-DGEMM_TRACE): per-phase shader-clock totals of wave 0 of the first 64 tiles.
 #ifdef GEMM_TRACE
 __device__ unsigned long long g_gemm_trace[64 * 8];
@@ -226,6 +233,15 @@ __device__ unsigned long long g_gemm_trace[64 * 8];
 #endif
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
+
+// A wave-uniform pointer pinned in scalar registers, so that `p + 32-bit lane offset` selects the
+// scalar-base addressing form and advancing p costs no vector instructions.
+template <typename T>
+__device__ __forceinline__ const T* scalar_ptr(const T* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <bool INT4>
@@ -249,37 +265,44 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     const int m0 = bm * GM_BM, n0 = bn * GM_BN;
     const size_t brow_bytes = INT4 ? (size_t)K / 2 : (size_t)K;
 
-    // per-lane source offsets of this thread's pieces (a piece = one wave instruction = 1 KB)
-    size_t a_src[2], b_src[2];
+    // Source of this thread's pieces (a piece = one wave instruction = 1 KB): a workgroup-uniform
+    // base that advances with kt (scalar registers) plus a 32-bit per-lane offset inside the tile's
+    // rows, which is the addressing form global_load_lds takes without any per-step vector math.
+    // Rows past M / N are clamped to the last row (their results are never stored).
+    const int8_t* a_base = A + (size_t)m0 * K;
+    const uint8_t* b_base = B + (size_t)n0 * brow_bytes;
+    unsigned a_src[2], b_src[2];
     int a_dst[2], b_dst[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int pi = w + 8 * j;
         const int row = pi * 8 + (lane >> 3), slot = lane & 7, ch = slot ^ ((row >> 1) & 7);
-        a_src[j] = (size_t)min(m0 + row, M - 1) * K + ch * 16;
+        a_src[j] = (unsigned)min(row, M - 1 - m0) * (unsigned)K + ch * 16;
         a_dst[j] = pi * 1024;
         if constexpr (!INT4) {
-            b_src[j] = (size_t)min(n0 + row, N - 1) * brow_bytes + ch * 16;
+            b_src[j] = (unsigned)min(row, N - 1 - n0) * (unsigned)brow_bytes + ch * 16;
             b_dst[j] = 16384 + pi * 1024;
         }
     }
     if constexpr (INT4) {
         const int row = w * 16 + (lane >> 2), slot = lane & 3, ch = slot ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3);
-        b_src[0] = (size_t)min(n0 + row, N - 1) * brow_bytes + ch * 16;
+        b_src[0] = (unsigned)min(row, N - 1 - n0) * (unsigned)brow_bytes + ch * 16;
         b_dst[0] = 16384 + w * 1024;
         b_src[1] = 0; b_dst[1] = 0;
     }
     auto issue_tile = [&](int kt) {
         uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
+        const int8_t* ak = scalar_ptr(a_base + (size_t)kt * 128);
+        const uint8_t* bk = scalar_ptr(b_base + (size_t)kt * (INT4 ? 64 : 128));
 #pragma unroll
         for (int j = 0; j < 2; j++)
-            __builtin_amdgcn_global_load_lds((gptr_t)(A + a_src[j] + (size_t)kt * 128), (lptr_t)(st + a_dst[j]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ak + a_src[j]), (lptr_t)(st + a_dst[j]), 16, 0, 0);
         if constexpr (INT4) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(B + b_src[0] + (size_t)kt * 64), (lptr_t)(st + b_dst[0]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(bk + b_src[0]), (lptr_t)(st + b_dst[0]), 16, 0, 0);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; j++)
-                __builtin_amdgcn_global_load_lds((gptr_t)(B + b_src[j] + (size_t)kt * 128), (lptr_t)(st + b_dst[j]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(bk + b_src[j]), (lptr_t)(st + b_dst[j]), 16, 0, 0);
         }
     };
 
@@ -437,36 +460,144 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     unsigned long long tr[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long tr_start = __builtin_readcyclecounter();
 #endif
-    if (wm == 1) barrier();                 // half 1 runs one barrier behind
-    for (int kt = 0; kt < G; kt++) {
-        G2_T(t0);
-        barrier();
-        G2_T(t1);
-        G2_T(t2);
-        load_phase(kt);
-        if (wm == 1) wait_tile(kt + 1, 1);   // half 1 has requested up to tile kt+2 so far
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        G2_T(t3);
-        barrier();
-        G2_T(t4);
-        math_phase(kt);
-        if (wm == 0) wait_tile(kt + 1, 2);
-#ifdef GEMM_TRACE
-        asm volatile("s_nop 0" ::: "memory");
-        const unsigned long long t5 = __builtin_readcyclecounter();
-        tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4;
-#endif
+    if constexpr (!INT4) {
+        // INT8: one software-pipelined stream per wave.  A K step is two 64-deep slabs; while the 8
+        // MFMAs of one slab run, the wave's LDS reads of the next slab are in flight and the fp32
+        // rescale of the PREVIOUS group's accumulators (a second register set) issues in the MFMA
+        // shadows, so neither the LDS latency nor the VALU work sits between MFMAs.  One barrier
+        // per K step, between the slabs: before it every wave has waited for its own pieces of
+        // tile kt+1 and has consumed every fragment of tile kt-1, so after it tile kt+1 is
+        // readable and the stage of tile kt-1 can take the requests of tile kt+3.
+        v4i f0a[4], f0b[2], f1a[4], f1b[2];
+        auto read_slab = [&](int kt, int sl, v4i (&xa)[4], v4i (&xb)[2]) {
+            const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
+#pragma unroll
+            for (int j = 0; j < 2; j++) xb[j] = *reinterpret_cast<const v4i*>(st + fb_off[j][sl]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) xa[i] = *reinterpret_cast<const v4i*>(st + fa_off[i][sl]);
+        };
+        // plain v_fma_f32 on purpose: beside MFMAs a packed fp32 fma costs far more than the two
+        // scalar ones it replaces (this file is built without SLP vectorization for the same reason)
+        auto rescale_half = [&](int half, v4i (&ap)[4][2], const float (&sp)[2]) {
+#pragma unroll
+            for (int i = 2 * half; i < 2 * half + 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        run[i][j][e >> 1][e & 1] = __builtin_fmaf((float)ap[i][j][e], sp[j], run[i][j][e >> 1][e & 1]);
+        };
+        // Issue order inside a half step, pinned with sched_barriers (nothing is scheduled across
+        // one): the LDS-DMA requests, the first MFMA (its operands were requested half a step ago,
+        // so the wait in front of it is short), the LDS reads of the next slab, then the other 7
+        // MFMAs with 4 VALU of the rescale (2 conversions, 2 fmas) behind each.
+        auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+        auto shadow = [&]() {
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#pragma unroll
+            for (int x = 0; x < 7; x++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+            fence();
+        };
+        // one K step: MFMAs into `ac`, rescale of `ap` (the previous group, raw fp16 scales `sp`);
+        // `steady`: tiles kt+1..kt+3 exist, so the body is one branch-free block
+        auto step = [&](auto steady, int kt, v4i (&ac)[4][2], v4i (&ap)[4][2], const unsigned (&sp)[2], unsigned (&sn)[2]) {
+            constexpr bool ST = decltype(steady)::value;
+            fence();
+            ac[0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f0a[0], f0b[0], v4i{0, 0, 0, 0}, 0, 0, 0);
+            fence();
+            if (!(G2_TIMING & 8)) read_slab(kt, 1, f1a, f1b);
+#pragma unroll
+            for (int j = 0; j < 2; j++) sn[j] = sc16[kt * GM_BN + wn * 32 + j * 16 + r];
+            fence();
+            const float spf[2] = {h2f((uint16_t)sp[0]), h2f((uint16_t)sp[1])};
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    if ((i | j) && !(G2_TIMING & 4)) ac[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f0a[i], f0b[j], v4i{0, 0, 0, 0}, 0, 0, 0);
+            if (!(G2_TIMING & 2)) rescale_half(0, ap, spf);
+            shadow();
+            if constexpr (G2_TIMING & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (ST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else wait_tile(kt + 1, 1);
+            if (!(G2_TIMING & 16)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            fence();
+            if (!(G2_TIMING & 1) && (ST || kt + 3 < G)) issue_tile(kt + 3);
+            fence();
+            ac[0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f1a[0], f1b[0], ac[0][0], 0, 0, 0);
+            fence();
+            if (!(G2_TIMING & 8) && (ST || kt + 1 < G)) read_slab(kt + 1, 0, f0a, f0b);
+            fence();
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    if ((i | j) && !(G2_TIMING & 4)) ac[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f1a[i], f1b[j], ac[i][j], 0, 0, 0);
+            if (!(G2_TIMING & 2)) rescale_half(1, ap, spf);
+            shadow();
+        };
+        v4i accx[4][2], accy[4][2];
+        unsigned scx[2] = {0, 0}, scy[2] = {0, 0};   // raw fp16 scales, widened when used
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) accy[i][j] = v4i{0, 0, 0, 0};
+        read_slab(0, 0, f0a, f0b);
+        int kt = 0;
+        for (; kt + 4 < G; kt += 2) {
+            step(std::true_type{}, kt, accx, accy, scy, scx);       // first pass: accy = 0, scy = 0 leaves `run` at +0
+            step(std::true_type{}, kt + 1, accy, accx, scx, scy);
+        }
+        for (; kt + 1 < G; kt += 2) {
+            step(std::false_type{}, kt, accx, accy, scy, scx);
+            step(std::false_type{}, kt + 1, accy, accx, scx, scy);
+        }
+        if (kt < G) {
+            step(std::false_type{}, kt, accx, accy, scy, scx);
+            const float lf[2] = {h2f((uint16_t)scx[0]), h2f((uint16_t)scx[1])};
+            rescale_half(0, accx, lf);
+            rescale_half(1, accx, lf);
+        } else {
+            const float lf[2] = {h2f((uint16_t)scy[0]), h2f((uint16_t)scy[1])};
+            rescale_half(0, accy, lf);
+            rescale_half(1, accy, lf);
+        }
+    } else {
+        if (wm == 1) barrier();                 // half 1 runs one barrier behind
+        for (int kt = 0; kt < G; kt++) {
+            G2_T(t0);
+            barrier();
+            G2_T(t1);
+            G2_T(t2);
+            load_phase(kt);
+            if (wm == 1) wait_tile(kt + 1, 1);   // half 1 has requested up to tile kt+2 so far
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            G2_T(t3);
+            barrier();
+            G2_T(t4);
+            math_phase(kt);
+            if (wm == 0) wait_tile(kt + 1, 2);
+    #ifdef GEMM_TRACE
+            asm volatile("s_nop 0" ::: "memory");
+            const unsigned long long t5 = __builtin_readcyclecounter();
+            tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4;
+    #endif
+        }
+    #ifdef GEMM_TRACE
+        if (lane == 0 && wg < 8) {
+            const int slot = wg * 8 + w;
+            g_gemm_trace[slot * 8 + 0] = __builtin_readcyclecounter() - tr_start;
+            g_gemm_trace[slot * 8 + 6] = tr_start - tr_entry;
+            g_gemm_trace[slot * 8 + 7] = __builtin_readcyclecounter();   // loop end (absolute)
+            for (int i = 0; i < 5; i++) g_gemm_trace[slot * 8 + 1 + i] = tr[i];
+        }
+    #endif
+        if (wm == 0) barrier();                 // same barrier count for both halves
     }
-#ifdef GEMM_TRACE
-    if (lane == 0 && wg < 8) {
-        const int slot = wg * 8 + w;
-        g_gemm_trace[slot * 8 + 0] = __builtin_readcyclecounter() - tr_start;
-        g_gemm_trace[slot * 8 + 6] = tr_start - tr_entry;
-        g_gemm_trace[slot * 8 + 7] = __builtin_readcyclecounter();   // loop end (absolute)
-        for (int i = 0; i < 5; i++) g_gemm_trace[slot * 8 + 1 + i] = tr[i];
-    }
-#endif
-    if (wm == 0) barrier();                 // same barrier count for both halves
 
     // Output: half(running * A_scale[m]).  The lane layout of the accumulators (4 consecutive rows
     // of one column) would give 2-byte stores; the tile goes through LDS (the ring is idle now)

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
 // (and its scales) is requested right after the last unit of tile i has been consumed, so the
 // memory pipe stays busy while tile i's barrier, fp32 chain and store run: the per-tile
 // latencies that bound a one-tile workgroup overlap with streaming.
-template <bool INT4, int W, int P>
+template <bool INT4, int W, int P, int CT>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
                                         uint16_t* __restrict__ C, int M, int K, int N, int tile0, int ntile) {
@@ -341,9 +341,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     constexpr int step = W * GPU_;
     const int SC = ((G + step - 1) / step) * step;
     const int SCP = SC + 4, GP = ((G + 3) & ~3) + 4;
-    float* gbuf = sk_lds;                                                        // [M*16][SCP] group sums
-    float* scl = sk_lds + (size_t)M * 16 * SCP;                                  // [16][GP] fp32 scales
-    int8_t* lds_a = reinterpret_cast<int8_t*>(scl + SK_TN * GP);                 // [M][K]
+    constexpr int TR = SK_TN * CT;   // weight rows per tile: CT MFMA column tiles share each activation fragment
+    float* gbuf = sk_lds;                                                        // [CT][M*16][SCP] group sums
+    float* scl = sk_lds + (size_t)CT * M * 16 * SCP;                             // [TR][GP] fp32 scales
+    int8_t* lds_a = reinterpret_cast<int8_t*>(scl + TR * GP);                    // [M][K]
     float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4]
 
     const int t = threadIdx.x;
@@ -362,29 +363,47 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     const bool a_live = r < M;
     const v4i zero4 = {0, 0, 0, 0};
     const int nunits = G / GPU_;
-    const bool sc_fast_shape = ((G & 7) == 0) && (SK_TN * G / 8 <= W * 64) &&
+    const bool sc_fast_shape = ((G & 7) == 0) && (TR * G / 8 <= CT * W * 64) &&
                                ((reinterpret_cast<uintptr_t>(B_scales) & 15) == 0);
 
-    struct Unit { v4i b[2]; };
+    struct Unit { v4i b[CT][2]; };
+    struct Boff { unsigned o[CT]; };
+    struct ScRegs { v4i v[CT]; };
     Unit ring[P];
     auto tile_boff = [&](int tl) {   // tl past the last tile or row past N: out of range, reads zeros
-        const int n = tl * SK_TN + r;
-        return (tl < tile0 + ntile && n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
+        Boff bo;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            const int n = tl * TR + ct * SK_TN + r;
+            bo.o[ct] = (tl < tile0 + ntile && n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
+        }
+        return bo;
     };
-    auto load_unit = [&](int u, unsigned boff, Unit& R) {
+    auto load_unit = [&](int u, const Boff& bo, Unit& R) {
         const unsigned uo = (u < nunits) ? (unsigned)u * 128u : SK_OOB;
-        R.b[0] = buf_load<2>(brsrc, boff + uo, 0);
-        R.b[1] = buf_load<2>(brsrc, boff + uo, 64);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            R.b[ct][0] = buf_load<2>(brsrc, bo.o[ct] + uo, 0);
+            R.b[ct][1] = buf_load<2>(brsrc, bo.o[ct] + uo, 64);
+        }
     };
-    auto scale_off = [&](int tl) {   // this thread's 8 scales of tile tl (fast path), else out of range
-        const bool fast = sc_fast_shape && tl < tile0 + ntile && tl * SK_TN + SK_TN <= N && t < SK_TN * G / 8;
-        return fast ? (unsigned)(((size_t)tl * SK_TN * G + (size_t)t * 8) * 2) : SK_OOB;
+    // this thread's chunks of 8 scales of tile tl (fast path: chunk t + j*W*64), else out of range
+    auto load_scales = [&](int tl) {
+        ScRegs sr;
+        const bool fast = sc_fast_shape && tl < tile0 + ntile && tl * TR + TR <= N;
+#pragma unroll
+        for (int j = 0; j < CT; j++) {
+            const int ch = t + j * W * 64;
+            const unsigned off = (fast && ch < TR * G / 8) ? (unsigned)(((size_t)tl * TR * G + (size_t)ch * 8) * 2) : SK_OOB;
+            sr.v[j] = buf_load<0>(srsrc, off, 0);
+        }
+        return sr;
     };
-    auto put_group = [&](int gl, v4i acc) {
+    auto put_group = [&](int ct, int gl, v4i acc) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int m = q * 4 + i;
-            if (m < M && gl < G) gbuf[(m * 16 + r) * SCP + gl] = (float)acc[i];
+            if (m < M && gl < G) gbuf[((ct * M + m) * 16 + r) * SCP + gl] = (float)acc[i];
         }
     };
     auto compute_unit = [&](int u, const Unit& R) {
@@ -393,13 +412,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             v4i a[4] = {ldg(ap), ldg(ap + 16), ldg(ap + 128), ldg(ap + 144)};
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                v4i blo, bhi, ae, ao;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t x = (uint32_t)R.b[h][i];
-                    blo[i] = (int)((x & 0x0F0F0F0Fu) << 4);
-                    bhi[i] = (int)(x & 0xF0F0F0F0u);
-                }
+                v4i ae, ao;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const uint32_t lo = (uint32_t)a[2 * h + (i >> 1)][(2 * i) & 3];
@@ -407,20 +420,33 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
                     ae[i] = a_live ? (int)__builtin_amdgcn_perm(hi, lo, 0x06040200u) : 0;
                     ao[i] = a_live ? (int)__builtin_amdgcn_perm(hi, lo, 0x07050301u) : 0;
                 }
-                v4i acc = zero4;
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, blo, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bhi, acc, 0, 0, 0);
-                put_group(2 * u + h, acc);
+#pragma unroll
+                for (int ct = 0; ct < CT; ct++) {
+                    v4i blo, bhi;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t x = (uint32_t)R.b[ct][h][i];
+                        blo[i] = (int)((x & 0x0F0F0F0Fu) << 4);
+                        bhi[i] = (int)(x & 0xF0F0F0F0u);
+                    }
+                    v4i acc = zero4;
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, blo, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bhi, acc, 0, 0, 0);
+                    put_group(ct, 2 * u + h, acc);
+                }
             }
         } else {
             const int8_t* ap = aptr_lds + (size_t)min(u, nunits - 1) * 128;
             v4i a0 = ldg(ap), a1 = ldg(ap + 64);
             a0 = a_live ? a0 : zero4;
             a1 = a_live ? a1 : zero4;
-            v4i acc = zero4;
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, R.b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, R.b[1], acc, 0, 0, 0);
-            put_group(u, acc);
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++) {
+                v4i acc = zero4;
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, R.b[ct][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, R.b[ct][1], acc, 0, 0, 0);
+                put_group(ct, u, acc);
+            }
         }
     };
 
@@ -430,10 +456,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     v4i a_stage[AST];
 #pragma unroll
     for (int j = 0; j < AST; j++) a_stage[j] = buf_load<0>(xrsrc, (unsigned)(t + j * W * 64) * 16u, 0);
-    unsigned boff = tile_boff(tile0);
+    Boff boff = tile_boff(tile0);
 #pragma unroll
     for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
-    v4i sc_regs = buf_load<0>(srsrc, scale_off(tile0), 0);
+    ScRegs sc_regs = load_scales(tile0);
     {
         float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto row_of = [&](int i16) {   // M <= 4: compares instead of a division
@@ -490,11 +516,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         asm volatile("" ::: "memory");
     }
 
-    constexpr int NR = (64 + W * 64 - 1) / (W * 64);   // chain elements per thread (M * 16 <= 64)
     const int rounds = (nunits + W * P - 1) / (W * P);
     for (int sub = 0; sub < ntile; sub++) {
         const int tl = tile0 + sub;
-        const int n0 = tl * SK_TN;
+        const int n0 = tl * TR;
         for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
 #pragma unroll
             for (int p = 0; p < P; p++) {
@@ -510,24 +535,28 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         boff = tile_boff(tl + 1);
 #pragma unroll
         for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
-        const v4i sc_next = buf_load<0>(srsrc, scale_off(tl + 1), 0);
+        const ScRegs sc_next = load_scales(tl + 1);
 
         // this tile's scales -> LDS as fp32 (x 1/16 for INT4)
-        const bool fast = sc_fast_shape && n0 + SK_TN <= N;
+        const bool fast = sc_fast_shape && n0 + TR <= N;
         if (fast) {
-            if (t < SK_TN * G / 8) {
-                const int row = (t * 8) / G, g = (t * 8) - row * G;
-                float* dst = scl + row * GP + g;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t x = (uint32_t)sc_regs[i];
-                    const float lo = h2f((uint16_t)(x & 0xFFFFu)), hi = h2f((uint16_t)(x >> 16));
-                    dst[2 * i] = INT4 ? lo * 0.0625f : lo;
-                    dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
+            for (int j = 0; j < CT; j++) {
+                const int ch = t + j * W * 64;
+                if (ch < TR * G / 8) {
+                    const int row = (ch * 8) / G, g = (ch * 8) - row * G;
+                    float* dst = scl + row * GP + g;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t x = (uint32_t)sc_regs.v[j][i];
+                        const float lo = h2f((uint16_t)(x & 0xFFFFu)), hi = h2f((uint16_t)(x >> 16));
+                        dst[2 * i] = INT4 ? lo * 0.0625f : lo;
+                        dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
+                    }
                 }
             }
         } else {
-            for (int idx = t; idx < SK_TN * G; idx += W * 64) {
+            for (int idx = t; idx < TR * G; idx += W * 64) {
                 const int row = idx / G, g = idx - row * G;
                 const float sv = h2f(B_scales[(size_t)min(n0 + row, N - 1) * G + g]);
                 scl[row * GP + g] = INT4 ? sv * 0.0625f : sv;
@@ -537,12 +566,12 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
-#pragma unroll
-        for (int k = 0; k < NR; k++) {
-            const int e = t + k * W * 64;
-            if (e < M * 16) {
-                const float* sp = scl + (e & 15) * GP;
-                const float* gp = gbuf + (size_t)e * SCP;
+        // wave ct runs the chains of column tile ct (W >= CT): thread (m, n) walks its groups in order
+        {
+            const int ct = w, e = lane;
+            if (ct < CT && e < M * 16) {
+                const float* sp = scl + (ct * SK_TN + (e & 15)) * GP;
+                const float* gp = gbuf + ((size_t)ct * M * 16 + e) * SCP;
                 float run = 0.0f;
                 int gl = 0;
                 for (; gl + 16 <= G; gl += 16) {   // eight ds_read_b128, then the serial fma chain
@@ -562,8 +591,8 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
                 for (int ww = 1; ww < W; ww++) rmax = fmaxf(rmax, wmax[ww * 4 + cm]);
                 float as = rmax / 127.0f;
                 if (as < 1e-10f) as = 1e-10f;
-                if (scales_out != nullptr && tl == 0 && cn == 0) scales_out[cm] = as;
-                if (n0 + cn < N) C[(size_t)cm * N + n0 + cn] = f2h_mul(run, as);
+                if (scales_out != nullptr && tl == 0 && ct == 0 && cn == 0) scales_out[cm] = as;
+                if (n0 + ct * SK_TN + cn < N) C[(size_t)cm * N + n0 + ct * SK_TN + cn] = f2h_mul(run, as);
             }
         }
         if (sub + 1 < ntile) {   // group sums and scales are rewritten by the next tile
@@ -575,15 +604,15 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     }
 }
 
-template <bool INT4, int W, int P>
+template <bool INT4, int W, int P, int CT>
 __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __restrict__ X,
                                                           float* __restrict__ scales_out,
                                                           const uint8_t* __restrict__ B,
                                                           const uint16_t* __restrict__ B_scales,
                                                           uint16_t* __restrict__ C, int M, int K, int N, int tpw) {
-    const int tiles = (N + SK_TN - 1) / SK_TN;
+    const int tiles = (N + SK_TN * CT - 1) / (SK_TN * CT);
     const int tile0 = (int)blockIdx.x * tpw;
-    fq_body<INT4, W, P>(X, scales_out, B, B_scales, C, M, K, N, tile0, min(tpw, tiles - tile0));
+    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, tile0, min(tpw, tiles - tile0));
 }
 
 // Several independent FP16-activation matmuls (M <= 4 each) in one launch: the projections
@@ -594,8 +623,8 @@ __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __res
 constexpr int SK_MAXB = 16;
 struct SkinnyBatch {
     int count;
-    int tpw;                        // 16-row tiles per workgroup
-    int tile_end[SK_MAXB];          // running sum of workgroups: ceil(ceil(N / 16) / tpw) per problem
+    int tpw;                        // tiles per workgroup
+    int tile_end[SK_MAXB];          // running sum of workgroups: ceil(tiles / tpw) per problem
     const void* X[SK_MAXB];
     const void* B[SK_MAXB];
     const uint16_t* Bs[SK_MAXB];
@@ -603,7 +632,7 @@ struct SkinnyBatch {
     int M[SK_MAXB], K[SK_MAXB], N[SK_MAXB];
 };
 
-template <bool INT4, int W, int P>
+template <bool INT4, int W, int P, int CT>
 #ifndef SK_WPE
 #define SK_WPE 0
 #endif
@@ -620,8 +649,8 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     int pi = 0;
     while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
     const int tile0 = (blk - (pi ? bt.tile_end[pi - 1] : 0)) * bt.tpw;
-    const int tiles = (bt.N[pi] + SK_TN - 1) / SK_TN;
-    fq_body<INT4, W, P>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
+    const int tiles = (bt.N[pi] + SK_TN * CT - 1) / (SK_TN * CT);
+    fq_body<INT4, W, P, CT>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                         reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
                         bt.N[pi], tile0, min(bt.tpw, tiles - tile0));
 }
@@ -678,14 +707,22 @@ bool skinny_fused_quant_ok(bool int4, size_t M, size_t K) {
     return M >= 1 && M <= 4 && K % 128 == 0 && (!int4 || K % 256 == 0) && lds <= 60 * 1024;
 }
 
-static size_t fq_lds_bytes(bool int4, int W, size_t M, size_t K) {
+static size_t fq_lds_bytes(bool int4, int W, int CT, size_t M, size_t K) {
     const size_t G = K / 128, step = (size_t)W * (int4 ? 2 : 1);
     const size_t SC = ((G + step - 1) / step) * step;
-    return (M * 16 * (SC + 4) + (size_t)SK_TN * (((G + 3) & ~(size_t)3) + 4)) * sizeof(float) +
+    return ((size_t)CT * M * 16 * (SC + 4) + (size_t)CT * SK_TN * (((G + 3) & ~(size_t)3) + 4)) * sizeof(float) +
            ((M * K + 15) & ~(size_t)15) + (size_t)W * 4 * sizeof(float);
 }
 
-// Waves per tile and tiles per workgroup for `tiles` 16-row tiles whose longest row is K.
+// Column tiles per tile.  2 (32 weight rows per workgroup, -DSK_CT=2) halves the quantization
+// prologues per byte streamed but needs 180 registers (2 waves per SIMD instead of 4) and
+// measured slower on the 16-shape sweep: 3.5 TB/s at best (ring depth 2) against 4.3 at 1.
+#ifndef SK_CT
+#define SK_CT 1
+#endif
+
+// Waves per tile, MFMA column tiles per tile and tiles per workgroup for `rows16` groups of 16
+// weight rows whose longest row is K.
 // Waves: as many as the row can feed (about 4 units each), but with plenty of tiles fewer waves
 // per tile keep more independent tiles in flight and shorten the waits at the tile barriers
 // (16-shape sweep, 3840 tiles: 8 waves 3.5 TB/s, 4 waves 4.1, 2 waves 4.0, 1 wave 3.4).
@@ -693,37 +730,47 @@ static size_t fq_lds_bytes(bool int4, int W, size_t M, size_t K) {
 // this tile's epilogue, but on the same sweep that measured slower than one tile per workgroup
 // (4 waves: 4.3 TB/s at 1 tile, 3.9 at 2, 2.8 at 4; 8 waves: 3.8 at 2, 4.0 at 4) -- more
 // independent workgroups hide the per-tile latencies better -- so it stays 1.
-static void fq_shape(bool int4, size_t kmax, size_t tiles, int* W_out, int* tpw_out) {
+static void fq_shape(bool int4, size_t kmax, size_t rows16, int* W_out, int* ct_out, int* tpw_out) {
     int W = skinny_waves(int4, kmax);
-    while (W > 1 && tiles * (size_t)W > 16384) W /= 2;
+    int ct = SK_CT;
+    if (W < ct) ct = 1;
+    while (W > ct && (rows16 / ct) * (size_t)W > 16384) W /= 2;
     *W_out = W;
+    *ct_out = ct;
     *tpw_out = 1;
 }
 
 int g_skinny_tpw = 1;   // benchmarks only: tiles per workgroup of the 2xxxx variants
+int g_skinny_ct = 1;    // benchmarks only: column tiles per tile of the 2xxxx variants
 
-static hipError_t launch_fq(bool int4, int W, int tpw, const uint16_t* X, float* scales_out, const void* B,
+static hipError_t launch_fq(bool int4, int W, int ct, int tpw, const uint16_t* X, float* scales_out, const void* B,
                             const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N, hipStream_t st) {
     if (!skinny_fused_quant_ok(int4, M, K) || tpw < 1) return hipErrorInvalidValue;
     if (N * (int4 ? K / 2 : K) > (size_t(1) << 31)) return hipErrorInvalidValue;
-    const size_t lds = fq_lds_bytes(int4, W, M, K);
+    if (ct != SK_CT || W < 2 || fq_lds_bytes(int4, W, ct, M, K) > 64 * 1024) ct = 1;
+    const size_t lds = fq_lds_bytes(int4, W, ct, M, K);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const size_t tiles = (N + SK_TN - 1) / SK_TN;
+    const size_t tiles = (N + SK_TN * ct - 1) / (SK_TN * ct);
     const dim3 grid((unsigned)((tiles + tpw - 1) / tpw)), block(W * 64);
-#define FQ_CASE(WW)                                                                                              \
-    case WW:                                                                                                      \
-        if (int4)                                                                                                 \
-            skinny_fq_kernel<true, WW, 4><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C, \
-                                                                  (int)M, (int)K, (int)N, tpw);                   \
-        else                                                                                                      \
-            skinny_fq_kernel<false, WW, 4><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C, \
-                                                                   (int)M, (int)K, (int)N, tpw);                  \
+#define FQ_LAUNCH(I4, WW, CC)                                                                                     \
+    skinny_fq_kernel<I4, WW, 4, CC><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C,       \
+                                                             (int)M, (int)K, (int)N, tpw)
+#define FQ_CASE(WW)                                                        \
+    case WW:                                                                \
+        if (ct == 2 && WW >= 2) {                                           \
+            if (int4) FQ_LAUNCH(true, WW, (WW >= 2 ? SK_CT : 1));           \
+            else FQ_LAUNCH(false, WW, (WW >= 2 ? SK_CT : 1));               \
+        } else {                                                            \
+            if (int4) FQ_LAUNCH(true, WW, 1);                               \
+            else FQ_LAUNCH(false, WW, 1);                                   \
+        }                                                                   \
         break;
     switch (W) {
         FQ_CASE(1) FQ_CASE(2) FQ_CASE(4) FQ_CASE(8)
         default: return hipErrorInvalidValue;
     }
 #undef FQ_CASE
+#undef FQ_LAUNCH
     return hipGetLastError();
 }
 
@@ -739,7 +786,7 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
         return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
                     : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
     if (variant >= 20000 && variant < 30000)   // fused quantization: A holds FP16 activations; W from the code
-        return launch_fq(int4, (variant - 20000) / 100, g_skinny_tpw, reinterpret_cast<const uint16_t*>(A), nullptr, B,
+        return launch_fq(int4, (variant - 20000) / 100, g_skinny_ct, g_skinny_tpw, reinterpret_cast<const uint16_t*>(A), nullptr, B,
                          B_scales, C, M, K, N, st);
     switch (variant) {
         SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
@@ -754,9 +801,9 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
 hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
                                    const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
                                    hipStream_t st) {
-    int W, tpw;
-    fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &tpw);
-    return launch_fq(int4, W, tpw, X, scales_out, B, B_scales, C, M, K, N, st);
+    int W, ct, tpw;
+    fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &ct, &tpw);
+    return launch_fq(int4, W, ct, tpw, X, scales_out, B, B_scales, C, M, K, N, st);
 }
 
 // Batched fused launch: every problem must satisfy skinny_fused_quant_ok and the alignment the
@@ -772,23 +819,26 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
         if (pr[i].K > kmax) kmax = pr[i].K;
     size_t total_tiles = 0;
     for (size_t i = 0; i < count; i++) total_tiles += (pr[i].N + SK_TN - 1) / SK_TN;
-    int W, tpw;
-    fq_shape(int4, kmax, total_tiles, &W, &tpw);
+    int W, ct, tpw;
+    fq_shape(int4, kmax, total_tiles, &W, &ct, &tpw);
 #ifdef SK_BATCH_W
     W = SK_BATCH_W;
 #endif
 #ifdef SK_BATCH_TPW
     tpw = SK_BATCH_TPW;
 #endif
+    if (ct == 2)
+        for (size_t i = 0; i < count; i++)
+            if (W < 2 || fq_lds_bytes(int4, W, 2, pr[i].M, pr[i].K) > 64 * 1024) ct = 1;
     bt.tpw = tpw;
     for (size_t i = 0; i < count; i++) {
         const SkinnyProblem& q = pr[i];
         if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
         if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
-        const size_t l = fq_lds_bytes(int4, W, q.M, q.K);
+        const size_t l = fq_lds_bytes(int4, W, ct, q.M, q.K);
         if (l > 64 * 1024) return hipErrorInvalidValue;
         if (l > lds) lds = l;
-        const size_t ptiles = (q.N + SK_TN - 1) / SK_TN;
+        const size_t ptiles = (q.N + SK_TN * ct - 1) / (SK_TN * ct);
         tiles += (ptiles + tpw - 1) / tpw;   // workgroups
         if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
         bt.tile_end[i] = (int)tiles;
@@ -797,10 +847,15 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     }
     if (tiles == 0) return hipSuccess;
     const dim3 grid((unsigned)tiles), block(W * 64);
-#define FQB_CASE(WW)                                                                  \
-    case WW:                                                                           \
-        if (int4) skinny_batch_kernel<true, WW, SK_BATCH_P><<<grid, block, lds, st>>>(bt);      \
-        else skinny_batch_kernel<false, WW, SK_BATCH_P><<<grid, block, lds, st>>>(bt);          \
+#define FQB_CASE(WW)                                                                                      \
+    case WW:                                                                                               \
+        if (ct == 2 && WW >= 2) {                                                                          \
+            if (int4) skinny_batch_kernel<true, WW, SK_BATCH_P, (WW >= 2 ? SK_CT : 1)><<<grid, block, lds, st>>>(bt);  \
+            else skinny_batch_kernel<false, WW, SK_BATCH_P, (WW >= 2 ? SK_CT : 1)><<<grid, block, lds, st>>>(bt);      \
+        } else {                                                                                           \
+            if (int4) skinny_batch_kernel<true, WW, SK_BATCH_P, 1><<<grid, block, lds, st>>>(bt);          \
+            else skinny_batch_kernel<false, WW, SK_BATCH_P, 1><<<grid, block, lds, st>>>(bt);              \
+        }                                                                                                  \
         break;
     switch (W) {
         FQB_CASE(1) FQB_CASE(2) FQB_CASE(4) FQB_CASE(8)
