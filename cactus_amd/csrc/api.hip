@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -309,6 +310,198 @@ int cactus_hip_unpack_int4_to_int8_dev(const uint8_t* packed, int8_t* unpacked, 
     return CACTUS_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Ops between the hot kernels of a decoder block
+// ---------------------------------------------------------------------------------------
+int cactus_hip_rms_norm_f16_dev(const cactus_half_t* input, const cactus_half_t* weight, cactus_half_t* output,
+                                size_t batch_size, size_t dims, float eps, void* stream) {
+    if (batch_size * dims == 0) return CACTUS_HIP_OK;
+    if (!input || !weight || !output) return fail(CACTUS_HIP_EINVAL, "rms_norm: null operand");
+    if (dims > (size_t(1) << 30)) return fail(CACTUS_HIP_EINVAL, "rms_norm: dims too large");
+    hipError_t e = launch_rms_norm(input, weight, output, batch_size, dims, eps, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "rms_norm launch", e);
+    return CACTUS_HIP_OK;
+}
+
+namespace {
+
+// cos/sin tables of one (head_dim, theta), built on the host exactly as the reference builds
+// them (kernel_attention.cpp:594-604: powf/cosf/sinf in fp32, rounded to half) and mirrored on
+// each device that used them.  Rows are independent of the table length, so the table grows by
+// appending rows.
+struct RopeTable {
+    std::vector<uint16_t> cos_h, sin_h;   // [npos][half_dim]
+    size_t npos = 0;
+    struct Dev { uint16_t* cos = nullptr; uint16_t* sin = nullptr; size_t npos = 0; };
+    std::unordered_map<int, Dev> dev;
+};
+std::mutex g_rope_mu;
+std::vector<std::pair<std::pair<size_t, uint32_t>, RopeTable>> g_rope;   // key: (head_dim, theta bits)
+
+uint16_t host_f2h(float f) {   // fp32 -> binary16, round to nearest even
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((x > 0x7F800000u) ? 0x200u : 0));
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            // rounds to infinity
+    if (x < 0x33000001u) return (uint16_t)sign;                          // below half of the smallest subnormal
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7FFFFFu) | 0x800000u;
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);
+    uint32_t kept = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (kept & 1))) kept++;
+    uint32_t out = e >= -14 ? (((uint32_t)(e + 15) << 10) + (kept - 0x400u)) : kept;
+    return (uint16_t)(sign | out);
+}
+
+// device pointers to the table rows [start_pos, start_pos + seq) of (head_dim, theta)
+int rope_rows(size_t head_dim, float theta, size_t start_pos, size_t seq, const uint16_t** cos_out,
+              const uint16_t** sin_out) {
+    const size_t half_dim = head_dim / 2, need = start_pos + seq;
+    uint32_t tb;
+    memcpy(&tb, &theta, 4);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_rope_mu);
+    RopeTable* t = nullptr;
+    for (auto& kv : g_rope)
+        if (kv.first.first == head_dim && kv.first.second == tb) t = &kv.second;
+    if (!t) {
+        g_rope.emplace_back(std::make_pair(head_dim, tb), RopeTable{});
+        t = &g_rope.back().second;
+    }
+    if (t->npos < need) {
+        size_t cap = t->npos ? t->npos : 1024;
+        while (cap < need) cap *= 2;
+        t->cos_h.resize(cap * half_dim);
+        t->sin_h.resize(cap * half_dim);
+        for (size_t pos = t->npos; pos < cap; pos++) {
+            const float pos_float = static_cast<float>(pos);
+            for (size_t i = 0; i < half_dim; i++) {
+                const float freq = 1.0f / powf(theta, (2.0f * i) / head_dim);
+                const float angle = pos_float * freq;
+                t->cos_h[pos * half_dim + i] = host_f2h(cosf(angle));
+                t->sin_h[pos * half_dim + i] = host_f2h(sinf(angle));
+            }
+        }
+        t->npos = cap;
+    }
+    RopeTable::Dev& d = t->dev[dev];
+    if (d.npos < need) {
+        const size_t bytes = t->npos * half_dim * sizeof(uint16_t);
+        uint16_t *nc = nullptr, *ns = nullptr;
+        if (hipMalloc(&nc, bytes) != hipSuccess || hipMalloc(&ns, bytes) != hipSuccess) {
+            if (nc) (void)hipFree(nc);
+            return fail(CACTUS_HIP_ENOMEM, "rope table hipMalloc");
+        }
+        HIP_TRY(hipMemcpy(nc, t->cos_h.data(), bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ns, t->sin_h.data(), bytes, hipMemcpyHostToDevice));
+        if (d.cos) {   // kernels still reading the old rows finish before the free returns
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(d.cos));
+            HIP_TRY(hipFree(d.sin));
+        }
+        d.cos = nc; d.sin = ns; d.npos = t->npos;
+    }
+    *cos_out = d.cos + start_pos * half_dim;
+    *sin_out = d.sin + start_pos * half_dim;
+    return CACTUS_HIP_OK;
+}
+
+}  // namespace
+
+int cactus_hip_rope_reserve(size_t head_dim, float theta, size_t max_positions) {
+    if (head_dim < 2 || max_positions == 0) return CACTUS_HIP_OK;
+    const uint16_t *c, *s;
+    return rope_rows(head_dim, theta, 0, max_positions, &c, &s);
+}
+
+int cactus_hip_rope_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t batch_size, size_t seq_len,
+                            size_t num_heads, size_t head_dim, size_t start_pos, float theta, void* stream) {
+    if (batch_size * seq_len * num_heads * head_dim == 0) return CACTUS_HIP_OK;
+    if (!input || !output) return fail(CACTUS_HIP_EINVAL, "rope: null operand");
+    if (head_dim & 1) return fail(CACTUS_HIP_EINVAL, "rope: head_dim must be even");
+    if (seq_len > (size_t(1) << 30) || num_heads > (size_t(1) << 30) || head_dim > (size_t(1) << 30))
+        return fail(CACTUS_HIP_EINVAL, "rope: dimension too large");
+    const uint16_t *c, *s;
+    int rc = rope_rows(head_dim, theta, start_pos, seq_len, &c, &s);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_rope(input, output, c, s, batch_size, seq_len, num_heads, head_dim, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "rope launch", e);
+    return CACTUS_HIP_OK;
+}
+
+namespace {
+int unary_dev(int op, const char* name, const cactus_half_t* in, cactus_half_t* out, size_t n, void* stream) {
+    if (n == 0) return CACTUS_HIP_OK;
+    if (!in || !out) return fail(CACTUS_HIP_EINVAL, name);
+    hipError_t e = launch_unary(op, in, out, n, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, name, e);
+    return CACTUS_HIP_OK;
+}
+int binary_dev(int op, const char* name, const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n,
+               void* stream) {
+    if (n == 0) return CACTUS_HIP_OK;
+    if (!a || !b || !out) return fail(CACTUS_HIP_EINVAL, name);
+    hipError_t e = launch_binary(op, a, b, out, n, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, name, e);
+    return CACTUS_HIP_OK;
+}
+}  // namespace
+
+int cactus_hip_silu_f16_dev(const cactus_half_t* in, cactus_half_t* out, size_t n, void* stream) {
+    return unary_dev(0, "silu: null operand or launch failure", in, out, n, stream);
+}
+int cactus_hip_gelu_f16_dev(const cactus_half_t* in, cactus_half_t* out, size_t n, void* stream) {
+    return unary_dev(1, "gelu: null operand or launch failure", in, out, n, stream);
+}
+int cactus_hip_add_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n, void* stream) {
+    return binary_dev(0, "add: null operand or launch failure", a, b, out, n, stream);
+}
+int cactus_hip_subtract_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n,
+                                void* stream) {
+    return binary_dev(1, "subtract: null operand or launch failure", a, b, out, n, stream);
+}
+int cactus_hip_multiply_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n,
+                                void* stream) {
+    return binary_dev(2, "multiply: null operand or launch failure", a, b, out, n, stream);
+}
+int cactus_hip_divide_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n,
+                              void* stream) {
+    return binary_dev(3, "divide: null operand or launch failure", a, b, out, n, stream);
+}
+int cactus_hip_add_f16_clipped_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n,
+                                   void* stream) {
+    return binary_dev(4, "add_clipped: null operand or launch failure", a, b, out, n, stream);
+}
+
+int cactus_hip_embedding_int8_dev(const int8_t* embeddings, const cactus_half_t* scales, const int32_t* indices,
+                                  cactus_half_t* output, size_t num_indices, size_t vocab_size, size_t hidden_dim,
+                                  size_t group_size, int* bad_index_flag, void* stream) {
+    if (num_indices * hidden_dim == 0) return CACTUS_HIP_OK;
+    if (!embeddings || !scales || !indices || !output) return fail(CACTUS_HIP_EINVAL, "embedding: null operand");
+    if (group_size == 0 || hidden_dim % group_size != 0)
+        return fail(CACTUS_HIP_EINVAL, "embedding: hidden_dim must be whole groups");
+    if (num_indices > 0x7FFFFFFFull || hidden_dim > 0x7FFFFFFFull) return fail(CACTUS_HIP_EINVAL, "embedding: too large");
+    hipError_t e = launch_embedding_int8(embeddings, scales, indices, output, num_indices, vocab_size, hidden_dim,
+                                         group_size, bad_index_flag, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "embedding launch", e);
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_embedding_f16_dev(const cactus_half_t* embeddings, const int32_t* indices, cactus_half_t* output,
+                                 size_t num_indices, size_t vocab_size, size_t hidden_dim, int* bad_index_flag,
+                                 void* stream) {
+    if (num_indices * hidden_dim == 0) return CACTUS_HIP_OK;
+    if (!embeddings || !indices || !output) return fail(CACTUS_HIP_EINVAL, "embedding: null operand");
+    if (num_indices > 0x7FFFFFFFull || hidden_dim > 0x7FFFFFFFull) return fail(CACTUS_HIP_EINVAL, "embedding: too large");
+    hipError_t e = launch_embedding_f16(embeddings, indices, output, num_indices, vocab_size, hidden_dim,
+                                        bad_index_flag, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "embedding launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_attention_f16_dev(const cactus_half_t* queries, const cactus_half_t* keys,
                                  const cactus_half_t* values, cactus_half_t* output, size_t batch_size,
                                  size_t seq_len, size_t kv_seq_len, size_t num_q_heads,
@@ -607,6 +800,77 @@ void cactus_hip_unpack_int4_to_int8(const uint8_t* packed, int8_t* unpacked, siz
         CACTUS_HIP_OK)
         return;
     download(unpacked, du, unpacked_count);
+}
+
+void cactus_hip_rms_norm_f16(const cactus_half_t* input, const cactus_half_t* weight, cactus_half_t* output,
+                             size_t batch_size, size_t dims, float eps) {
+    const size_t n = batch_size * dims;
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    void* di = upload(0, input, n * 2);
+    void* dw = upload(1, weight, dims * 2);
+    void* dout = stage(2, n * 2);
+    if (!di || !dw || !dout) return;
+    if (cactus_hip_rms_norm_f16_dev((const cactus_half_t*)di, (const cactus_half_t*)dw, (cactus_half_t*)dout,
+                                    batch_size, dims, eps, nullptr) != CACTUS_HIP_OK)
+        return;
+    download(output, dout, n * 2);
+}
+
+void cactus_hip_rope_f16(const cactus_half_t* input, cactus_half_t* output, size_t batch_size, size_t seq_len,
+                         size_t num_heads, size_t head_dim, size_t start_pos, float theta) {
+    const size_t n = batch_size * seq_len * num_heads * head_dim;
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    void* di = upload(0, input, n * 2);
+    void* dout = stage(1, n * 2);
+    if (!di || !dout) return;
+    if (cactus_hip_rope_f16_dev((const cactus_half_t*)di, (cactus_half_t*)dout, batch_size, seq_len, num_heads,
+                                head_dim, start_pos, theta, nullptr) != CACTUS_HIP_OK)
+        return;
+    download(output, dout, n * 2);
+}
+
+namespace {
+typedef int (*unary_dev_fn)(const cactus_half_t*, cactus_half_t*, size_t, void*);
+typedef int (*binary_dev_fn)(const cactus_half_t*, const cactus_half_t*, cactus_half_t*, size_t, void*);
+void unary_host(unary_dev_fn fn, const cactus_half_t* in, cactus_half_t* out, size_t n) {
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    void* di = upload(0, in, n * 2);
+    void* dout = stage(1, n * 2);
+    if (!di || !dout) return;
+    if (fn((const cactus_half_t*)di, (cactus_half_t*)dout, n, nullptr) != CACTUS_HIP_OK) return;
+    download(out, dout, n * 2);
+}
+void binary_host(binary_dev_fn fn, const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n) {
+    if (n == 0) return;
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    void* da = upload(0, a, n * 2);
+    void* db = upload(1, b, n * 2);
+    void* dout = stage(2, n * 2);
+    if (!da || !db || !dout) return;
+    if (fn((const cactus_half_t*)da, (const cactus_half_t*)db, (cactus_half_t*)dout, n, nullptr) != CACTUS_HIP_OK) return;
+    download(out, dout, n * 2);
+}
+}  // namespace
+
+void cactus_hip_silu_f16(const cactus_half_t* in, cactus_half_t* out, size_t n) { unary_host(cactus_hip_silu_f16_dev, in, out, n); }
+void cactus_hip_gelu_f16(const cactus_half_t* in, cactus_half_t* out, size_t n) { unary_host(cactus_hip_gelu_f16_dev, in, out, n); }
+void cactus_hip_add_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n) {
+    binary_host(cactus_hip_add_f16_dev, a, b, out, n);
+}
+void cactus_hip_add_f16_clipped(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n) {
+    binary_host(cactus_hip_add_f16_clipped_dev, a, b, out, n);
+}
+void cactus_hip_subtract_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n) {
+    binary_host(cactus_hip_subtract_f16_dev, a, b, out, n);
+}
+void cactus_hip_multiply_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n) {
+    binary_host(cactus_hip_multiply_f16_dev, a, b, out, n);
+}
+void cactus_hip_divide_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n) {
+    binary_host(cactus_hip_divide_f16_dev, a, b, out, n);
 }
 
 }  // extern "C"

@@ -92,4 +92,19 @@ struct AttnArgs {
 size_t attn_workspace_bytes(const AttnArgs& a);
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 
+// block_ops.hip: the ops between the hot kernels of a decoder block
+hipError_t launch_rms_norm(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t rows, size_t dims, float eps,
+                           hipStream_t st);
+// cos_t / sin_t: [seq][head_dim / 2] table rows for positions start_pos .. start_pos + seq - 1
+hipError_t launch_rope(const uint16_t* in, uint16_t* out, const uint16_t* cos_t, const uint16_t* sin_t,
+                       size_t batch, size_t seq, size_t heads, size_t head_dim, hipStream_t st);
+hipError_t launch_unary(int op, const uint16_t* in, uint16_t* out, size_t n, hipStream_t st);     // 0 silu, 1 gelu
+hipError_t launch_binary(int op, const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n,
+                         hipStream_t st);   // 0 add, 1 subtract, 2 multiply, 3 divide, 4 clipped add
+hipError_t launch_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices, uint16_t* out,
+                                 size_t num_indices, size_t vocab, size_t hidden, size_t group_size, int* bad,
+                                 hipStream_t st);
+hipError_t launch_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out, size_t num_indices,
+                                size_t vocab, size_t hidden, int* bad, hipStream_t st);
+
 }  // namespace cactus_hip

@@ -28,6 +28,7 @@
 // Waves drop their converted group sums into LDS; thread (m, n) of the workgroup then runs the
 // g-ordered fma chain with the tile's scales, which are copied to LDS behind the first weight
 // loads.  K is processed in chunks only when the M*G group sums exceed the LDS budget.
+#include <algorithm>
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __res
 constexpr int SK_MAXB = 16;
 struct SkinnyBatch {
     int count;
-    int tpw;                        // tiles per workgroup
+    int tpw[SK_MAXB];               // tiles per workgroup, per problem
     int tile_end[SK_MAXB];          // running sum of workgroups: ceil(tiles / tpw) per problem
     const void* X[SK_MAXB];
     const void* B[SK_MAXB];
@@ -648,11 +649,12 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     const int blk = (int)blockIdx.x;
     int pi = 0;
     while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
-    const int tile0 = (blk - (pi ? bt.tile_end[pi - 1] : 0)) * bt.tpw;
+    const int tpw = bt.tpw[pi];
+    const int tile0 = (blk - (pi ? bt.tile_end[pi - 1] : 0)) * tpw;
     const int tiles = (bt.N[pi] + SK_TN * CT - 1) / (SK_TN * CT);
     fq_body<INT4, W, P, CT>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                         reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
-                        bt.N[pi], tile0, min(bt.tpw, tiles - tile0));
+                        bt.N[pi], tile0, min(tpw, tiles - tile0));
 }
 
 int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
@@ -830,16 +832,29 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     if (ct == 2)
         for (size_t i = 0; i < count; i++)
             if (W < 2 || fq_lds_bytes(int4, W, 2, pr[i].M, pr[i].K) > 64 * 1024) ct = 1;
-    bt.tpw = tpw;
+#ifndef SK_TARGET_KB
+#define SK_TARGET_KB 0
+#endif
+    // Longest rows first: a workgroup's run time grows with K, so the long ones start first and
+    // the short ones fill the tail of the launch (16-shape sweep: 51 us against 56 in K*N order).
+    size_t order[SK_MAXB];
+    for (size_t i = 0; i < count; i++) order[i] = i;
+    std::stable_sort(order, order + count, [&](size_t a, size_t b) { return pr[a].K > pr[b].K; });
     for (size_t i = 0; i < count; i++) {
-        const SkinnyProblem& q = pr[i];
+        const SkinnyProblem& q = pr[order[i]];
         if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
         if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
         const size_t l = fq_lds_bytes(int4, W, ct, q.M, q.K);
         if (l > 64 * 1024) return hipErrorInvalidValue;
         if (l > lds) lds = l;
         const size_t ptiles = (q.N + SK_TN * ct - 1) / (SK_TN * ct);
-        tiles += (ptiles + tpw - 1) / tpw;   // workgroups
+        int ptpw = tpw;
+        if (SK_TARGET_KB > 0) {   // equal bytes per workgroup: short rows take several tiles
+            const size_t tile_bytes = (size_t)SK_TN * ct * (int4 ? q.K / 2 : q.K);
+            ptpw = (int)std::max<size_t>(1, ((size_t)SK_TARGET_KB * 1024 + tile_bytes / 2) / tile_bytes);
+        }
+        bt.tpw[i] = ptpw;
+        tiles += (ptiles + ptpw - 1) / ptpw;   // workgroups
         if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
         bt.tile_end[i] = (int)tiles;
         bt.X[i] = q.X; bt.B[i] = q.B; bt.Bs[i] = q.Bs; bt.C[i] = q.C;

@@ -61,6 +61,27 @@ SIGNATURES = {
     "cactus_hip_fp16_max_abs": (_f, [_vp, _sz]),
     "cactus_hip_fp16_to_int8": (None, [_vp, _vp, _sz, _f]),
     "cactus_hip_unpack_int4_to_int8": (None, [_vp, _vp, _sz]),
+    "cactus_hip_rms_norm_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _f, _vp]),
+    "cactus_hip_rope_f16_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _f, _vp]),
+    "cactus_hip_rope_reserve": (_i, [_sz, _f, _sz]),
+    "cactus_hip_silu_f16_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "cactus_hip_gelu_f16_dev": (_i, [_vp, _vp, _sz, _vp]),
+    "cactus_hip_add_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_add_f16_clipped_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_subtract_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_divide_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "cactus_hip_embedding_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "cactus_hip_rms_norm_f16": (None, [_vp, _vp, _vp, _sz, _sz, _f]),
+    "cactus_hip_rope_f16": (None, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _f]),
+    "cactus_hip_silu_f16": (None, [_vp, _vp, _sz]),
+    "cactus_hip_gelu_f16": (None, [_vp, _vp, _sz]),
+    "cactus_hip_add_f16": (None, [_vp, _vp, _vp, _sz]),
+    "cactus_hip_add_f16_clipped": (None, [_vp, _vp, _vp, _sz]),
+    "cactus_hip_subtract_f16": (None, [_vp, _vp, _vp, _sz]),
+    "cactus_hip_multiply_f16": (None, [_vp, _vp, _vp, _sz]),
+    "cactus_hip_divide_f16": (None, [_vp, _vp, _vp, _sz]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
@@ -214,6 +235,92 @@ def unpack_int4(packed, count, out=None):
     _dev(packed, torch.uint8)
     o = out if out is not None else torch.zeros((count,), dtype=torch.int8, device=packed.device)
     _check(lib.cactus_hip_unpack_int4_to_int8_dev(_p(packed), _p(o), count, _stream()))
+    return o
+
+
+def rms_norm(x, weight, eps=1e-5, out=None):
+    """fp16 [rows, dims] normalised row-wise and multiplied by weight [dims]."""
+    _dev(x, torch.float16); _dev(weight, torch.float16)
+    rows, dims = x.shape
+    o = out if out is not None else torch.empty_like(x)
+    _check(lib.cactus_hip_rms_norm_f16_dev(_p(x), _p(weight), _p(o), rows, dims, float(eps), _stream()))
+    return o
+
+
+def rope(x, theta, start_pos=0, out=None):
+    """Half-split rotary embedding on fp16 [batch, seq, heads, head_dim]."""
+    _dev(x, torch.float16)
+    B, S, H, D = x.shape
+    o = out if out is not None else torch.empty_like(x)
+    _check(lib.cactus_hip_rope_f16_dev(_p(x), _p(o), B, S, H, D, start_pos, float(theta), _stream()))
+    return o
+
+
+def rope_reserve(head_dim, theta, max_positions):
+    _check(lib.cactus_hip_rope_reserve(head_dim, float(theta), max_positions))
+
+
+def _unary(fn, x, out):
+    _dev(x, torch.float16)
+    o = out if out is not None else torch.empty_like(x)
+    _check(fn(_p(x), _p(o), x.numel(), _stream()))
+    return o
+
+
+def silu(x, out=None):
+    return _unary(lib.cactus_hip_silu_f16_dev, x, out)
+
+
+def gelu(x, out=None):
+    return _unary(lib.cactus_hip_gelu_f16_dev, x, out)
+
+
+def _binary(fn, a, b, out):
+    _dev(a, torch.float16); _dev(b, torch.float16)
+    assert a.shape == b.shape
+    o = out if out is not None else torch.empty_like(a)
+    _check(fn(_p(a), _p(b), _p(o), a.numel(), _stream()))
+    return o
+
+
+def add(a, b, out=None):
+    return _binary(lib.cactus_hip_add_f16_dev, a, b, out)
+
+
+def add_clipped(a, b, out=None):
+    return _binary(lib.cactus_hip_add_f16_clipped_dev, a, b, out)
+
+
+def subtract(a, b, out=None):
+    return _binary(lib.cactus_hip_subtract_f16_dev, a, b, out)
+
+
+def multiply(a, b, out=None):
+    return _binary(lib.cactus_hip_multiply_f16_dev, a, b, out)
+
+
+def divide(a, b, out=None):
+    return _binary(lib.cactus_hip_divide_f16_dev, a, b, out)
+
+
+def embedding(table, indices, scales=None, group_size=128, out=None):
+    """Rows of an INT8 (per-group fp16 scales) or FP16 table; indices int32 [n].  Raises on an
+    index outside the table (after synchronising, like the reference's exception)."""
+    _dev(indices, torch.int32)
+    vocab, hidden = table.shape
+    n = indices.numel()
+    o = out if out is not None else torch.empty((n, hidden), dtype=torch.float16, device=table.device)
+    bad = torch.zeros((1,), dtype=torch.int32, device=table.device)
+    if table.dtype == torch.int8:
+        _dev(table, torch.int8); _dev(scales, torch.float16)
+        _check(lib.cactus_hip_embedding_int8_dev(_p(table), _p(scales), _p(indices), _p(o), n, vocab, hidden,
+                                                 group_size, _p(bad), _stream()))
+    else:
+        _dev(table, torch.float16)
+        _check(lib.cactus_hip_embedding_f16_dev(_p(table), _p(indices), _p(o), n, vocab, hidden, _p(bad),
+                                                _stream()))
+    if int(bad.item()):
+        raise CactusHipError("Embedding index out of bounds")
     return o
 
 

@@ -151,6 +151,52 @@ int cactus_hip_quantize_kv_fp16_to_int8_dev(const cactus_half_t* src, int8_t* ds
 int cactus_hip_unpack_int4_to_int8_dev(const uint8_t* packed, int8_t* unpacked,
                                        size_t unpacked_count, void* stream);
 
+/* ---- ops between the hot kernels of a decoder block (device pointers) ---- */
+
+/* cactus_rms_norm_f16 (kernel.h:72-73; kernel_attention.cpp:484-563): input half[batch,dims],
+ * weight half[dims]; fp32 sum of squares in the reference's lane order, fp16 products. */
+int cactus_hip_rms_norm_f16_dev(const cactus_half_t* input, const cactus_half_t* weight,
+                                cactus_half_t* output, size_t batch_size, size_t dims, float eps,
+                                void* stream);
+
+/* cactus_rope_f16 (kernel.h:75-76; kernel_attention.cpp:614-676): half-split rotation on
+ * half[batch,seq,heads,head_dim], token s at position start_pos + s.  The cos/sin tables are
+ * built on the host as the reference builds them (:594-604) and kept per device; a call that
+ * needs more positions than the table holds grows it (a blocking allocation and copy), which
+ * cactus_hip_rope_reserve does ahead of time (e.g. before stream capture). */
+int cactus_hip_rope_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t batch_size,
+                            size_t seq_len, size_t num_heads, size_t head_dim, size_t start_pos,
+                            float theta, void* stream);
+int cactus_hip_rope_reserve(size_t head_dim, float theta, size_t max_positions);
+
+/* cactus_silu_f16 / cactus_gelu_f16 (kernel.h:81, 83; kernel_nn.cpp:12-91): the call is one
+ * piece: whole groups of 8 from the start take the reference's polynomial / rational formulas,
+ * the last n % 8 elements its scalar expf / tanhf ones. */
+int cactus_hip_silu_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t num_elements, void* stream);
+int cactus_hip_gelu_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t num_elements, void* stream);
+
+/* cactus_add_f16, cactus_add_f16_clipped, cactus_subtract_f16, cactus_multiply_f16,
+ * cactus_divide_f16 (kernel.h:20-24; kernel_blas.cpp:187-343): one fp16 operation per element;
+ * the clipped add sums in fp32 and clamps to +-65500. */
+int cactus_hip_add_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
+int cactus_hip_add_f16_clipped_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
+int cactus_hip_subtract_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
+int cactus_hip_multiply_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
+int cactus_hip_divide_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
+
+/* compute_embedding_node (graph_ops_tensor.cpp:226-320): output row i = row indices[i] of the
+ * table; INT8 rows with per-group fp16 scales dequantize as half(float(q) * float(scale))
+ * (:243-254), FP16 rows are copied (:301-316).  indices: device int32[num_indices].  An index
+ * outside [0, vocab_size) writes nothing for that row and stores 1 to *bad_index_flag (device
+ * int, may be NULL; the caller clears it) -- the reference throws there (:261-263). */
+int cactus_hip_embedding_int8_dev(const int8_t* embeddings, const cactus_half_t* scales,
+                                  const int32_t* indices, cactus_half_t* output, size_t num_indices,
+                                  size_t vocab_size, size_t hidden_dim, size_t group_size,
+                                  int* bad_index_flag, void* stream);
+int cactus_hip_embedding_f16_dev(const cactus_half_t* embeddings, const int32_t* indices,
+                                 cactus_half_t* output, size_t num_indices, size_t vocab_size,
+                                 size_t hidden_dim, int* bad_index_flag, void* stream);
+
 /* cactus_attention_f16 (kernel.h:87-90; kernel_attention.cpp:10-255).
  * Q half[B,S,Hq,D], K/V half[B,KV,Hkv,D], O half[B,S,Hq,D]; mask half[B,S,KV]
  * (0 = masked) or NULL.  scale 0 means 1/sqrt(D). */
@@ -217,6 +263,19 @@ void  cactus_hip_quantize_kv_fp16_to_int8(const cactus_half_t* src, int8_t* dst,
 float cactus_hip_fp16_max_abs(const cactus_half_t* src, size_t count);
 void  cactus_hip_fp16_to_int8(const cactus_half_t* src, int8_t* dst, size_t count, float scale);
 void  cactus_hip_unpack_int4_to_int8(const uint8_t* packed, int8_t* unpacked, size_t unpacked_count);
+
+/* Host-pointer forms of the block ops, same argument meaning as kernel.h:20-24, 72-83. */
+void  cactus_hip_rms_norm_f16(const cactus_half_t* input, const cactus_half_t* weight, cactus_half_t* output,
+                              size_t batch_size, size_t dims, float eps);
+void  cactus_hip_rope_f16(const cactus_half_t* input, cactus_half_t* output, size_t batch_size, size_t seq_len,
+                          size_t num_heads, size_t head_dim, size_t start_pos, float theta);
+void  cactus_hip_silu_f16(const cactus_half_t* input, cactus_half_t* output, size_t num_elements);
+void  cactus_hip_gelu_f16(const cactus_half_t* input, cactus_half_t* output, size_t num_elements);
+void  cactus_hip_add_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements);
+void  cactus_hip_add_f16_clipped(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements);
+void  cactus_hip_subtract_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements);
+void  cactus_hip_multiply_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements);
+void  cactus_hip_divide_f16(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements);
 
 #ifdef __cplusplus
 }

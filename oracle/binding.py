@@ -44,6 +44,17 @@ def _load():
     lib.oracle_attention_hybrid_int8_fp16.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp,
                                                       sz, sz, sz, sz, sz, sz, sz, C.c_float,
                                                       sz, C.c_int, sz]
+    lib.oracle_rms_norm_f16.argtypes = [vp, vp, vp, sz, sz, C.c_float]
+    lib.oracle_rope_tables.argtypes = [vp, vp, sz, sz, sz, C.c_float]
+    lib.oracle_rope_f16.argtypes = [vp, vp, sz, sz, sz, sz, sz, C.c_float]
+    lib.oracle_silu_f16.argtypes = [vp, vp, sz, sz]
+    lib.oracle_gelu_f16.argtypes = [vp, vp, sz, sz]
+    lib.oracle_binary_f16.argtypes = [C.c_int, vp, vp, vp, sz]
+    lib.oracle_add_f16_clipped.argtypes = [vp, vp, vp, sz]
+    lib.oracle_embedding_int8.restype = C.c_int
+    lib.oracle_embedding_int8.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz]
+    lib.oracle_embedding_f16.restype = C.c_int
+    lib.oracle_embedding_f16.argtypes = [vp, vp, vp, sz, sz, sz]
     return lib
 
 
@@ -170,4 +181,72 @@ def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, sc
                                           _p(out), B, S, cache_len, new_len, Hq, Hkv, D,
                                           float(scale), position_offset, int(bool(is_causal)),
                                           group_size)
+    return out
+
+
+def rms_norm(x, weight, eps=1e-5):
+    x = _c(x, np.uint16); w = _c(weight, np.uint16)
+    rows, dims = x.shape
+    out = np.zeros(x.shape, np.uint16)
+    lib.oracle_rms_norm_f16(_p(x), _p(w), _p(out), rows, dims, float(eps))
+    return out
+
+
+def rope_tables(pos0, npos, head_dim, theta):
+    c = np.zeros((npos, head_dim // 2), np.uint16)
+    s = np.zeros((npos, head_dim // 2), np.uint16)
+    lib.oracle_rope_tables(_p(c), _p(s), pos0, npos, head_dim, float(theta))
+    return c, s
+
+
+def rope(x, theta, start_pos=0):
+    x = _c(x, np.uint16)
+    B, S, H, D = x.shape
+    out = np.zeros(x.shape, np.uint16)
+    lib.oracle_rope_f16(_p(x), _p(out), B, S, H, D, start_pos, float(theta))
+    return out
+
+
+def silu(x, ranges=1):
+    x = _c(x, np.uint16)
+    out = np.zeros(x.shape, np.uint16)
+    lib.oracle_silu_f16(_p(x), _p(out), x.size, ranges)
+    return out
+
+
+def gelu(x, ranges=1):
+    x = _c(x, np.uint16)
+    out = np.zeros(x.shape, np.uint16)
+    lib.oracle_gelu_f16(_p(x), _p(out), x.size, ranges)
+    return out
+
+
+BINARY_OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3}
+
+
+def binary(op, a, b):
+    a = _c(a, np.uint16); b = _c(b, np.uint16)
+    out = np.zeros(a.shape, np.uint16)
+    lib.oracle_binary_f16(BINARY_OPS[op], _p(a), _p(b), _p(out), a.size)
+    return out
+
+
+def add_clipped(a, b):
+    a = _c(a, np.uint16); b = _c(b, np.uint16)
+    out = np.zeros(a.shape, np.uint16)
+    lib.oracle_add_f16_clipped(_p(a), _p(b), _p(out), a.size)
+    return out
+
+
+def embedding(table, indices, scales=None, group_size=128):
+    idx = _c(indices, np.int32)
+    vocab, hidden = table.shape
+    out = np.zeros((idx.size, hidden), np.uint16)
+    if table.dtype == np.int8:
+        rc = lib.oracle_embedding_int8(_p(_c(table, np.int8)), _p(_c(scales, np.uint16)), _p(idx), _p(out),
+                                       idx.size, vocab, hidden, group_size)
+    else:
+        rc = lib.oracle_embedding_f16(_p(_c(table, np.uint16)), _p(idx), _p(out), idx.size, vocab, hidden)
+    if rc != 0:
+        raise IndexError("Embedding index out of bounds")
     return out

@@ -562,3 +562,250 @@ void oracle_attention_hybrid_int8_fp16(const uint16_t* queries,
         free(acc);
     }
 }
+
+/* ======================================================================== */
+/* Ops between the hot kernels of a decoder block                            */
+/* ======================================================================== */
+
+/* fp16 a*b with one rounding (vmulq_f16): the product of two halves is exact
+ * in double. */
+static uint16_t h_mul(uint16_t a, uint16_t b) {
+    return d2h((double)oracle_h2f(a) * (double)oracle_h2f(b));
+}
+static uint16_t h_neg(uint16_t a) { return (uint16_t)(a ^ 0x8000u); }
+
+/* ------------------------------------------------------------------------ */
+/* cactus_rms_norm_f16: cactus/kernel/kernel_attention.cpp:484-563           */
+/*   Sum of squares in fp32 over 16 lane accumulators: element i < simd_end  */
+/*   (= dims rounded down to 8) goes to accumulator i % 16 with vfmaq_f32    */
+/*   (:508-525: four float32x4 registers over a 16-element tile, the 8-wide  */
+/*   remainder into the first two); the registers are added ((v0+v1)+v2)+v3  */
+/*   lane-wise (:527-530) and reduced with vaddvq_f32 = (t0+t1)+(t2+t3)      */
+/*   (:531); the scalar tail adds val*val as a plain statement (:533-536).   */
+/*   rms = sqrtf(ss/dims + eps), inv = 1/rms (:538-539).  The vector part    */
+/*   multiplies in fp16: (x * half(inv)) * w, each product rounded (:540-557);*/
+/*   the tail computes x*inv*w in fp32 and rounds once (:559-561).           */
+/* ------------------------------------------------------------------------ */
+void oracle_rms_norm_f16(const uint16_t* input, const uint16_t* weight, uint16_t* output,
+                         size_t batch_size, size_t dims, float eps) {
+    const size_t simd_end = (dims / 8) * 8;
+    for (size_t b = 0; b < batch_size; b++) {
+        const uint16_t* x = input + b * dims;
+        uint16_t* y = output + b * dims;
+        float acc[16];
+        for (int l = 0; l < 16; l++) acc[l] = 0.0f;
+        for (size_t i = 0; i < simd_end; i++) {
+            const float v = oracle_h2f(x[i]);
+            acc[i % 16] = fmaf(v, v, acc[i % 16]);
+        }
+        float t[4];
+        for (int l = 0; l < 4; l++) t[l] = ((acc[l] + acc[4 + l]) + acc[8 + l]) + acc[12 + l];
+        float ss = (t[0] + t[1]) + (t[2] + t[3]);
+        for (size_t i = simd_end; i < dims; i++) {
+            const float v = oracle_h2f(x[i]);
+            ss = mad_stmt(v, v, ss);
+        }
+        const float rms = sqrtf(ss / (float)dims + eps);
+        const float inv = 1.0f / rms;
+        const uint16_t inv_h = oracle_f2h(inv);
+        for (size_t i = 0; i < simd_end; i++) y[i] = h_mul(h_mul(x[i], inv_h), weight[i]);
+        for (size_t i = simd_end; i < dims; i++)
+            y[i] = oracle_f2h(oracle_h2f(x[i]) * inv * oracle_h2f(weight[i]));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* RoPE tables: cactus/kernel/kernel_attention.cpp:594-604                   */
+/*   freq = 1/powf(theta, (2.0f*i)/head_dim), angle = float(pos)*freq,       */
+/*   cos/sin tables hold half(cosf(angle)), half(sinf(angle)), [pos][i].     */
+/* ------------------------------------------------------------------------ */
+void oracle_rope_tables(uint16_t* cos_t, uint16_t* sin_t, size_t pos0, size_t npos,
+                        size_t head_dim, float theta) {
+    const size_t half_dim = head_dim / 2;
+    for (size_t p = 0; p < npos; p++) {
+        const float pos_float = (float)(pos0 + p);
+        for (size_t i = 0; i < half_dim; i++) {
+            const float freq = 1.0f / powf(theta, (2.0f * (float)i) / (float)head_dim);
+            const float angle = pos_float * freq;
+            cos_t[p * half_dim + i] = oracle_f2h(cosf(angle));
+            sin_t[p * half_dim + i] = oracle_f2h(sinf(angle));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* cactus_rope_f16: cactus/kernel/kernel_attention.cpp:614-676               */
+/*   Half-split rotation on [batch, seq, heads, head_dim]; token seq_idx uses*/
+/*   table row start_pos + seq_idx (:628-629, :642-643).  Vector part (i <   */
+/*   half_dim rounded down to 8), all in fp16: first = (x1*cos) - x2*sin with*/
+/*   the product rounded and the subtraction fused (vfmsq_f16, :655), second */
+/*   = (x2*cos) + x1*sin likewise (vfmaq_f16, :656).  The scalar tail (:662- */
+/*   672) evaluates in fp32 (products of halves are exact there) and rounds  */
+/*   the result to half.                                                      */
+/* ------------------------------------------------------------------------ */
+void oracle_rope_f16(const uint16_t* input, uint16_t* output, size_t batch_size, size_t seq_len,
+                     size_t num_heads, size_t head_dim, size_t start_pos, float theta) {
+    const size_t half_dim = head_dim / 2;
+    const size_t vec = (half_dim / 8) * 8;
+    uint16_t* cos_t = (uint16_t*)malloc(sizeof(uint16_t) * (seq_len * half_dim + 1));
+    uint16_t* sin_t = (uint16_t*)malloc(sizeof(uint16_t) * (seq_len * half_dim + 1));
+    oracle_rope_tables(cos_t, sin_t, start_pos, seq_len, head_dim, theta);
+    for (size_t b = 0; b < batch_size; b++)
+        for (size_t s = 0; s < seq_len; s++)
+            for (size_t h = 0; h < num_heads; h++) {
+                const size_t off = ((b * seq_len + s) * num_heads + h) * head_dim;
+                const uint16_t* x = input + off;
+                uint16_t* y = output + off;
+                const uint16_t* c = cos_t + s * half_dim;
+                const uint16_t* sn = sin_t + s * half_dim;
+                for (size_t i = 0; i < vec; i++) {
+                    const uint16_t x1 = x[i], x2 = x[i + half_dim];
+                    y[i] = h_fma(h_mul(x1, c[i]), h_neg(x2), sn[i]);
+                    y[i + half_dim] = h_fma(h_mul(x2, c[i]), x1, sn[i]);
+                }
+                for (size_t i = vec; i < half_dim; i++) {
+                    const float x1 = oracle_h2f(x[i]), x2 = oracle_h2f(x[i + half_dim]);
+                    const float cf = oracle_h2f(c[i]), sf = oracle_h2f(sn[i]);
+                    y[i] = oracle_f2h(x1 * cf - x2 * sf);
+                    y[i + half_dim] = oracle_f2h(x2 * cf + x1 * sf);
+                }
+            }
+    free(cos_t);
+    free(sin_t);
+}
+
+/* fast_exp_f32x4 on one element: cactus/kernel/kernel_utils.h:108-141 */
+static inline float fast_exp(float x) {
+    x = fmaxf(x, -87.0f);
+    x = fminf(x, 87.0f);
+    const float z = x * 1.4426950408889634f;
+    int32_t zi = (int32_t)z;                      /* vcvtq_s32_f32: toward zero */
+    float zf = z - (float)zi;
+    if (zf < 0.0f) { zi -= 1; zf += 1.0f; }
+    const float zl = zf * 0.6931471805599453f;
+    float p = 0.009618129842071803f;
+    p = fmaf(p, zl, 0.05550410866482158f);        /* vfmaq_f32(c, p, zl) = c + p*zl */
+    p = fmaf(p, zl, 0.2402265069591007f);
+    p = fmaf(p, zl, 0.6931471805599453f);
+    p = fmaf(p, zl, 1.0f);
+    const uint32_t e = (uint32_t)(zi + 127) << 23;
+    float sc;
+    memcpy(&sc, &e, 4);
+    return p * sc;
+}
+
+/* fast_tanh_f32x4 on one element: cactus/kernel/kernel_utils.h:143-163 */
+static inline float fast_tanh(float x) {
+    const float x2 = x * x;
+    const float num = 27.0f + x2;
+    const float den = fmaf(9.0f, x2, 27.0f);
+    float r = x * (num / den);
+    if (x > 4.5f) r = 1.0f;
+    if (x < -4.5f) r = -1.0f;
+    return r;
+}
+
+/* The reference splits an element-wise call into `ranges` contiguous pieces
+ * of num_elements / ranges elements, the last taking the remainder (kernel_utils.h:533-
+ * 541; the count depends on the machine's pool size and the op's threshold, :413-419);
+ * inside a piece, whole groups of 8 from the piece's start take the vector
+ * formula and the rest the scalar libm one. */
+typedef uint16_t (*unary_fn)(uint16_t, int vector_part);
+
+static void unary_ranges(const uint16_t* in, uint16_t* out, size_t n, size_t ranges, unary_fn f) {
+    if (ranges < 1) ranges = 1;
+    if (ranges > n && n > 0) ranges = n;
+    const size_t per = n / ranges;
+    for (size_t t = 0; t < ranges; t++) {
+        const size_t s = t * per, e = (t == ranges - 1) ? n : (t + 1) * per;
+        const size_t vend = s + ((e - s) / 8) * 8;
+        for (size_t i = s; i < e; i++) out[i] = f(in[i], i < vend);
+    }
+}
+
+/* cactus_silu_f16: cactus/kernel/kernel_nn.cpp:12-44 */
+static uint16_t silu_one(uint16_t h, int vector_part) {
+    const float x = oracle_h2f(h);
+    const float e = vector_part ? fast_exp(-x) : expf(-x);
+    const float sig = 1.0f / (1.0f + e);
+    return oracle_f2h(x * sig);
+}
+void oracle_silu_f16(const uint16_t* in, uint16_t* out, size_t n, size_t ranges) {
+    unary_ranges(in, out, n, ranges, silu_one);
+}
+
+/* cactus_gelu_f16: cactus/kernel/kernel_nn.cpp:46-91 */
+static uint16_t gelu_one(uint16_t h, int vector_part) {
+    const float x = oracle_h2f(h);
+    if (vector_part) {
+        const float x3 = (x * x) * x;
+        float inner = fmaf(0.044715f, x3, x);
+        inner = 0.7978845608028654f * inner;
+        const float th = fast_tanh(inner);
+        return oracle_f2h((0.5f * x) * (1.0f + th));
+    }
+    /* scalar tail (:84-89): plain statements, contraction as the compiler chooses */
+    const float x3 = 0.044715f * x * x * x;
+    const float inner = 0.7978845608028654f * (x + x3);
+    return oracle_f2h(0.5f * x * (1.0f + tanhf(inner)));
+}
+void oracle_gelu_f16(const uint16_t* in, uint16_t* out, size_t n, size_t ranges) {
+    unary_ranges(in, out, n, ranges, gelu_one);
+}
+
+/* cactus_add_f16 / subtract / multiply / divide: cactus/kernel/kernel_blas.cpp:187-343.
+ * One fp16 operation per element (vaddq_f16 ...); the scalar tails promote to
+ * fp32 and round back, which gives the same half for all four operations.
+ * op: 0 add, 1 subtract, 2 multiply, 3 divide. */
+void oracle_binary_f16(int op, const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        const double x = oracle_h2f(a[i]), y = oracle_h2f(b[i]);
+        double r;
+        switch (op) {
+            case 0: r = x + y; break;
+            case 1: r = x - y; break;
+            case 2: r = x * y; break;
+            default: r = (double)((float)x / (float)y); break;   /* fp32 quotient, then half: 24 >= 2*11+2 */
+        }
+        out[i] = d2h(r);
+    }
+}
+
+/* cactus_add_f16_clipped: cactus/kernel/kernel_blas.cpp:224-262 (fp32 sum clamped to +-65500) */
+void oracle_add_f16_clipped(const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        float r = oracle_h2f(a[i]) + oracle_h2f(b[i]);
+        r = fminf(fmaxf(r, -65500.0f), 65500.0f);
+        out[i] = oracle_f2h(r);
+    }
+}
+
+/* compute_embedding_node: cactus/graph/graph_ops_tensor.cpp:226-320.
+ * INT8 rows with per-group fp16 scales: half(float(q) * float(scale)) (:243-254);
+ * FP16 rows are copied (:301-316).  Returns -1 on an index >= vocab_size (the
+ * reference throws, :261-263), 0 otherwise. */
+int oracle_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices,
+                          uint16_t* out, size_t num_indices, size_t vocab_size, size_t hidden_dim,
+                          size_t group_size) {
+    const size_t num_groups = hidden_dim / group_size;
+    for (size_t i = 0; i < num_indices; i++) {
+        const size_t idx = (size_t)indices[i];
+        if (indices[i] < 0 || idx >= vocab_size) return -1;
+        for (size_t g = 0; g < num_groups; g++) {
+            const float sc = oracle_h2f(scales[idx * num_groups + g]);
+            for (size_t k = g * group_size; k < (g + 1) * group_size && k < hidden_dim; k++)
+                out[i * hidden_dim + k] = oracle_f2h((float)emb[idx * hidden_dim + k] * sc);
+        }
+    }
+    return 0;
+}
+
+int oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out,
+                         size_t num_indices, size_t vocab_size, size_t hidden_dim) {
+    for (size_t i = 0; i < num_indices; i++) {
+        const size_t idx = (size_t)indices[i];
+        if (indices[i] < 0 || idx >= vocab_size) return -1;
+        memcpy(out + i * hidden_dim, emb + idx * hidden_dim, hidden_dim * sizeof(uint16_t));
+    }
+    return 0;
+}

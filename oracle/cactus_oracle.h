@@ -23,6 +23,10 @@
  *   - oracle_fp16_max_abs / oracle_fp16_to_int8 / oracle_attention_f16 /
  *     oracle_attention_hybrid_int8_fp16: PARITY UNPINNED -- the reference holds
  *     no golden vector for them and its NEON sources do not build on x86.
+ *   - oracle_rms_norm_f16 / oracle_rope_f16 / oracle_silu_f16 / oracle_gelu_f16 /
+ *     oracle_binary_f16 / oracle_add_f16_clipped / oracle_embedding_*: PARITY
+ *     UNPINNED beyond the reference's loose tests (tests/test_kernel.cpp,
+ *     tolerance-based on unseeded inputs), for the same reason.
  */
 #ifndef CACTUS_ORACLE_H
 #define CACTUS_ORACLE_H
@@ -83,6 +87,26 @@ void oracle_attention_hybrid_int8_fp16(const uint16_t* queries,
                                        size_t new_len, size_t num_q_heads, size_t num_kv_heads,
                                        size_t head_dim, float scale, size_t position_offset,
                                        int is_causal, size_t group_size);
+
+/* Ops between the hot kernels of a decoder block.  `ranges` is the number of
+ * contiguous pieces the reference's thread pool would cut the call into (1 =
+ * one piece: groups of 8 from the start take the vector formula, the last
+ * n % 8 elements the scalar libm one). */
+void oracle_rms_norm_f16(const uint16_t* input, const uint16_t* weight, uint16_t* output,
+                         size_t batch_size, size_t dims, float eps);
+void oracle_rope_tables(uint16_t* cos_t, uint16_t* sin_t, size_t pos0, size_t npos,
+                        size_t head_dim, float theta);
+void oracle_rope_f16(const uint16_t* input, uint16_t* output, size_t batch_size, size_t seq_len,
+                     size_t num_heads, size_t head_dim, size_t start_pos, float theta);
+void oracle_silu_f16(const uint16_t* in, uint16_t* out, size_t n, size_t ranges);
+void oracle_gelu_f16(const uint16_t* in, uint16_t* out, size_t n, size_t ranges);
+void oracle_binary_f16(int op, const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n);
+void oracle_add_f16_clipped(const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n);
+int  oracle_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices,
+                           uint16_t* out, size_t num_indices, size_t vocab_size, size_t hidden_dim,
+                           size_t group_size);
+int  oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out,
+                          size_t num_indices, size_t vocab_size, size_t hidden_dim);
 
 #ifdef __cplusplus
 }

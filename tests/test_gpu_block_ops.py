@@ -1,0 +1,198 @@
+"""GPU parity tests of the ops between the hot kernels of a decoder block (RMS norm, RoPE, SiLU,
+GELU, element-wise fp16 binaries, clipped add, embedding), called through the C ABI and compared
+with the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact.  The kernels keep the reference's evaluation order (fp32 lane accumulators,
+fp16 products, the polynomial exp / rational tanh of the 8-wide paths); the RoPE tables are built
+by the host's libm in both the library and the oracle.  Only the scalar tails of SiLU / GELU
+(the last n % 8 elements, which the reference evaluates with libm expf / tanhf) go through the
+GPU's own expf / tanhf and are held to 1 fp16 ulp.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import ulp_diff_f16
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def H():
+    import cactus_amd.hip as hip
+    hip.init(0)
+    return hip
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(t):
+    return t.cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def halves(rng, shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float16)
+
+
+# ------------------------------------------------------------------------------ RMS norm
+@pytest.mark.parametrize("rows,dims", [(1, 1024), (7, 128), (3, 20), (5, 8), (49, 64), (2, 4096), (1, 7),
+                                       (33, 136), (4, 2560), (1, 8192)])
+@pytest.mark.parametrize("eps", [1e-5, 1e-6])
+def test_rms_norm_bit_exact(H, rows, dims, eps):
+    """kernel_attention.cpp:484-563: 16 fp32 lane accumulators, fp16 products, fp32 scalar tail."""
+    rng = np.random.default_rng(rows * 131 + dims)
+    x = halves(rng, (rows, dims), 2.0)
+    if rows > 1:
+        x[1] = 0                      # zero row: rms = sqrt(eps)
+    if rows > 2:
+        x[2] *= 40.0                  # large row
+    w = (1.0 + 0.1 * rng.standard_normal(dims)).astype(np.float16)
+    want = O.rms_norm(x, w, eps)
+    got = bits(H.rms_norm(dev(x), dev(w), eps))
+    assert np.array_equal(got, want)
+
+
+def test_rms_norm_reference_known_answer(H):
+    """tests/test_graph.cpp:176-200: input 1..8, unit weight, eps 1e-5, tolerance 0.01 there."""
+    x = np.arange(1, 9, dtype=np.float16)[None, :]
+    w = np.ones(8, np.float16)
+    got = H.rms_norm(dev(x), dev(w), 1e-5).cpu().numpy().astype(np.float32)
+    inv = 1.0 / np.sqrt(np.float32((x.astype(np.float32) ** 2).sum() / 8 + 1e-5))
+    assert np.abs(got - x.astype(np.float32) * inv).max() < 0.01
+
+
+# ---------------------------------------------------------------------------------- RoPE
+@pytest.mark.parametrize("shape,start,theta", [((1, 1, 16, 128), 0, 1e6), ((1, 1, 16, 128), 37, 1e6),
+                                               ((2, 3, 4, 64), 5, 10000.0), ((1, 5, 2, 20), 2, 10000.0),
+                                               ((1, 2, 1, 4), 0, 10000.0), ((1, 7, 8, 256), 1500, 1e6),
+                                               ((1, 300, 2, 64), 0, 10000.0)])
+def test_rope_bit_exact(H, shape, start, theta):
+    """kernel_attention.cpp:614-676 with the tables of :594-604 (positions start .. start+seq-1);
+    head_dim 20 and 4 exercise the scalar tail (half_dim % 8 != 0)."""
+    rng = np.random.default_rng(sum(shape) + start)
+    x = halves(rng, shape, 1.5)
+    want = O.rope(x, theta, start)
+    got = bits(H.rope(dev(x), theta, start))
+    assert np.array_equal(got, want)
+
+
+def test_rope_table_grows_and_keeps_rows(H):
+    """A later call at a far position grows the cached table; earlier positions give the same bits."""
+    rng = np.random.default_rng(9)
+    x = halves(rng, (1, 4, 2, 64))
+    first = bits(H.rope(dev(x), 5e5, 3))
+    far = bits(H.rope(dev(x), 5e5, 40000))
+    again = bits(H.rope(dev(x), 5e5, 3))
+    assert np.array_equal(first, again)
+    assert np.array_equal(far, O.rope(x, 5e5, 40000))
+    H.rope_reserve(64, 5e5, 70000)
+    assert np.array_equal(bits(H.rope(dev(x), 5e5, 69990)), O.rope(x, 5e5, 69990))
+
+
+# ---------------------------------------------------------------------------- SiLU / GELU
+@pytest.mark.parametrize("name", ["silu", "gelu"])
+@pytest.mark.parametrize("n", [8, 4096, 13, 3, 100003, 1 << 20])
+def test_unary_vector_part_bit_exact_tail_one_ulp(H, name, n):
+    """kernel_nn.cpp:12-91: groups of 8 use the polynomial exp (kernel_utils.h:108-141) / rational
+    tanh (:143-163); the last n % 8 elements use expf / tanhf."""
+    rng = np.random.default_rng(n)
+    x = halves(rng, n, 4.0)
+    x[: min(n, 6)] = np.array([0.0, -0.0, 100.0, -100.0, 4.5, -4.6], np.float16)[: min(n, 6)]
+    want = getattr(O, name)(x)
+    got = bits(getattr(H, name)(dev(x)))
+    vend = (n // 8) * 8
+    assert np.array_equal(got[:vend], want[:vend])
+    if vend < n:
+        assert ulp_diff_f16(got[vend:], want[vend:]).max() <= 1
+
+
+# ------------------------------------------------------------------------ binaries, clipped add
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide"])
+@pytest.mark.parametrize("n", [5, 1000, 65536 + 3])
+def test_binary_bit_exact(H, op, n):
+    """kernel_blas.cpp:187-343: one fp16 operation per element."""
+    rng = np.random.default_rng(n + len(op))
+    a, b = halves(rng, n, 8.0), halves(rng, n, 0.5)
+    sp = np.array([0.0, 65504.0, -65504.0, 6e-8, 6.1e-5, 1.0], np.float16)
+    a[: min(n, 5)] = sp[: min(n, 5)]
+    b[: min(n, 5)] = sp[::-1][: min(n, 5)]
+    want = O.binary(op, a, b)
+    got = bits(getattr(H, op)(dev(a), dev(b)))
+    nan_w = np.isnan(want.view(np.float16)); nan_g = np.isnan(got.view(np.float16))
+    assert np.array_equal(nan_w, nan_g)
+    assert np.array_equal(got[~nan_w], want[~nan_w])
+
+
+def test_binary_reference_known_answers(H):
+    """tests/test_graph.cpp:35-72."""
+    f = lambda v: dev(np.array(v, np.float16))
+    assert H.add(f([1, 2, 3, 4]), f([5, 6, 7, 8])).cpu().tolist() == [6, 8, 10, 12]
+    assert H.subtract(f([10, 8, 6, 4]), f([2, 3, 1, 2])).cpu().tolist() == [8, 5, 5, 2]
+    assert H.multiply(f([2, 3, 4, 5]), f([3, 4, 2, 2])).cpu().tolist() == [6, 12, 8, 10]
+    assert H.divide(f([12, 15, 8, 9]), f([3, 5, 2, 3])).cpu().tolist() == [4, 3, 4, 3]
+
+
+@pytest.mark.parametrize("n", [7, 4096 + 5])
+def test_add_clipped_bit_exact(H, n):
+    """kernel_blas.cpp:224-262: fp32 sum clamped to +-65500 (so never infinite)."""
+    rng = np.random.default_rng(n)
+    a, b = halves(rng, n, 30000.0), halves(rng, n, 30000.0)
+    a[:3] = np.array([65504, -65504, 40000], np.float16)
+    b[:3] = np.array([65504, -65504, 30000], np.float16)
+    want = O.add_clipped(a, b)
+    got = bits(H.add_clipped(dev(a), dev(b)))
+    assert np.array_equal(got, want)
+    assert np.isfinite(got.view(np.float16)).all()
+
+
+# ------------------------------------------------------------------------------ embedding
+def test_embedding_int8_grouped_bit_exact(H):
+    """graph_ops_tensor.cpp:243-254: half(float(q) * float(scale[row, group]))."""
+    rng = np.random.default_rng(5)
+    vocab, hidden = 300, 512
+    table = rng.integers(-127, 128, (vocab, hidden), dtype=np.int8)
+    scales = (0.01 + np.abs(rng.standard_normal((vocab, hidden // 128))) * 0.05).astype(np.float16)
+    idx = rng.integers(0, vocab, 37).astype(np.int32)
+    idx[:2] = [0, vocab - 1]
+    want = O.embedding(table, idx, scales, 128)
+    got = bits(H.embedding(dev(table), dev(idx), dev(scales), 128))
+    assert np.array_equal(got, want)
+
+
+def test_embedding_f16_and_bounds(H):
+    """graph_ops_tensor.cpp:301-316 (copy) and :261-263 (index >= vocab is an error)."""
+    rng = np.random.default_rng(6)
+    table = halves(rng, (50, 96))
+    idx = np.array([3, 49, 0, 3], np.int32)
+    got = bits(H.embedding(dev(table), dev(idx)))
+    assert np.array_equal(got, table.view(np.uint16)[idx])
+    with pytest.raises(H.CactusHipError):
+        H.embedding(dev(table), dev(np.array([1, 50], np.int32)))
+    with pytest.raises(IndexError):
+        O.embedding(table, np.array([1, 50], np.int32))
+
+
+def test_host_pointer_forms_match_device_forms(H):
+    """The kernel.h-shaped host-pointer entries stage through the device and give the same bits."""
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    x = halves(rng, (3, 64)); w = halves(rng, 64)
+    out = np.zeros_like(x)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    H.lib.cactus_hip_rms_norm_f16(p(x), p(w), p(out), 3, 64, 1e-6)
+    assert np.array_equal(out.view(np.uint16), O.rms_norm(x, w, 1e-6))
+    q = halves(rng, (1, 2, 2, 32)); qo = np.zeros_like(q)
+    H.lib.cactus_hip_rope_f16(p(q), p(qo), 1, 2, 2, 32, 11, 10000.0)
+    assert np.array_equal(qo.view(np.uint16), O.rope(q, 10000.0, 11))
+    a, b = halves(rng, 40), halves(rng, 40)
+    o = np.zeros_like(a)
+    H.lib.cactus_hip_silu_f16(p(a), p(o), 40)
+    assert np.array_equal(o.view(np.uint16), O.silu(a))
+    H.lib.cactus_hip_multiply_f16(p(a), p(b), p(o), 40)
+    assert np.array_equal(o.view(np.uint16), O.binary("multiply", a, b))
+    H.lib.cactus_hip_add_f16_clipped(p(a), p(b), p(o), 40)
+    assert np.array_equal(o.view(np.uint16), O.add_clipped(a, b))
