@@ -476,6 +476,15 @@ int cactus_hip_add_f16_clipped_dev(const cactus_half_t* a, const cactus_half_t* 
     return binary_dev(4, "add_clipped: null operand or launch failure", a, b, out, n, stream);
 }
 
+int cactus_hip_indices_to_int32_dev(const void* indices, int precision, int32_t* output, size_t count, void* stream) {
+    if (count == 0) return CACTUS_HIP_OK;
+    if (!indices || !output) return fail(CACTUS_HIP_EINVAL, "indices_to_int32: null operand");
+    if (precision != 0 && precision != 2) return fail(CACTUS_HIP_EINVAL, "indices_to_int32: precision must be INT8 (0) or FP32 (2)");
+    hipError_t e = launch_indices_to_i32(indices, precision == 2, output, count, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "indices_to_int32 launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_embedding_int8_dev(const int8_t* embeddings, const cactus_half_t* scales, const int32_t* indices,
                                   cactus_half_t* output, size_t num_indices, size_t vocab_size, size_t hidden_dim,
                                   size_t group_size, int* bad_index_flag, void* stream) {

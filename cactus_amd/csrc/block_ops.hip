@@ -278,7 +278,26 @@ __global__ __launch_bounds__(256) void embedding_f16_kernel(const uint16_t* __re
     for (int k = threadIdx.x; k < hidden; k += 256) out[i * hidden + k] = emb[(size_t)idx * hidden + k];
 }
 
+// Embedding indices as the graph holds them (FP32 or INT8 values) -> int32; a value that is not
+// a valid size_t (negative, NaN) becomes -1 so that the lookup reports it.
+__global__ __launch_bounds__(256) void indices_to_i32_kernel(const void* __restrict__ src, int is_f32,
+                                                             int32_t* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (is_f32) {
+        const float v = static_cast<const float*>(src)[i];
+        dst[i] = (v >= 0.0f && v < 2147483648.0f) ? (int32_t)v : -1;
+    } else {
+        dst[i] = static_cast<const int8_t*>(src)[i];   // negative stays negative = out of range
+    }
+}
+
 }  // namespace
+
+hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, size_t n, hipStream_t st) {
+    indices_to_i32_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, is_f32 ? 1 : 0, dst, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_rms_norm(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t rows, size_t dims, float eps,
                            hipStream_t st) {

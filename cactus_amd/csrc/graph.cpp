@@ -137,6 +137,51 @@ size_t CactusGraph::attention_int8_hybrid(size_t q, size_t key_new, size_t value
     return add_node(OpType::ATTENTION_INT8_HYBRID, {q, key_new, value_new}, {}, p);
 }
 
+// graph_builder.cpp:11-59.  Equal shapes only: the reference also broadcasts
+// (BroadcastInfo::compute); the decoder blocks add and multiply tensors of one shape.
+size_t CactusGraph::binary_node(OpType op, size_t input1, size_t input2) {
+    const auto& lhs = get_output_buffer(input1);
+    const auto& rhs = get_output_buffer(input2);
+    if (lhs.shape != rhs.shape)
+        throw std::invalid_argument("Binary operations on the HIP graph require equal shapes (no broadcasting)");
+    return add_node(op, {input1, input2}, lhs.shape);
+}
+size_t CactusGraph::add(size_t a, size_t b) { return binary_node(OpType::ADD, a, b); }
+size_t CactusGraph::add_clipped(size_t a, size_t b) { return binary_node(OpType::ADD_CLIPPED, a, b); }
+size_t CactusGraph::subtract(size_t a, size_t b) { return binary_node(OpType::SUBTRACT, a, b); }
+size_t CactusGraph::multiply(size_t a, size_t b) { return binary_node(OpType::MULTIPLY, a, b); }
+size_t CactusGraph::divide(size_t a, size_t b) { return binary_node(OpType::DIVIDE, a, b); }
+size_t CactusGraph::silu(size_t input) { return add_node(OpType::SILU, {input}, {}); }   // graph_builder.cpp:468-474
+size_t CactusGraph::gelu(size_t input) { return add_node(OpType::GELU, {input}, {}); }
+
+size_t CactusGraph::reshape(size_t input, const std::vector<size_t>& new_shape) {   // graph_builder.cpp:120-123
+    if (product(new_shape) != get_output_buffer(input).total_size)
+        throw std::invalid_argument("Reshape must keep the number of elements");
+    return add_node(OpType::RESHAPE, {input}, new_shape);
+}
+
+size_t CactusGraph::embedding(size_t embedding_tensor, size_t indices) {   // graph_builder.cpp:524-539
+    const auto& emb = get_output_buffer(embedding_tensor);
+    if (emb.shape.size() != 2) throw std::runtime_error("Embedding tensor must be 2D [vocab_size, hidden_dim]");
+    std::vector<size_t> shape = get_output_buffer(indices).shape;
+    shape.push_back(emb.shape[1]);
+    OpParams p;
+    p.output_precision = Precision::FP16;
+    return add_node(OpType::EMBEDDING, {embedding_tensor, indices}, shape, p);
+}
+
+size_t CactusGraph::rms_norm(size_t input, size_t weight, float epsilon) {   // graph_builder.cpp:253-256
+    OpParams p;
+    p.epsilon = epsilon;
+    return add_node(OpType::RMS_NORM, {input, weight}, {}, p);
+}
+
+size_t CactusGraph::rope(size_t input, float theta, size_t position_offset, ComputeBackend backend) {   // :258-261
+    OpParams p;
+    p.theta = theta; p.position_offset = position_offset; p.backend = backend;
+    return add_node(OpType::ROPE, {input}, {}, p);
+}
+
 void CactusGraph::ensure_device(BufferDesc& b) {
     if (b.device_data == nullptr) {
         b.device_data = dev_alloc(b.byte_size);
@@ -340,6 +385,100 @@ void CactusGraph::compute_attention_int8_hybrid_node(GraphNode& n) {
         n.params.head_dim, n.params.scale, n.params.position_offset, 1, CACTUS_KV_QUANT_GROUP_SIZE, nullptr));
 }
 
+// graph_ops_math.cpp:110-153 without the broadcasting branch
+void CactusGraph::compute_binary_node(GraphNode& n) {
+    const BufferDesc& lhs = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& rhs = node(n.input_ids[1]).output_buffer;
+    if (lhs.precision != Precision::FP16) throw std::runtime_error("Binary operations only support FP16 precision");
+    const cactus_half_t* a = static_cast<const cactus_half_t*>(lhs.device_data);
+    const cactus_half_t* b = static_cast<const cactus_half_t*>(rhs.device_data);
+    cactus_half_t* o = static_cast<cactus_half_t*>(n.output_buffer.device_data);
+    const size_t count = n.output_buffer.total_size;
+    switch (n.op_type) {
+        case OpType::ADD: abi_check(cactus_hip_add_f16_dev(a, b, o, count, nullptr)); break;
+        case OpType::ADD_CLIPPED: abi_check(cactus_hip_add_f16_clipped_dev(a, b, o, count, nullptr)); break;
+        case OpType::SUBTRACT: abi_check(cactus_hip_subtract_f16_dev(a, b, o, count, nullptr)); break;
+        case OpType::MULTIPLY: abi_check(cactus_hip_multiply_f16_dev(a, b, o, count, nullptr)); break;
+        default: abi_check(cactus_hip_divide_f16_dev(a, b, o, count, nullptr)); break;
+    }
+}
+
+// graph_ops_math.cpp:158-180
+void CactusGraph::compute_activation_node(GraphNode& n) {
+    const BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    if (in.precision != Precision::FP16) throw std::runtime_error("Activation operations only support FP16 precision");
+    const cactus_half_t* x = static_cast<const cactus_half_t*>(in.device_data);
+    cactus_half_t* o = static_cast<cactus_half_t*>(n.output_buffer.device_data);
+    if (n.op_type == OpType::SILU) abi_check(cactus_hip_silu_f16_dev(x, o, n.output_buffer.total_size, nullptr));
+    else abi_check(cactus_hip_gelu_f16_dev(x, o, n.output_buffer.total_size, nullptr));
+}
+
+// graph_ops_nn.cpp:233-251
+void CactusGraph::compute_rms_norm_node(GraphNode& n) {
+    const BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& w = node(n.input_ids[1]).output_buffer;
+    if (in.shape.size() != 2)
+        throw std::runtime_error("RMS normalization requires 2D input tensor [batch_size, dims], got " +
+                                 std::to_string(in.shape.size()) + "D tensor");
+    if (in.precision != Precision::FP16) throw std::runtime_error("RMS normalization only supports FP16 precision");
+    if (w.total_size < in.shape[1]) throw std::runtime_error("RMS normalization weight is shorter than dims");
+    abi_check(cactus_hip_rms_norm_f16_dev(static_cast<const cactus_half_t*>(in.device_data),
+                                          static_cast<const cactus_half_t*>(w.device_data),
+                                          static_cast<cactus_half_t*>(n.output_buffer.device_data), in.shape[0],
+                                          in.shape[1], n.params.epsilon, nullptr));
+}
+
+// graph_ops_nn.cpp:253-277
+void CactusGraph::compute_rope_node(GraphNode& n) {
+    if (n.params.backend == ComputeBackend::NPU) throw std::runtime_error("NPU RoPE operation not yet implemented");
+    const BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    if (in.shape.size() < 4)
+        throw std::runtime_error("RoPE operation requires 4D tensor with shape [batch, seq_len, num_heads, head_dim], got " +
+                                 std::to_string(in.shape.size()) + "D tensor");
+    if (in.precision != Precision::FP16 || n.output_buffer.precision != Precision::FP16)
+        throw std::runtime_error("RoPE operation only supports FP16 precision");
+    abi_check(cactus_hip_rope_f16_dev(static_cast<const cactus_half_t*>(in.device_data),
+                                      static_cast<cactus_half_t*>(n.output_buffer.device_data), in.shape[0],
+                                      in.shape[1], in.shape[2], in.shape[3], n.params.position_offset,
+                                      n.params.theta, nullptr));
+}
+
+// graph_ops_tensor.cpp:226-320.  Indices arrive as FP32 or INT8 values (:257-275), are widened
+// to int32 on the device, and an index outside the table raises the reference's exception
+// (:261-263) after the lookup kernel has reported it.
+void CactusGraph::compute_embedding_node(GraphNode& n) {
+    const BufferDesc& emb = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& idx = node(n.input_ids[1]).output_buffer;
+    const size_t vocab = emb.shape[0], hidden = emb.shape[1], count = idx.total_size;
+    if (idx.precision != Precision::FP32 && idx.precision != Precision::INT8)
+        throw std::runtime_error("Embedding indices must be FP32 or INT8");
+    if (index_scratch_count_ < count + 1) {
+        if (index_scratch_) (void)hipFree(index_scratch_);
+        index_scratch_ = static_cast<int32_t*>(dev_alloc((count + 1) * sizeof(int32_t)));
+        index_scratch_count_ = count + 1;
+    }
+    int* flag = reinterpret_cast<int*>(index_scratch_ + count);
+    hip_check(hipMemsetAsync(flag, 0, sizeof(int), nullptr), "hipMemsetAsync");
+    abi_check(cactus_hip_indices_to_int32_dev(idx.device_data, idx.precision == Precision::FP32 ? 2 : 0,
+                                              index_scratch_, count, nullptr));
+    cactus_half_t* out = static_cast<cactus_half_t*>(n.output_buffer.device_data);
+    if (emb.precision == Precision::INT8) {
+        if (!emb.is_grouped_int8() || emb.scales_device == nullptr)
+            throw std::runtime_error("INT8 embedding tables need group scales on the HIP graph");
+        abi_check(cactus_hip_embedding_int8_dev(static_cast<const int8_t*>(emb.device_data),
+                                                static_cast<const cactus_half_t*>(emb.scales_device), index_scratch_,
+                                                out, count, vocab, hidden, emb.group_size, flag, nullptr));
+    } else if (emb.precision == Precision::FP16) {
+        abi_check(cactus_hip_embedding_f16_dev(static_cast<const cactus_half_t*>(emb.device_data), index_scratch_, out,
+                                               count, vocab, hidden, flag, nullptr));
+    } else {
+        throw std::runtime_error("Embedding table must be INT8 or FP16");
+    }
+    int bad = 0;
+    hip_check(hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy D2H (index flag)");
+    if (bad) throw std::runtime_error("Embedding index out of bounds: >= " + std::to_string(vocab));
+}
+
 // A matmul node the batched decode launch can take: grouped INT8 or packed INT4 weights,
 // pretransposed, FP16 activations with at most 4 rows, inputs already computed.
 bool CactusGraph::batchable_matmul(const GraphNode& n, bool* int4) const {
@@ -404,8 +543,23 @@ void CactusGraph::execute() {
             }
         }
 
+        if (n.op_type == OpType::RESHAPE) {   // a view: same bytes, new shape
+            BufferDesc& in = node(n.input_ids[0]).output_buffer;
+            BufferDesc& out = n.output_buffer;
+            if (out.owns_device && out.device_data) (void)hipFree(out.device_data);
+            out.device_data = in.device_data;
+            out.owns_device = false;
+            out.device_valid = true;
+            continue;
+        }
         ensure_device(n.output_buffer);
         switch (n.op_type) {
+            case OpType::ADD: case OpType::ADD_CLIPPED: case OpType::SUBTRACT: case OpType::MULTIPLY:
+            case OpType::DIVIDE: compute_binary_node(n); break;
+            case OpType::SILU: case OpType::GELU: compute_activation_node(n); break;
+            case OpType::RMS_NORM: compute_rms_norm_node(n); break;
+            case OpType::ROPE: compute_rope_node(n); break;
+            case OpType::EMBEDDING: compute_embedding_node(n); break;
             case OpType::MATMUL: compute_matmul_node(n); break;
             case OpType::ATTENTION: compute_attention_node(n); break;
             case OpType::ATTENTION_INT8_HYBRID: compute_attention_int8_hybrid_node(n); break;
@@ -458,6 +612,9 @@ void CactusGraph::hard_reset() {
     for (auto& kv : quant_cache_)
         if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
     quant_cache_.clear();
+    if (index_scratch_) (void)hipFree(index_scratch_);
+    index_scratch_ = nullptr;
+    index_scratch_count_ = 0;
     next_node_id_ = 0;
 }
 
@@ -710,6 +867,32 @@ long cactus_hip_graph_attention_int8_hybrid(void* g, size_t q, size_t key_new, s
                                                   cached_values, k_scales, v_scales, cache_len, num_kv_heads,
                                                   head_dim);
     });
+}
+long cactus_hip_graph_binary(void* g, int op, size_t a, size_t b) {
+    return guarded<long>(-1, [&] {
+        switch (op) {
+            case 0: return (long)G_(g)->add(a, b);
+            case 1: return (long)G_(g)->subtract(a, b);
+            case 2: return (long)G_(g)->multiply(a, b);
+            case 3: return (long)G_(g)->divide(a, b);
+            case 4: return (long)G_(g)->add_clipped(a, b);
+            default: throw std::invalid_argument("binary op must be 0..4");
+        }
+    });
+}
+long cactus_hip_graph_silu(void* g, size_t input) { return guarded<long>(-1, [&] { return (long)G_(g)->silu(input); }); }
+long cactus_hip_graph_gelu(void* g, size_t input) { return guarded<long>(-1, [&] { return (long)G_(g)->gelu(input); }); }
+long cactus_hip_graph_reshape(void* g, size_t input, const size_t* shape, size_t ndim) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->reshape(input, std::vector<size_t>(shape, shape + ndim)); });
+}
+long cactus_hip_graph_embedding(void* g, size_t table, size_t indices) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->embedding(table, indices); });
+}
+long cactus_hip_graph_rms_norm(void* g, size_t input, size_t weight, float epsilon) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->rms_norm(input, weight, epsilon); });
+}
+long cactus_hip_graph_rope(void* g, size_t input, float theta, size_t position_offset) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->rope(input, theta, position_offset); });
 }
 int cactus_hip_graph_set_input(void* g, size_t node, const void* data, int precision) {
     return guarded<int>(-1, [&] { G_(g)->set_input(node, data, static_cast<Precision>(precision)); return 0; });

@@ -29,7 +29,11 @@ namespace cactus_hip {
 
 enum class Precision { INT8 = 0, FP16 = 1, FP32 = 2, INT4 = 3 };   // values as graph.h:99-104
 enum class ComputeBackend { CPU = 0, NPU = 1, HIP = 2 };           // HIP is the additive enumerator
-enum class OpType { INPUT, MATMUL, ATTENTION, ATTENTION_INT8_HYBRID, QUANTIZE_ACTIVATIONS };
+enum class OpType {
+    INPUT, MATMUL, ATTENTION, ATTENTION_INT8_HYBRID, QUANTIZE_ACTIVATIONS,
+    // the ops between the hot kernels of a decoder block
+    ADD, ADD_CLIPPED, SUBTRACT, MULTIPLY, DIVIDE, SILU, GELU, RMS_NORM, ROPE, RESHAPE, EMBEDDING
+};
 
 size_t precision_size(Precision p);   // bytes per element (INT4 counted as 1, graph.h:128-136)
 
@@ -66,6 +70,8 @@ struct OpParams {
     float scale = 1.0f;
     bool pretransposed_rhs = false;
     size_t position_offset = 0;
+    float epsilon = 1e-5f;   // RMS_NORM
+    float theta = 0.0f;      // ROPE
     size_t window_size = 0;
     bool is_causal = true;
     Precision output_precision = Precision::INT8;
@@ -110,6 +116,22 @@ public:
                                  const int8_t* cached_values, const float* k_scales, const float* v_scales,
                                  size_t cache_len, size_t num_kv_heads, size_t head_dim);
 
+    // Decoder-block ops (graph.h:400-404, 416-417, 423, 443, 448-449; graph_builder.cpp:11-59,
+    // 120-123, 253-261, 468-474, 524-539).  The binaries take equal shapes only (the reference
+    // also broadcasts); reshape is a view of its input's buffer.
+    size_t add(size_t input1, size_t input2);
+    size_t add_clipped(size_t input1, size_t input2);
+    size_t subtract(size_t input1, size_t input2);
+    size_t multiply(size_t input1, size_t input2);
+    size_t divide(size_t input1, size_t input2);
+    size_t silu(size_t input);
+    size_t gelu(size_t input);
+    size_t reshape(size_t input, const std::vector<size_t>& new_shape);
+    size_t embedding(size_t embedding_tensor, size_t indices);
+    size_t rms_norm(size_t input, size_t weight, float epsilon = 1e-5f);
+    size_t rope(size_t input, float theta, size_t position_offset = 0,
+                ComputeBackend backend = ComputeBackend::HIP);
+
     // Host data: copied to HBM now (set_input) or once per distinct pointer and kept resident
     // (set_external_input: weights that outlive the graph's steps).
     void set_input(size_t node_id, const void* data, Precision precision);
@@ -143,6 +165,12 @@ private:
     void compute_attention_node(GraphNode& n);
     void compute_attention_int8_hybrid_node(GraphNode& n);
     void compute_quantize_activations_node(GraphNode& n);
+    size_t binary_node(OpType op, size_t input1, size_t input2);
+    void compute_binary_node(GraphNode& n);
+    void compute_activation_node(GraphNode& n);
+    void compute_rms_norm_node(GraphNode& n);
+    void compute_rope_node(GraphNode& n);
+    void compute_embedding_node(GraphNode& n);
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;
@@ -154,6 +182,8 @@ private:
     // activation quantization shared by the matmuls that read one FP16 node (keyed by node id)
     struct QuantCache { void* q = nullptr; void* scales = nullptr; size_t M = 0, K = 0; };
     std::unordered_map<size_t, QuantCache> quant_cache_;
+    int32_t* index_scratch_ = nullptr;   // int32 copy of an EMBEDDING node's indices + one flag word
+    size_t index_scratch_count_ = 0;
 };
 
 // INT8 KV cache resident in HBM: per layer keys/values int8 [slot, Hkv, D] and fp32 scales

@@ -21,6 +21,13 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_quantize_activations": (_l, [_vp, _sz]),
     "cactus_hip_graph_attention": (_l, [_vp, _sz, _sz, _sz, _f, _sz, _sz, _i]),
     "cactus_hip_graph_attention_int8_hybrid": (_l, [_vp, _sz, _sz, _sz, _f, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]),
+    "cactus_hip_graph_binary": (_l, [_vp, _i, _sz, _sz]),
+    "cactus_hip_graph_silu": (_l, [_vp, _sz]),
+    "cactus_hip_graph_gelu": (_l, [_vp, _sz]),
+    "cactus_hip_graph_reshape": (_l, [_vp, _sz, _szp, _sz]),
+    "cactus_hip_graph_embedding": (_l, [_vp, _sz, _sz]),
+    "cactus_hip_graph_rms_norm": (_l, [_vp, _sz, _sz, _f]),
+    "cactus_hip_graph_rope": (_l, [_vp, _sz, _f, _sz]),
     "cactus_hip_graph_set_input": (_i, [_vp, _sz, _vp, _i]),
     "cactus_hip_graph_set_external_input": (_i, [_vp, _sz, _vp, _i]),
     "cactus_hip_graph_set_grouped_scales": (_i, [_vp, _sz, _sz, _sz, _vp]),
@@ -98,6 +105,51 @@ class CactusGraph:
         n = _node(lib.cactus_hip_graph_quantize_activations(self._g, x))
         self._shapes[n] = (self._shapes[x][0], INT8)
         return n
+
+    def _same(self, n, src, precision=None):
+        self._shapes[n] = (self._shapes[src][0], self._shapes[src][1] if precision is None else precision)
+        return n
+
+    def _binary(self, op, a, b):
+        return self._same(_node(lib.cactus_hip_graph_binary(self._g, op, a, b)), a)
+
+    def add(self, a, b):
+        return self._binary(0, a, b)
+
+    def subtract(self, a, b):
+        return self._binary(1, a, b)
+
+    def multiply(self, a, b):
+        return self._binary(2, a, b)
+
+    def divide(self, a, b):
+        return self._binary(3, a, b)
+
+    def add_clipped(self, a, b):
+        return self._binary(4, a, b)
+
+    def silu(self, x):
+        return self._same(_node(lib.cactus_hip_graph_silu(self._g, x)), x)
+
+    def gelu(self, x):
+        return self._same(_node(lib.cactus_hip_graph_gelu(self._g, x)), x)
+
+    def reshape(self, x, shape):
+        arr = (C.c_size_t * len(shape))(*shape)
+        n = _node(lib.cactus_hip_graph_reshape(self._g, x, arr, len(shape)))
+        self._shapes[n] = (tuple(shape), self._shapes[x][1])
+        return n
+
+    def embedding(self, table, indices):
+        n = _node(lib.cactus_hip_graph_embedding(self._g, table, indices))
+        self._shapes[n] = (tuple(self._shapes[indices][0]) + (self._shapes[table][0][1],), FP16)
+        return n
+
+    def rms_norm(self, x, weight, epsilon=1e-5):
+        return self._same(_node(lib.cactus_hip_graph_rms_norm(self._g, x, weight, epsilon)), x)
+
+    def rope(self, x, theta, position_offset=0):
+        return self._same(_node(lib.cactus_hip_graph_rope(self._g, x, theta, position_offset)), x)
 
     def attention(self, q, k, v, scale, position_offset=0, window_size=0, is_causal=True):
         n = _node(lib.cactus_hip_graph_attention(self._g, q, k, v, scale, position_offset, window_size,
@@ -178,6 +230,9 @@ class KVCache:
         k = (C.c_size_t * len(k_nodes))(*k_nodes)
         v = (C.c_size_t * len(v_nodes))(*v_nodes)
         _ok(lib.cactus_hip_kvcache_update(self._c, graph._g, k, v, seq_len))
+
+    def is_empty(self):
+        return self.get_effective_seq_len() == 0
 
     def get_effective_seq_len(self):
         return lib.cactus_hip_kvcache_len(self._c)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "cactus_hip_subtract_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_divide_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_indices_to_int32_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
     "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "cactus_hip_embedding_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "cactus_hip_rms_norm_f16": (None, [_vp, _vp, _vp, _sz, _sz, _f]),

@@ -189,6 +189,11 @@ int cactus_hip_divide_f16_dev(const cactus_half_t* a, const cactus_half_t* b, ca
  * (:243-254), FP16 rows are copied (:301-316).  indices: device int32[num_indices].  An index
  * outside [0, vocab_size) writes nothing for that row and stores 1 to *bad_index_flag (device
  * int, may be NULL; the caller clears it) -- the reference throws there (:261-263). */
+/* The index conversion of compute_embedding_node (graph_ops_tensor.cpp:257-275: indices held as
+ * FP32 or INT8 values, `static_cast<size_t>(indices[i])`): precision 2 = float, 0 = int8; values
+ * that are not a valid index (negative, NaN) become -1. */
+int cactus_hip_indices_to_int32_dev(const void* indices, int precision, int32_t* output, size_t count,
+                                    void* stream);
 int cactus_hip_embedding_int8_dev(const int8_t* embeddings, const cactus_half_t* scales,
                                   const int32_t* indices, cactus_half_t* output, size_t num_indices,
                                   size_t vocab_size, size_t hidden_dim, size_t group_size,

@@ -42,6 +42,16 @@ long   cactus_hip_graph_attention_int8_hybrid(void* graph, size_t q, size_t key_
                                               const int8_t* cached_keys, const int8_t* cached_values,
                                               const float* k_scales, const float* v_scales,
                                               size_t cache_len, size_t num_kv_heads, size_t head_dim);
+/* Decoder-block ops (cactus/graph/graph.h:400-404, 416-417, 423, 443, 448-449).  binary op:
+ * 0 add, 1 subtract, 2 multiply, 3 divide, 4 add_clipped; equal shapes only.  reshape is a view.
+ * embedding: table node INT8 (with grouped scales) or FP16, indices node FP32 or INT8 values. */
+long   cactus_hip_graph_binary(void* graph, int op, size_t a, size_t b);
+long   cactus_hip_graph_silu(void* graph, size_t input);
+long   cactus_hip_graph_gelu(void* graph, size_t input);
+long   cactus_hip_graph_reshape(void* graph, size_t input, const size_t* shape, size_t ndim);
+long   cactus_hip_graph_embedding(void* graph, size_t table, size_t indices);
+long   cactus_hip_graph_rms_norm(void* graph, size_t input, size_t weight, float epsilon);
+long   cactus_hip_graph_rope(void* graph, size_t input, float theta, size_t position_offset);
 int    cactus_hip_graph_set_input(void* graph, size_t node, const void* host_data, int precision);
 int    cactus_hip_graph_set_external_input(void* graph, size_t node, void* host_data, int precision);
 int    cactus_hip_graph_set_grouped_scales(void* graph, size_t node, size_t group_size, size_t num_groups,
