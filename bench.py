@@ -287,22 +287,30 @@ def main():
         dist.destroy_process_group()
 
 
-def qwen3_hotpath_decode(H, gen, batch, cache_len, layers=28):
-    """One decode step of the Qwen3-0.6B op sequence restricted to this library's ops (hidden
-    1024, 16 q / 8 kv heads of 128, ffn 3072, vocab 151936: cactus/engine/engine.h:44-59; op
-    order model_qwen.cpp:51-129): per layer q/k/v projections, attention over the INT8 cache plus
-    the new FP16 token, KV quantization of the new token, o projection, gate/up, down; then the
-    lm_head.  Norms, RoPE, activations and residual adds are not part of the library yet and are
-    left out, so this is the hot path's share of a token, not a model's tok/s.  Synthetic INT8
-    weights, distinct per layer (596 MB in total, streamed from HBM every step); the whole step
-    is one HIP graph."""
+def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
+    """One decode step of the Qwen3-0.6B op sequence (hidden 1024, 16 q / 8 kv heads of 128, ffn
+    3072, vocab 151936: cactus/engine/engine.h:44-59; op order model_qwen.cpp:51-129, 169-172):
+    per layer input norm, q/k/v projections, per-head q/k norms, RoPE, attention over the INT8
+    cache plus the new FP16 token, KV quantization of the new token into the cache, o projection,
+    residual add, post-attention norm, gate/up, SiLU x up, down, residual add; then the final norm
+    and the lm_head -- with the back-to-back small ops going out as the library's one-launch
+    sequences (add + norm, q/k norm + RoPE, SiLU x up, K + V quantization).  The embedding lookup and the sampler are outside the timed step.  Synthetic
+    INT8 weights, distinct per layer (596 MB in total, streamed from HBM every step); the whole
+    step is one HIP graph."""
     Hd, Hq, Hkv, D, F, V = 1024, 16, 8, 128, 3072, 151936
     mk = lambda N, K: make_weights(K, N, False, gen)
     Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), gate=mk(F, Hd),
                up=mk(F, Hd), down=mk(Hd, F)) for _ in range(layers)]
     head = mk(V, Hd)
+    nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
+    for L in Ls:
+        L.update(in_norm=nw(Hd), post_norm=nw(Hd), q_norm=nw(D), k_norm=nw(D))
+    final_norm = nw(Hd)
+    theta, eps, pos = 1e6, 1e-6, cache_len
+    H.rope_reserve(D, theta, pos + 1)
     half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
-    x = (torch.rand((batch, Hd), device="cuda", generator=gen) * 2 - 1).half()
+    h0 = (torch.rand((batch, Hd), device="cuda", generator=gen) * 2 - 1).half()   # embedding output
+    hid, x = half(batch, Hd), half(batch, Hd)
     kc = torch.randint(-127, 128, (layers, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
     vc = torch.randint(-127, 128, (layers, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
     ksc = torch.rand((layers, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
@@ -310,17 +318,23 @@ def qwen3_hotpath_decode(H, gen, batch, cache_len, layers=28):
     lens = torch.full((batch,), cache_len, dtype=torch.int32, device="cuda")
     qo, ko, vo = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hkv * D)
     oo, go, uo, do, logits = half(batch, Hd), half(batch, F), half(batch, F), half(batch, Hd), half(batch, V)
+    qr, kr, h2, xn2, act = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hd), half(batch, Hd), half(batch, F)
+    kq_new = torch.empty((batch, Hkv, D), dtype=torch.int8, device="cuda"); vq_new = torch.empty_like(kq_new)
+    ks_new = torch.empty((batch, Hkv, 1), dtype=torch.float32, device="cuda"); vs_new = torch.empty_like(ks_new)
     ao = [None]
     batches = []
     if batch <= 4:
         for L in Ls:
-            batches.append((H.MatmulBatch([(x, *L["q"], qo), (x, *L["k"], ko), (x, *L["v"], vo)], 128),
-                            H.MatmulBatch([(oo, *L["gate"], go), (oo, *L["up"], uo)], 128)))
+            batches.append((H.MatmulBatch([(x, L["q"][0], L["q"][1], qo), (x, L["k"][0], L["k"][1], ko),
+                                           (x, L["v"][0], L["v"][1], vo)], 128),
+                            H.MatmulBatch([(xn2, L["gate"][0], L["gate"][1], go), (xn2, L["up"][0], L["up"][1], uo)], 128)))
 
     def proj(inp, w, out):
         H.matmul_f16act(inp, w[0], w[1], 128, out=out)
 
     def step():
+        H.rms_norm(h0, Ls[0]["in_norm"], eps, out=x)     # h0 = the embedding rows
+        res = h0
         for li, L in enumerate(Ls):
             if batch <= 4:
                 batches[li][0].run()
@@ -328,26 +342,33 @@ def qwen3_hotpath_decode(H, gen, batch, cache_len, layers=28):
                 q8, s8 = H.quantize_activations(x)
                 for name, out in (("q", qo), ("k", ko), ("v", vo)):
                     H.matmul_int8(q8, s8, L[name][0], L[name][1], 128, out=out)
-            a = H.attention_hybrid_batched(qo.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
-                                           ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
+            H.qk_norm_rope(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), L["q_norm"], L["k_norm"], eps, theta,
+                           pos, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
+            a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
+                                           kr.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
             # the new token's K and V join the cache (slot cache_len of every sequence)
-            for src, dst, dsc in ((ko, kc, ksc), (vo, vc, vsc)):
-                if batch == 1:   # straight into the cache slot
-                    H.quantize_kv(src.view(1, Hkv, D), out=dst[li, 0, cache_len:cache_len + 1],
-                                  out_scales=dsc[li, 0, cache_len:cache_len + 1])
-                else:
-                    qn, sn = H.quantize_kv(src.view(batch, Hkv, D))
-                    dst[li, :, cache_len] = qn
-                    dsc[li, :, cache_len] = sn
+            if batch == 1:   # straight into the cache slot
+                H.quantize_kv_pair(kr.view(1, Hkv, D), vo.view(1, Hkv, D), kc[li, 0, cache_len:cache_len + 1],
+                                   vc[li, 0, cache_len:cache_len + 1], ksc[li, 0, cache_len:cache_len + 1],
+                                   vsc[li, 0, cache_len:cache_len + 1])
+            else:
+                H.quantize_kv_pair(kr.view(batch, Hkv, D), vo.view(batch, Hkv, D), kq_new, vq_new, ks_new, vs_new)
+                kc[li, :, cache_len] = kq_new; vc[li, :, cache_len] = vq_new
+                ksc[li, :, cache_len] = ks_new; vsc[li, :, cache_len] = vs_new
             proj(a.view(batch, Hq * D), L["o"], oo)
+            H.add_rms_norm(res, oo, L["post_norm"], eps, out_sum=h2, out_norm=xn2)
             if batch <= 4:
                 batches[li][1].run()
             else:
-                q8, s8 = H.quantize_activations(oo)
+                q8, s8 = H.quantize_activations(xn2)
                 H.matmul_int8(q8, s8, L["gate"][0], L["gate"][1], 128, out=go)
                 H.matmul_int8(q8, s8, L["up"][0], L["up"][1], 128, out=uo)
-            proj(go, L["down"], do)
-        proj(do, head, logits)
+            H.silu_multiply(go, uo, out=act)
+            proj(act, L["down"], do)
+            nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
+            H.add_rms_norm(h2, do, nxt, eps, out_sum=hid, out_norm=x)   # residual add + the next norm
+            res = hid
+        proj(x, head, logits)
 
     step()
     torch.cuda.synchronize()
@@ -368,7 +389,7 @@ def qwen3_hotpath_decode(H, gen, batch, cache_len, layers=28):
     kvbytes = layers * batch * 2 * cache_len * Hkv * (D + 4)
     return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
             "cache_len": cache_len, "GBps": round((wbytes + kvbytes) / (ms * 1e-3) / 1e9, 1),
-            "note": "matmul + attention + KV-quant ops of a Qwen3-0.6B token only (no norm/RoPE/activation)"}
+            "note": "every op of a Qwen3-0.6B decode step after the embedding lookup and before the sampler"}
 
 
 def extra_table(H, gen, big):
@@ -425,8 +446,8 @@ def extra_table(H, gen, big):
         rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
     ex["attn_decode_int8kv"] = rows
     torch.cuda.empty_cache()
-    ex["qwen3_0p6b_hotpath_decode"] = {"b1_c512": qwen3_hotpath_decode(H, gen, 1, 512),
-                                       "b256_c512": qwen3_hotpath_decode(H, gen, 256, 512)}
+    ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
+                                       "b256_c512": qwen3_decode_step(H, gen, 256, 512)}
     return ex
 
 

@@ -301,6 +301,19 @@ int cactus_hip_quantize_kv_fp16_to_int8_dev(const cactus_half_t* src, int8_t* ds
     return CACTUS_HIP_OK;
 }
 
+int cactus_hip_quantize_kv_pair_fp16_to_int8_dev(const cactus_half_t* k_src, const cactus_half_t* v_src,
+                                                 int8_t* k_dst, int8_t* v_dst, float* k_scales, float* v_scales,
+                                                 size_t seq_len, size_t kv_heads, size_t head_dim,
+                                                 size_t group_size, void* stream) {
+    if (seq_len * kv_heads * head_dim == 0) return CACTUS_HIP_OK;
+    if (!k_src || !v_src || !k_dst || !v_dst || !k_scales || !v_scales || group_size == 0)
+        return fail(CACTUS_HIP_EINVAL, "quantize_kv_pair: bad operand");
+    hipError_t e = launch_kv_quant_pair(k_src, k_dst, k_scales, v_src, v_dst, v_scales, seq_len, kv_heads, head_dim,
+                                        group_size, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "kv_quant launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_unpack_int4_to_int8_dev(const uint8_t* packed, int8_t* unpacked, size_t unpacked_count,
                                        void* stream) {
     if (unpacked_count == 0) return CACTUS_HIP_OK;
@@ -411,6 +424,17 @@ int rope_rows(size_t head_dim, float theta, size_t start_pos, size_t seq, const 
 
 }  // namespace
 
+int cactus_hip_add_rms_norm_f16_dev(const cactus_half_t* a, const cactus_half_t* b, const cactus_half_t* weight,
+                                    cactus_half_t* sum_output, cactus_half_t* norm_output, size_t batch_size,
+                                    size_t dims, float eps, void* stream) {
+    if (batch_size * dims == 0) return CACTUS_HIP_OK;
+    if (!a || !b || !weight || !sum_output || !norm_output) return fail(CACTUS_HIP_EINVAL, "add_rms_norm: null operand");
+    if (dims > (size_t(1) << 30)) return fail(CACTUS_HIP_EINVAL, "add_rms_norm: dims too large");
+    hipError_t e = launch_add_rms_norm(a, b, weight, sum_output, norm_output, batch_size, dims, eps, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "add_rms_norm launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_rope_reserve(size_t head_dim, float theta, size_t max_positions) {
     if (head_dim < 2 || max_positions == 0) return CACTUS_HIP_OK;
     const uint16_t *c, *s;
@@ -429,6 +453,25 @@ int cactus_hip_rope_f16_dev(const cactus_half_t* input, cactus_half_t* output, s
     if (rc != CACTUS_HIP_OK) return rc;
     hipError_t e = launch_rope(input, output, c, s, batch_size, seq_len, num_heads, head_dim, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "rope launch", e);
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_qk_norm_rope_f16_dev(const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* q_weight,
+                                    const cactus_half_t* k_weight, cactus_half_t* q_output, cactus_half_t* k_output,
+                                    size_t batch_size, size_t seq_len, size_t num_q_heads, size_t num_kv_heads,
+                                    size_t head_dim, float eps, size_t start_pos, float theta, void* stream) {
+    if (batch_size * seq_len * head_dim == 0 || num_q_heads + num_kv_heads == 0) return CACTUS_HIP_OK;
+    if (!q || !k || !q_weight || !k_weight || !q_output || !k_output)
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope: null operand");
+    if ((head_dim & 1) || head_dim > 2048) return fail(CACTUS_HIP_EINVAL, "qk_norm_rope: head_dim must be even and <= 2048");
+    if (seq_len > (size_t(1) << 30) || num_q_heads > (size_t(1) << 20) || num_kv_heads > (size_t(1) << 20))
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope: dimension too large");
+    const uint16_t *c, *s;
+    int rc = rope_rows(head_dim, theta, start_pos, seq_len, &c, &s);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_qk_norm_rope(q, k, q_weight, k_weight, q_output, k_output, c, s, batch_size * seq_len,
+                                       num_q_heads, num_kv_heads, head_dim, seq_len, eps, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "qk_norm_rope launch", e);
     return CACTUS_HIP_OK;
 }
 
@@ -455,6 +498,22 @@ int cactus_hip_silu_f16_dev(const cactus_half_t* in, cactus_half_t* out, size_t 
 }
 int cactus_hip_gelu_f16_dev(const cactus_half_t* in, cactus_half_t* out, size_t n, void* stream) {
     return unary_dev(1, "gelu: null operand or launch failure", in, out, n, stream);
+}
+int cactus_hip_silu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up, cactus_half_t* out, size_t n,
+                                     void* stream) {
+    if (n == 0) return CACTUS_HIP_OK;
+    if (!gate || !up || !out) return fail(CACTUS_HIP_EINVAL, "silu_multiply: null operand");
+    hipError_t e = launch_unary_mul(0, gate, up, out, n, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "silu_multiply launch", e);
+    return CACTUS_HIP_OK;
+}
+int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up, cactus_half_t* out, size_t n,
+                                     void* stream) {
+    if (n == 0) return CACTUS_HIP_OK;
+    if (!gate || !up || !out) return fail(CACTUS_HIP_EINVAL, "gelu_multiply: null operand");
+    hipError_t e = launch_unary_mul(1, gate, up, out, n, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "gelu_multiply launch", e);
+    return CACTUS_HIP_OK;
 }
 int cactus_hip_add_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n, void* stream) {
     return binary_dev(0, "add: null operand or launch failure", a, b, out, n, stream);

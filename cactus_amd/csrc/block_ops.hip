@@ -33,64 +33,161 @@ __device__ __forceinline__ uint16_t h2bits(h16 h) { return __builtin_bit_cast(ui
 // output multiplies in fp16, (x * half(inv)) * w with both products rounded; the tail computes
 // x*inv*w in fp32 and rounds once.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rms_norm_kernel(const uint16_t* __restrict__ x,
-                                                       const uint16_t* __restrict__ w,
-                                                       uint16_t* __restrict__ y, size_t rows, int dims,
-                                                       float eps) {
-    const int l = threadIdx.x & 15;
-    const size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = row < rows;
-    const size_t r = live ? row : rows - 1;   // dead groups recompute the last row and store nothing
-    const uint16_t* xr = x + r * dims;
+
+// 1 / rms of one row, computed by the 16 lanes [base, base + 16) of a wave; `elem(i)` returns the
+// binary16 bits of element i.  Loads run 8 ahead of the fma chain.
+template <typename Elem>
+__device__ __forceinline__ float row_inv_rms(Elem elem, int dims, float eps, int l, int base) {
     const int simd_end = dims & ~7;
     float acc = 0.0f;
-    for (int i = l; i < simd_end; i += 16) {
-        const float v = h2f(xr[i]);
-        acc = fmaf(v, v, acc);
+    int i = l;
+    for (; i + 7 * 16 < simd_end; i += 8 * 16) {
+        uint16_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = elem(i + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float f = h2f(v[u]);
+            acc = fmaf(f, f, acc);
+        }
     }
-    const int base = (threadIdx.x & 63) & ~15;
+    for (; i < simd_end; i += 16) {
+        const float f = h2f(elem(i));
+        acc = fmaf(f, f, acc);
+    }
     const float a0 = __shfl(acc, base + (l & 3)), a1 = __shfl(acc, base + 4 + (l & 3));
     const float a2 = __shfl(acc, base + 8 + (l & 3)), a3 = __shfl(acc, base + 12 + (l & 3));
     const float t = ((a0 + a1) + a2) + a3;
     const float t0 = __shfl(t, base), t1 = __shfl(t, base + 1), t2 = __shfl(t, base + 2), t3 = __shfl(t, base + 3);
     float ss = (t0 + t1) + (t2 + t3);
-    for (int i = simd_end; i < dims; i++) {
-        const float v = h2f(xr[i]);
-        ss = fmaf(v, v, ss);
+    for (int k = simd_end; k < dims; k++) {
+        const float f = h2f(elem(k));
+        ss = fmaf(f, f, ss);
     }
     const float rms = __builtin_sqrtf(ss / (float)dims + eps);
-    const float inv = 1.0f / rms;
+    return 1.0f / rms;
+}
+
+// normalized element i: fp16 products in the vector part, one fp32 expression in the tail
+__device__ __forceinline__ uint16_t rms_out(uint16_t xb, uint16_t wb, float inv, h16 inv_h, bool vector_part) {
+    if (vector_part) {
+        const h16 p = bits2h(xb) * inv_h;
+        return h2bits(p * bits2h(wb));
+    }
+    return f2h(h2f(xb) * inv * h2f(wb));
+}
+
+// ADD: the row normalized is a + b (one fp16 add per element, as cactus_add_f16), which is also
+// written to sum_out: the residual add and the norm that follows it in a decoder block
+// (model_qwen.cpp:125-126), one launch.
+// A workgroup takes rpb (<= 16) rows.  All 256 threads first copy the rows (summed if ADD) into
+// LDS with 16-byte loads, so that a row costs one load latency instead of one per step of the
+// 16-lane accumulation chain; the chain and the output pass then read LDS.  rpb = 0: rows too
+// long for LDS, 16 rows per workgroup read straight from global memory.
+template <bool ADD>
+__global__ __launch_bounds__(256) void rms_norm_kernel(const uint16_t* __restrict__ x,
+                                                       const uint16_t* __restrict__ addend,
+                                                       const uint16_t* __restrict__ w_in,
+                                                       uint16_t* __restrict__ sum_out,
+                                                       uint16_t* __restrict__ y, size_t rows, int dims,
+                                                       float eps, int rpb) {
+    const uint16_t* w = w_in;
+    extern __shared__ __attribute__((aligned(16))) uint16_t rn_lds[];   // [rpb][dims]
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const bool staged = rpb > 0;
+    const int per_block = staged ? rpb : 16;
+    const size_t row0 = (size_t)blockIdx.x * per_block;
+    if (staged) {
+        const size_t nrows = min((size_t)rpb, rows - row0);
+        const size_t n = nrows * dims;
+        const uint16_t* xs = x + row0 * dims;
+        const uint16_t* as = ADD ? addend + row0 * dims : nullptr;
+        bool vec = ((reinterpret_cast<uintptr_t>(xs)) & 15) == 0;
+        if (ADD) vec = vec && (reinterpret_cast<uintptr_t>(as) & 15) == 0;
+        const size_t nv = vec ? n / 8 : 0;
+        for (size_t c = threadIdx.x; c < nv; c += 256) {
+            v4i xv = *reinterpret_cast<const v4i*>(xs + c * 8);
+            if (ADD) {
+                const v4i av = *reinterpret_cast<const v4i*>(as + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t lo = h2bits(bits2h((uint16_t)((uint32_t)xv[e] & 0xFFFFu)) + bits2h((uint16_t)((uint32_t)av[e] & 0xFFFFu)));
+                    const uint32_t hi = h2bits(bits2h((uint16_t)((uint32_t)xv[e] >> 16)) + bits2h((uint16_t)((uint32_t)av[e] >> 16)));
+                    xv[e] = (int)(lo | (hi << 16));
+                }
+            }
+            *reinterpret_cast<v4i*>(rn_lds + c * 8) = xv;
+        }
+        for (size_t i = nv * 8 + threadIdx.x; i < n; i += 256)
+            rn_lds[i] = ADD ? h2bits(bits2h(xs[i]) + bits2h(as[i])) : xs[i];
+        // the weight row rides along (behind the rows, 16-byte aligned), so that every global load
+        // of the kernel is in flight at once
+        uint16_t* wl = rn_lds + (((size_t)rpb * dims + 7) & ~(size_t)7);
+        const size_t wv = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) ? (size_t)dims / 8 : 0;
+        for (size_t c = threadIdx.x; c < wv; c += 256)
+            *reinterpret_cast<v4i*>(wl + c * 8) = *reinterpret_cast<const v4i*>(w + c * 8);
+        for (size_t i = wv * 8 + threadIdx.x; i < (size_t)dims; i += 256) wl[i] = w[i];
+        __syncthreads();
+        w = wl;
+    }
+    const size_t row = row0 + grp;
+    const bool live = row < rows && grp < per_block;
+    const size_t r = live ? row : (staged ? row0 : rows - 1);   // idle groups redo a valid row, store nothing
+    const uint16_t* xr = x + r * dims;
+    const uint16_t* ar = ADD ? addend + r * dims : nullptr;
+    const uint16_t* lr = rn_lds + (r - row0) * dims;
+    const int simd_end = dims & ~7;
+    const int base = (threadIdx.x & 63) & ~15;
+    auto elem = [&](int i) -> uint16_t {
+        if (staged) return lr[i];
+        if (ADD) return h2bits(bits2h(xr[i]) + bits2h(ar[i]));
+        return xr[i];
+    };
+    const float inv = row_inv_rms(elem, dims, eps, l, base);
     if (!live) return;
     const h16 inv_h = (h16)inv;
     uint16_t* yr = y + r * dims;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(xr) | reinterpret_cast<uintptr_t>(yr) |
-                          reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    uint16_t* sr = ADD ? sum_out + r * dims : nullptr;
+    bool vec_ok = (reinterpret_cast<uintptr_t>(yr) & 15) == 0;
+    if (!staged) vec_ok = vec_ok && ((reinterpret_cast<uintptr_t>(xr) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    if (staged) vec_ok = vec_ok && ((dims & 7) == 0);   // LDS rows stay 16-byte aligned
+    if (ADD) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(sr) & 15) == 0 &&
+                      (staged || (reinterpret_cast<uintptr_t>(ar) & 15) == 0);
     if (vec_ok) {
         for (int c = l; c < simd_end / 8; c += 16) {
-            const v4i xv = *reinterpret_cast<const v4i*>(xr + c * 8);
+            v4i xv = staged ? *reinterpret_cast<const v4i*>(lr + c * 8) : *reinterpret_cast<const v4i*>(xr + c * 8);
             const v4i wv = *reinterpret_cast<const v4i*>(w + c * 8);
-            v4i o;
+            v4i av = {0, 0, 0, 0};
+            if (ADD && !staged) av = *reinterpret_cast<const v4i*>(ar + c * 8);
+            v4i o, so;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                uint32_t res = 0;
+                uint32_t res = 0, sres = 0;
 #pragma unroll
                 for (int hh = 0; hh < 2; hh++) {
-                    const h16 xe = bits2h((uint16_t)((uint32_t)xv[e] >> (16 * hh)));
-                    const h16 we = bits2h((uint16_t)((uint32_t)wv[e] >> (16 * hh)));
-                    const h16 p = xe * inv_h;
-                    res |= (uint32_t)h2bits(p * we) << (16 * hh);
+                    uint16_t xb = (uint16_t)((uint32_t)xv[e] >> (16 * hh));
+                    if (ADD && !staged) xb = h2bits(bits2h(xb) + bits2h((uint16_t)((uint32_t)av[e] >> (16 * hh))));
+                    sres |= (uint32_t)xb << (16 * hh);
+                    res |= (uint32_t)rms_out(xb, (uint16_t)((uint32_t)wv[e] >> (16 * hh)), inv, inv_h, true) << (16 * hh);
                 }
                 o[e] = (int)res;
+                so[e] = (int)sres;
             }
             *reinterpret_cast<v4i*>(yr + c * 8) = o;
+            if (ADD) *reinterpret_cast<v4i*>(sr + c * 8) = so;
         }
     } else {
         for (int i = l; i < simd_end; i += 16) {
-            const h16 p = bits2h(xr[i]) * inv_h;
-            yr[i] = h2bits(p * bits2h(w[i]));
+            const uint16_t xb = elem(i);
+            yr[i] = rms_out(xb, w[i], inv, inv_h, true);
+            if (ADD) sr[i] = xb;
         }
     }
-    for (int i = simd_end + l; i < dims; i += 16) yr[i] = f2h(h2f(xr[i]) * inv * h2f(w[i]));
+    for (int i = simd_end + l; i < dims; i += 16) {
+        const uint16_t xb = elem(i);
+        yr[i] = rms_out(xb, w[i], inv, inv_h, false);
+        if (ADD) sr[i] = xb;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -122,6 +219,56 @@ __global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ 
         const float a = x1 * c, b = x2 * sn, d = x2 * c, e = x1 * sn;
         out[off + i] = f2h(a - b);
         out[off + half_dim + i] = f2h(d + e);
+    }
+}
+
+// Per-head RMS norm of the q and k projections followed by RoPE (model_qwen.cpp:63-81), one
+// launch: a 16-lane group takes one (token, head) row of head_dim elements, normalizes it into
+// LDS with the arithmetic of rms_norm_kernel, then rotates it with the arithmetic of rope_kernel.
+// Rows [0, tokens*Hq) are q rows, the rest k rows; cos_t / sin_t as in rope_kernel.
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __restrict__ q,
+                                                           const uint16_t* __restrict__ k,
+                                                           const uint16_t* __restrict__ qw,
+                                                           const uint16_t* __restrict__ kw,
+                                                           uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_out,
+                                                           const uint16_t* __restrict__ cos_t,
+                                                           const uint16_t* __restrict__ sin_t, size_t tokens,
+                                                           int Hq, int Hkv, int D, int seq_len, float eps) {
+    extern __shared__ uint16_t qk_lds[];   // [16][D]
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t nq = tokens * Hq, total = nq + tokens * Hkv;
+    const size_t row = (size_t)blockIdx.x * 16 + grp;
+    const bool live = row < total;
+    const size_t r = live ? row : total - 1;
+    const bool is_q = r < nq;
+    const size_t hr = is_q ? r : r - nq;                    // token * heads + head
+    const size_t token = hr / (is_q ? Hq : Hkv);
+    const uint16_t* xr = (is_q ? q : k) + hr * D;
+    const uint16_t* w = is_q ? qw : kw;
+    uint16_t* orow = (is_q ? q_out : k_out) + hr * D;
+    const int base = (threadIdx.x & 63) & ~15;
+    const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, D, eps, l, base);
+    const h16 inv_h = (h16)inv;
+    uint16_t* nrm = qk_lds + grp * D;
+    const int simd_end = D & ~7;
+    for (int i = l; i < D; i += 16) nrm[i] = rms_out(xr[i], w[i], inv, inv_h, i < simd_end);
+    __syncthreads();
+    if (!live) return;
+    const int half_dim = D / 2, s = (int)(token % seq_len);
+    for (int i = l; i < half_dim; i += 16) {
+        const uint16_t cb = cos_t[(size_t)s * half_dim + i], sb = sin_t[(size_t)s * half_dim + i];
+        const uint16_t x1b = nrm[i], x2b = nrm[half_dim + i];
+        if (i < (half_dim & ~7)) {
+            const h16 c = bits2h(cb), sn = bits2h(sb), x1 = bits2h(x1b), x2 = bits2h(x2b);
+            const h16 p1 = x1 * c, p2 = x2 * c;
+            orow[i] = h2bits(__builtin_fmaf16(-x2, sn, p1));
+            orow[half_dim + i] = h2bits(__builtin_fmaf16(x1, sn, p2));
+        } else {
+            const float c = h2f(cb), sn = h2f(sb), x1 = h2f(x1b), x2 = h2f(x2b);
+            const float pa = x1 * c, pb = x2 * sn, pd = x2 * c, pe = x1 * sn;
+            orow[i] = f2h(pa - pb);
+            orow[half_dim + i] = f2h(pd + pe);
+        }
     }
 }
 
@@ -182,25 +329,32 @@ __device__ __forceinline__ uint16_t unary_one(uint16_t hb, bool vector_part) {
 // The call is treated as one contiguous piece: whole groups of 8 from the start take the vector
 // formula, the last n % 8 elements the scalar libm one (what the reference does whenever it runs
 // the call on one thread).
-template <int OP>
-__global__ __launch_bounds__(256) void unary_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                    size_t n) {
+// MUL: the result is multiplied by mul[i] in fp16 (cactus_multiply_f16 on the rounded activation):
+// silu(gate) * up of the MLP (model_qwen.cpp:114-115) in one launch.
+template <int OP, bool MUL>
+__global__ __launch_bounds__(256) void unary_kernel(const uint16_t* __restrict__ in, const uint16_t* __restrict__ mul,
+                                                    uint16_t* __restrict__ out, size_t n) {
     const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;   // chunk of 8 halves
     const size_t vend = n & ~(size_t)7;
     if (c * 8 >= n) return;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    bool vec_ok = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (MUL) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(mul) & 15) == 0;
+    auto times = [](uint16_t a, uint16_t m) -> uint16_t { return MUL ? h2bits(bits2h(a) * bits2h(m)) : a; };
     if (c * 8 < vend && vec_ok) {
         const v4i xv = *reinterpret_cast<const v4i*>(in + c * 8);
+        v4i mv = {0, 0, 0, 0};
+        if (MUL) mv = *reinterpret_cast<const v4i*>(mul + c * 8);
         v4i o;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const uint32_t lo = unary_one<OP>((uint16_t)((uint32_t)xv[e] & 0xFFFFu), true);
-            const uint32_t hi = unary_one<OP>((uint16_t)((uint32_t)xv[e] >> 16), true);
+            const uint32_t lo = times(unary_one<OP>((uint16_t)((uint32_t)xv[e] & 0xFFFFu), true), (uint16_t)((uint32_t)mv[e] & 0xFFFFu));
+            const uint32_t hi = times(unary_one<OP>((uint16_t)((uint32_t)xv[e] >> 16), true), (uint16_t)((uint32_t)mv[e] >> 16));
             o[e] = (int)(lo | (hi << 16));
         }
         *reinterpret_cast<v4i*>(out + c * 8) = o;
     } else {
-        for (size_t i = c * 8; i < c * 8 + 8 && i < n; i++) out[i] = unary_one<OP>(in[i], i < vend);
+        for (size_t i = c * 8; i < c * 8 + 8 && i < n; i++)
+            out[i] = times(unary_one<OP>(in[i], i < vend), MUL ? mul[i] : (uint16_t)0);
     }
 }
 
@@ -299,9 +453,41 @@ hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, siz
     return hipGetLastError();
 }
 
+// rows staged in LDS per workgroup: as many as fit 32 KB, at most 16; 0 = too long to stage
+static int rms_rows_per_block(size_t dims) {
+    const size_t fit = (30 * 1024) / (dims * sizeof(uint16_t));   // rows + one weight row within 64 KB
+    return (int)(fit > 16 ? 16 : fit);
+}
+
+static size_t rms_lds_bytes(int rpb, size_t dims) {
+    return rpb ? ((((size_t)rpb * dims + 7) & ~(size_t)7) + dims) * sizeof(uint16_t) : 0;
+}
+
 hipError_t launch_rms_norm(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t rows, size_t dims, float eps,
                            hipStream_t st) {
-    rms_norm_kernel<<<dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st>>>(x, w, y, rows, (int)dims, eps);
+    const int rpb = rms_rows_per_block(dims);
+    const size_t per = rpb ? rpb : 16;
+    rms_norm_kernel<false><<<dim3((unsigned)((rows + per - 1) / per)), dim3(256), rms_lds_bytes(rpb, dims), st>>>(
+        x, nullptr, w, nullptr, y, rows, (int)dims, eps, rpb);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_rms_norm(const uint16_t* a, const uint16_t* b, const uint16_t* w, uint16_t* sum_out,
+                               uint16_t* y, size_t rows, size_t dims, float eps, hipStream_t st) {
+    const int rpb = rms_rows_per_block(dims);
+    const size_t per = rpb ? rpb : 16;
+    rms_norm_kernel<true><<<dim3((unsigned)((rows + per - 1) / per)), dim3(256), rms_lds_bytes(rpb, dims), st>>>(
+        a, b, w, sum_out, y, rows, (int)dims, eps, rpb);
+    return hipGetLastError();
+}
+
+hipError_t launch_qk_norm_rope(const uint16_t* q, const uint16_t* k, const uint16_t* qw, const uint16_t* kw,
+                               uint16_t* q_out, uint16_t* k_out, const uint16_t* cos_t, const uint16_t* sin_t,
+                               size_t tokens, size_t Hq, size_t Hkv, size_t D, size_t seq_len, float eps,
+                               hipStream_t st) {
+    const size_t total = tokens * (Hq + Hkv);
+    qk_norm_rope_kernel<<<dim3((unsigned)((total + 15) / 16)), dim3(256), 16 * D * sizeof(uint16_t), st>>>(
+        q, k, qw, kw, q_out, k_out, cos_t, sin_t, tokens, (int)Hq, (int)Hkv, (int)D, (int)seq_len, eps);
     return hipGetLastError();
 }
 
@@ -316,8 +502,16 @@ hipError_t launch_rope(const uint16_t* in, uint16_t* out, const uint16_t* cos_t,
 
 hipError_t launch_unary(int op, const uint16_t* in, uint16_t* out, size_t n, hipStream_t st) {
     const dim3 grid((unsigned)(((n + 7) / 8 + 255) / 256)), block(256);
-    if (op == OP_SILU) unary_kernel<OP_SILU><<<grid, block, 0, st>>>(in, out, n);
-    else if (op == OP_GELU) unary_kernel<OP_GELU><<<grid, block, 0, st>>>(in, out, n);
+    if (op == OP_SILU) unary_kernel<OP_SILU, false><<<grid, block, 0, st>>>(in, nullptr, out, n);
+    else if (op == OP_GELU) unary_kernel<OP_GELU, false><<<grid, block, 0, st>>>(in, nullptr, out, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_unary_mul(int op, const uint16_t* in, const uint16_t* mul, uint16_t* out, size_t n, hipStream_t st) {
+    const dim3 grid((unsigned)(((n + 7) / 8 + 255) / 256)), block(256);
+    if (op == OP_SILU) unary_kernel<OP_SILU, true><<<grid, block, 0, st>>>(in, mul, out, n);
+    else if (op == OP_GELU) unary_kernel<OP_GELU, true><<<grid, block, 0, st>>>(in, mul, out, n);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

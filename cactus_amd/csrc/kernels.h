@@ -17,6 +17,9 @@ hipError_t launch_fp16_to_int8(const uint16_t* src, int8_t* dst, size_t count, f
 hipError_t launch_max_abs(const uint16_t* src, size_t count, float* out, hipStream_t st);
 hipError_t launch_kv_quant(const uint16_t* src, int8_t* dst, float* scales, size_t seq, size_t heads,
                            size_t D, size_t gs, hipStream_t st);
+hipError_t launch_kv_quant_pair(const uint16_t* k_src, int8_t* k_dst, float* k_scales, const uint16_t* v_src,
+                                int8_t* v_dst, float* v_scales, size_t seq, size_t heads, size_t D, size_t gs,
+                                hipStream_t st);
 hipError_t launch_unpack_int4(const uint8_t* packed, int8_t* unpacked, size_t count, hipStream_t st);
 
 // matmul_skinny.hip: M <= 16, group_size == 128.  B is int8[N,K] or packed uint8[N,K/2].
@@ -95,6 +98,16 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 // block_ops.hip: the ops between the hot kernels of a decoder block
 hipError_t launch_rms_norm(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t rows, size_t dims, float eps,
                            hipStream_t st);
+// sum_out = a + b, y = rms_norm(sum_out, w): the residual add and the norm after it, one launch
+hipError_t launch_add_rms_norm(const uint16_t* a, const uint16_t* b, const uint16_t* w, uint16_t* sum_out,
+                               uint16_t* y, size_t rows, size_t dims, float eps, hipStream_t st);
+// per-head RMS norm of q [tokens, Hq, D] and k [tokens, Hkv, D], then RoPE of both, one launch
+hipError_t launch_qk_norm_rope(const uint16_t* q, const uint16_t* k, const uint16_t* qw, const uint16_t* kw,
+                               uint16_t* q_out, uint16_t* k_out, const uint16_t* cos_t, const uint16_t* sin_t,
+                               size_t tokens, size_t Hq, size_t Hkv, size_t D, size_t seq_len, float eps,
+                               hipStream_t st);
+hipError_t launch_unary_mul(int op, const uint16_t* in, const uint16_t* mul, uint16_t* out, size_t n,
+                            hipStream_t st);   // act(in) * mul
 // cos_t / sin_t: [seq][head_dim / 2] table rows for positions start_pos .. start_pos + seq - 1
 hipError_t launch_rope(const uint16_t* in, uint16_t* out, const uint16_t* cos_t, const uint16_t* sin_t,
                        size_t batch, size_t seq, size_t heads, size_t head_dim, hipStream_t st);

@@ -103,9 +103,14 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const uint16_t* __restrict
 
 // One 16-lane subgroup per (token*head, group) item; lane j owns elements 8j..8j+7 of each
 // 128-wide slice of the group.
+// blockIdx.y = 1 takes the second (src, dst, scales) set: K and V of a step in one launch.
 __global__ __launch_bounds__(256) void kv_quant_kernel(
-    const uint16_t* __restrict__ src, int8_t* __restrict__ dst, float* __restrict__ scales,
+    const uint16_t* __restrict__ src0, int8_t* __restrict__ dst0, float* __restrict__ scales0,
+    const uint16_t* __restrict__ src1, int8_t* __restrict__ dst1, float* __restrict__ scales1,
     size_t rows, size_t D, size_t gs, size_t G) {
+    const uint16_t* __restrict__ src = blockIdx.y ? src1 : src0;
+    int8_t* __restrict__ dst = blockIdx.y ? dst1 : dst0;
+    float* __restrict__ scales = blockIdx.y ? scales1 : scales0;
     const size_t item = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int j = threadIdx.x & 15;
     const bool live = item < rows * G;
@@ -209,8 +214,20 @@ hipError_t launch_kv_quant(const uint16_t* src, int8_t* dst, float* scales, size
     if (rows == 0 || D == 0) return hipSuccess;
     const size_t G = (D + gs - 1) / gs;
     const size_t items = rows * G;
-    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st>>>(src, dst, scales, rows,
-                                                                             D, gs, G);
+    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st>>>(src, dst, scales, nullptr, nullptr,
+                                                                             nullptr, rows, D, gs, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_kv_quant_pair(const uint16_t* k_src, int8_t* k_dst, float* k_scales, const uint16_t* v_src,
+                                int8_t* v_dst, float* v_scales, size_t seq, size_t heads, size_t D, size_t gs,
+                                hipStream_t st) {
+    const size_t rows = seq * heads;
+    if (rows == 0 || D == 0) return hipSuccess;
+    const size_t G = (D + gs - 1) / gs;
+    const size_t items = rows * G;
+    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(k_src, k_dst, k_scales, v_src, v_dst,
+                                                                                v_scales, rows, D, gs, G);
     return hipGetLastError();
 }
 

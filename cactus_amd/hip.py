@@ -71,6 +71,11 @@ SIGNATURES = {
     "cactus_hip_subtract_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_divide_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_add_rms_norm_f16_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _f, _vp]),
+    "cactus_hip_qk_norm_rope_f16_dev": (_i, [_vp] * 6 + [_sz] * 5 + [_f, _sz, _f, _vp]),
+    "cactus_hip_silu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_gelu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_quantize_kv_pair_fp16_to_int8_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp]),
     "cactus_hip_indices_to_int32_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
     "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "cactus_hip_embedding_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
@@ -246,6 +251,45 @@ def rms_norm(x, weight, eps=1e-5, out=None):
     o = out if out is not None else torch.empty_like(x)
     _check(lib.cactus_hip_rms_norm_f16_dev(_p(x), _p(weight), _p(o), rows, dims, float(eps), _stream()))
     return o
+
+
+def add_rms_norm(a, b, weight, eps=1e-5, out_sum=None, out_norm=None):
+    """(a + b, rms_norm(a + b, weight)) in one launch."""
+    _dev(a, torch.float16); _dev(b, torch.float16); _dev(weight, torch.float16)
+    rows, dims = a.shape
+    s = out_sum if out_sum is not None else torch.empty_like(a)
+    n = out_norm if out_norm is not None else torch.empty_like(a)
+    _check(lib.cactus_hip_add_rms_norm_f16_dev(_p(a), _p(b), _p(weight), _p(s), _p(n), rows, dims, float(eps),
+                                               _stream()))
+    return s, n
+
+
+def qk_norm_rope(q, k, q_weight, k_weight, eps, theta, start_pos=0, out_q=None, out_k=None):
+    """Per-head RMS norm then RoPE of q [batch, seq, Hq, D] and k [batch, seq, Hkv, D], one launch."""
+    _dev(q, torch.float16); _dev(k, torch.float16)
+    B, S, Hq, D = q.shape
+    Hkv = k.shape[2]
+    oq = out_q if out_q is not None else torch.empty_like(q)
+    ok = out_k if out_k is not None else torch.empty_like(k)
+    _check(lib.cactus_hip_qk_norm_rope_f16_dev(_p(q), _p(k), _p(q_weight), _p(k_weight), _p(oq), _p(ok), B, S, Hq,
+                                               Hkv, D, float(eps), start_pos, float(theta), _stream()))
+    return oq, ok
+
+
+def silu_multiply(gate, up, out=None):
+    return _binary(lib.cactus_hip_silu_multiply_f16_dev, gate, up, out)
+
+
+def gelu_multiply(gate, up, out=None):
+    return _binary(lib.cactus_hip_gelu_multiply_f16_dev, gate, up, out)
+
+
+def quantize_kv_pair(k, v, out_k, out_v, out_k_scales, out_v_scales, group_size=128):
+    """K and V [seq, kv_heads, head_dim] quantized in one launch into the given int8 / fp32 outputs."""
+    _dev(k, torch.float16); _dev(v, torch.float16)
+    S, Hh, D = k.shape
+    _check(lib.cactus_hip_quantize_kv_pair_fp16_to_int8_dev(_p(k), _p(v), _p(out_k), _p(out_v), _p(out_k_scales),
+                                                            _p(out_v_scales), S, Hh, D, group_size, _stream()))
 
 
 def rope(x, theta, start_pos=0, out=None):

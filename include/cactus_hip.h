@@ -147,6 +147,13 @@ int cactus_hip_quantize_kv_fp16_to_int8_dev(const cactus_half_t* src, int8_t* ds
                                             size_t seq_len, size_t kv_heads, size_t head_dim,
                                             size_t group_size, void* stream);
 
+/* K and V of one step in a single launch: two cactus_quantize_kv_fp16_to_int8 calls
+ * (engine_cache.cpp:253-263 makes them back to back); dst / scales may point into cache slots. */
+int cactus_hip_quantize_kv_pair_fp16_to_int8_dev(const cactus_half_t* k_src, const cactus_half_t* v_src,
+                                                 int8_t* k_dst, int8_t* v_dst, float* k_scales,
+                                                 float* v_scales, size_t seq_len, size_t kv_heads,
+                                                 size_t head_dim, size_t group_size, void* stream);
+
 /* cactus_unpack_int4_to_int8 (kernel.h:163; kernel_quants.cpp:295-351). */
 int cactus_hip_unpack_int4_to_int8_dev(const uint8_t* packed, int8_t* unpacked,
                                        size_t unpacked_count, void* stream);
@@ -183,6 +190,29 @@ int cactus_hip_add_f16_clipped_dev(const cactus_half_t* a, const cactus_half_t* 
 int cactus_hip_subtract_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
 int cactus_hip_multiply_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
 int cactus_hip_divide_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
+
+/* Sequences of the calls above that a decoder block makes back to back, in one launch each, with
+ * the arithmetic of the separate calls (results are bit-identical to making them one by one):
+ *   add_rms_norm    sum = cactus_add_f16(a, b); norm = cactus_rms_norm_f16(sum, weight)
+ *                   (model_qwen.cpp:125-126; :128 with the next block's :123)
+ *   qk_norm_rope    per-head cactus_rms_norm_f16 of q [batch*seq*Hq, D] and k [batch*seq*Hkv, D],
+ *                   then cactus_rope_f16 of both (model_qwen.cpp:63-81)
+ *   silu_multiply / gelu_multiply   cactus_multiply_f16(cactus_silu_f16(gate), up)
+ *                   (model_qwen.cpp:114-115; model_gemma.cpp uses gelu) */
+int cactus_hip_add_rms_norm_f16_dev(const cactus_half_t* a, const cactus_half_t* b,
+                                    const cactus_half_t* weight, cactus_half_t* sum_output,
+                                    cactus_half_t* norm_output, size_t batch_size, size_t dims, float eps,
+                                    void* stream);
+int cactus_hip_qk_norm_rope_f16_dev(const cactus_half_t* q, const cactus_half_t* k,
+                                    const cactus_half_t* q_weight, const cactus_half_t* k_weight,
+                                    cactus_half_t* q_output, cactus_half_t* k_output, size_t batch_size,
+                                    size_t seq_len, size_t num_q_heads, size_t num_kv_heads,
+                                    size_t head_dim, float eps, size_t start_pos, float theta,
+                                    void* stream);
+int cactus_hip_silu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                     cactus_half_t* output, size_t num_elements, void* stream);
+int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                     cactus_half_t* output, size_t num_elements, void* stream);
 
 /* compute_embedding_node (graph_ops_tensor.cpp:226-320): output row i = row indices[i] of the
  * table; INT8 rows with per-group fp16 scales dequantize as half(float(q) * float(scale))

@@ -40,7 +40,7 @@ def halves(rng, shape, scale=1.0):
 
 # ------------------------------------------------------------------------------ RMS norm
 @pytest.mark.parametrize("rows,dims", [(1, 1024), (7, 128), (3, 20), (5, 8), (49, 64), (2, 4096), (1, 7),
-                                       (33, 136), (4, 2560), (1, 8192)])
+                                       (33, 136), (4, 2560), (1, 8192), (3, 20000), (5, 16384), (19, 1023)])
 @pytest.mark.parametrize("eps", [1e-5, 1e-6])
 def test_rms_norm_bit_exact(H, rows, dims, eps):
     """kernel_attention.cpp:484-563: 16 fp32 lane accumulators, fp16 products, fp32 scalar tail."""
@@ -196,3 +196,57 @@ def test_host_pointer_forms_match_device_forms(H):
     assert np.array_equal(o.view(np.uint16), O.binary("multiply", a, b))
     H.lib.cactus_hip_add_f16_clipped(p(a), p(b), p(o), 40)
     assert np.array_equal(o.view(np.uint16), O.add_clipped(a, b))
+
+
+# ------------------------------------------------------------- sequences fused into one launch
+@pytest.mark.parametrize("rows,dims", [(1, 1024), (5, 136), (3, 20), (33, 2560), (2, 20000), (18, 1023)])
+def test_add_rms_norm_equals_the_two_calls(H, rows, dims):
+    """model_qwen.cpp:125-126: residual add, then the norm of the sum."""
+    rng = np.random.default_rng(rows + dims)
+    a, b = halves(rng, (rows, dims), 2.0), halves(rng, (rows, dims), 2.0)
+    w = (1.0 + 0.1 * rng.standard_normal(dims)).astype(np.float16)
+    s, n = H.add_rms_norm(dev(a), dev(b), dev(w), 1e-6)
+    want_s = O.binary("add", a, b)
+    assert np.array_equal(bits(s), want_s)
+    assert np.array_equal(bits(n), O.rms_norm(want_s, w, 1e-6))
+
+
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,start", [(1, 1, 16, 8, 128, 512), (1, 7, 4, 2, 64, 0), (2, 3, 2, 1, 20, 9),
+                                                (1, 300, 16, 8, 128, 100), (1, 1, 8, 4, 256, 3)])
+def test_qk_norm_rope_equals_the_four_calls(H, B, S, Hq, Hkv, D, start):
+    """model_qwen.cpp:63-81: per-head RMS norm of q and k, then RoPE of both."""
+    rng = np.random.default_rng(B + S + D)
+    q, k = halves(rng, (B, S, Hq, D), 3.0), halves(rng, (B, S, Hkv, D), 3.0)
+    qw = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float16)
+    kw = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float16)
+    oq, ok = H.qk_norm_rope(dev(q), dev(k), dev(qw), dev(kw), 1e-6, 1e6, start)
+    want_q = O.rope(O.rms_norm(q.reshape(-1, D), qw, 1e-6).reshape(q.shape), 1e6, start)
+    want_k = O.rope(O.rms_norm(k.reshape(-1, D), kw, 1e-6).reshape(k.shape), 1e6, start)
+    assert np.array_equal(bits(oq), want_q)
+    assert np.array_equal(bits(ok), want_k)
+
+
+@pytest.mark.parametrize("name", ["silu", "gelu"])
+@pytest.mark.parametrize("n", [3072, 13, 4096 * 5 + 3])
+def test_activation_multiply_equals_the_two_calls(H, name, n):
+    """model_qwen.cpp:114-115 (silu) and the Gemma MLP (gelu): activation, rounded, times up."""
+    rng = np.random.default_rng(n)
+    g, u = halves(rng, n, 3.0), halves(rng, n, 1.0)
+    got = bits(getattr(H, name + "_multiply")(dev(g), dev(u)))
+    act = bits(getattr(H, name)(dev(g)))                       # the device activation (tail: its own expf / tanhf)
+    assert np.array_equal(got, O.binary("multiply", act.view(np.float16), u))
+    vend = (n // 8) * 8
+    assert np.array_equal(got[:vend], O.binary("multiply", getattr(O, name)(g).view(np.float16), u)[:vend])
+
+
+def test_quantize_kv_pair_equals_two_calls(H):
+    """engine_cache.cpp:253-263: K then V, written straight into cache-slot views."""
+    rng = np.random.default_rng(4)
+    k, v = halves(rng, (3, 8, 128), 2.0), halves(rng, (3, 8, 128), 2.0)
+    kc = torch.zeros((10, 8, 128), dtype=torch.int8, device="cuda"); vc = torch.zeros_like(kc)
+    ks = torch.zeros((10, 8, 1), dtype=torch.float32, device="cuda"); vs = torch.zeros_like(ks)
+    H.quantize_kv_pair(dev(k), dev(v), kc[4:7], vc[4:7], ks[4:7], vs[4:7])
+    okq, oks = O.quantize_kv(k); ovq, ovs = O.quantize_kv(v)
+    assert np.array_equal(kc[4:7].cpu().numpy(), okq) and np.array_equal(vc[4:7].cpu().numpy(), ovq)
+    assert np.array_equal(ks[4:7].cpu().numpy(), oks) and np.array_equal(vs[4:7].cpu().numpy(), ovs)
+    assert not kc[:4].any() and not kc[7:].any()
