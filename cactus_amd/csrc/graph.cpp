@@ -3,6 +3,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstring>
 
@@ -248,6 +253,89 @@ void CactusGraph::set_packed_int4(size_t node_id, const void* packed, size_t pac
     b.packed_int4_size = packed_bytes;
     b.device_valid = true;
     is_weight_[node_id] = true;
+}
+
+CactHeader parse_cact_header(const void* bytes, size_t file_size) {   // graph_io.cpp:497-566
+    constexpr size_t HEADER_SIZE = 80;
+    if (file_size < HEADER_SIZE) throw std::runtime_error("File too small: insufficient data for header");
+    const char* p = static_cast<const char*>(bytes);
+    auto u32 = [&](size_t off) { uint32_t v; std::memcpy(&v, p + off, 4); return v; };
+    auto u64 = [&](size_t off) { uint64_t v; std::memcpy(&v, p + off, 8); return v; };
+    if (u32(0) != 0x54434143u) throw std::runtime_error("Invalid tensor file: missing CACT magic number");
+    CactHeader h;
+    h.version = u32(4);
+    h.alignment = u32(12) ? u32(12) : 1;
+    h.ndim = u32(16);
+    for (int i = 0; i < 4; i++) h.dims[i] = u64(20 + 8 * i);
+    h.precision = u32(52);
+    h.data_bytes = u64(56);
+    h.scales_bytes = u64(64);
+    h.group_size = u32(72);
+    h.num_groups = u32(76);
+    auto align = [&](uint64_t off) { const uint64_t r = off % h.alignment; return r ? off + (h.alignment - r) : off; };
+    const uint64_t aligned_header = align(HEADER_SIZE);
+    if (h.scales_bytes > 0) {
+        h.scales_offset = aligned_header;
+        h.data_offset = align(h.scales_offset + h.scales_bytes);
+    } else {
+        h.scales_offset = 0;
+        h.data_offset = aligned_header;
+    }
+    if (h.data_offset + h.data_bytes > file_size)
+        throw std::runtime_error("File corrupted: data extends beyond file size (v2)");
+    return h;
+}
+
+size_t CactusGraph::mmap_weights(const std::string& filename) {   // graph_io.cpp:48-72, 470-495
+    auto it = weight_cache_.find(filename);
+    if (it != weight_cache_.end()) return it->second;
+    const int fd = open(filename.c_str(), O_RDONLY);
+    if (fd == -1) throw std::runtime_error("Cannot open file for mapping: " + filename);
+    struct stat st;
+    if (fstat(fd, &st) == -1) { close(fd); throw std::runtime_error("Cannot get file size: " + filename); }
+    const size_t file_size = (size_t)st.st_size;
+    void* map = mmap(nullptr, file_size ? file_size : 1, PROT_READ, MAP_SHARED, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) throw std::runtime_error("Cannot map file: " + filename);
+    struct Unmap { void* p; size_t n; ~Unmap() { munmap(p, n ? n : 1); } } unmap{map, file_size};
+    const CactHeader h = parse_cact_header(map, file_size);
+    std::vector<size_t> shape;
+    for (uint32_t i = 0; i < 4; i++)
+        if (i < h.ndim && h.dims[i] > 0) shape.push_back((size_t)h.dims[i]);
+    if (h.precision > 3) throw std::runtime_error("Unknown precision in tensor file: " + filename);
+    const bool int4 = h.precision == (uint32_t)Precision::INT4;
+    const Precision prec = int4 ? Precision::INT8 : static_cast<Precision>(h.precision);   // effective_precision()
+    const size_t id = input(shape, prec);
+    BufferDesc& b = node(id).output_buffer;
+    const char* base = static_cast<const char*>(map);
+    void* dev = dev_alloc(h.data_bytes);
+    hip_check(hipMemcpy(dev, base + h.data_offset, h.data_bytes, hipMemcpyHostToDevice), "hipMemcpy H2D (weights)");
+    if (int4) {
+        b.packed_int4_device = dev;
+        b.packed_int4_size = h.data_bytes;
+        b.owns_packed = true;
+    } else {
+        if (h.data_bytes < b.byte_size) {
+            (void)hipFree(dev);
+            throw std::runtime_error("File corrupted: payload smaller than the tensor: " + filename);
+        }
+        b.device_data = dev;
+        b.owns_device = true;
+    }
+    b.device_valid = true;
+    if (h.group_size > 0 && h.scales_bytes > 0 && (int4 || prec == Precision::INT8)) {
+        if (shape.empty() || h.scales_bytes < shape[0] * (size_t)h.num_groups * sizeof(uint16_t))
+            throw std::runtime_error("File corrupted: group scales smaller than [rows, groups]: " + filename);
+        b.group_size = h.group_size;
+        b.num_groups = h.num_groups;
+        b.scales_device = dev_alloc(h.scales_bytes);
+        b.owns_scales = true;
+        hip_check(hipMemcpy(b.scales_device, base + h.scales_offset, h.scales_bytes, hipMemcpyHostToDevice),
+                  "hipMemcpy H2D (scales)");
+    }
+    is_weight_[id] = true;
+    weight_cache_[filename] = id;
+    return id;
 }
 
 // graph_ops_nn.cpp:129-231
@@ -584,6 +672,10 @@ static void free_node(GraphNode& n) {
     BufferDesc& b = n.output_buffer;
     if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
     if (b.activation_scales_device) (void)hipFree(b.activation_scales_device);
+    if (b.owns_scales && b.scales_device) (void)hipFree(b.scales_device);
+    if (b.owns_packed && b.packed_int4_device) (void)hipFree(b.packed_int4_device);
+    b.scales_device = nullptr;
+    b.packed_int4_device = nullptr;
     b.device_data = nullptr;
     b.activation_scales_device = nullptr;
 }
@@ -607,6 +699,7 @@ void CactusGraph::hard_reset() {
     nodes_.clear();
     node_index_map_.clear();
     is_weight_.clear();
+    weight_cache_.clear();
     for (auto& kv : resident_) (void)hipFree(kv.second.dev);
     resident_.clear();
     for (auto& kv : quant_cache_)
@@ -893,6 +986,34 @@ long cactus_hip_graph_rms_norm(void* g, size_t input, size_t weight, float epsil
 }
 long cactus_hip_graph_rope(void* g, size_t input, float theta, size_t position_offset) {
     return guarded<long>(-1, [&] { return (long)G_(g)->rope(input, theta, position_offset); });
+}
+long cactus_hip_graph_mmap_weights(void* g, const char* filename) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->mmap_weights(filename ? filename : ""); });
+}
+int cactus_hip_graph_node_info(void* g, size_t node, size_t* shape4, size_t* ndim, int* precision, size_t* group_size,
+                               size_t* num_groups, int* packed_int4) {
+    return guarded<int>(-1, [&] {
+        const cactus_hip::BufferDesc& b = G_(g)->get_output_buffer(node);
+        if (b.shape.size() > 4) throw std::runtime_error("node has more than 4 dimensions");
+        for (size_t i = 0; i < b.shape.size(); i++) shape4[i] = b.shape[i];
+        *ndim = b.shape.size();
+        *precision = (int)b.precision;
+        *group_size = b.group_size;
+        *num_groups = b.num_groups;
+        *packed_int4 = b.is_packed_int4() ? 1 : 0;
+        return 0;
+    });
+}
+int cactus_hip_cact_parse_header(const void* bytes, size_t size, uint64_t* out12) {   // 14 values, see the header
+    return guarded<int>(-1, [&] {
+        const cactus_hip::CactHeader h = cactus_hip::parse_cact_header(bytes, size);
+        const uint64_t v[12] = {h.version, h.alignment, h.ndim, h.dims[0], h.dims[1], h.dims[2], h.dims[3], h.precision,
+                                h.data_bytes, h.scales_bytes, h.group_size, h.num_groups};
+        for (int i = 0; i < 12; i++) out12[i] = v[i];
+        out12[12] = h.scales_offset;
+        out12[13] = h.data_offset;
+        return 0;
+    });
 }
 int cactus_hip_graph_set_input(void* g, size_t node, const void* data, int precision) {
     return guarded<int>(-1, [&] { G_(g)->set_input(node, data, static_cast<Precision>(precision)); return 0; });

@@ -54,6 +54,7 @@ struct BufferDesc {
     bool owns_scales = false;
     void* packed_int4_device = nullptr;   // uint8 [N, K/2]
     size_t packed_int4_size = 0;
+    bool owns_packed = false;
 
     // per-row activation scales of a QUANTIZE_ACTIVATIONS output (graph.h:211-213)
     void* activation_scales_device = nullptr;
@@ -144,6 +145,12 @@ public:
     // MappedFile::load_into_graph sets (graph_io.cpp:470-495), kept packed on the device.
     void set_packed_int4(size_t node_id, const void* packed, size_t packed_bytes);
 
+    // A CACT tensor file (graph_io.cpp:48-72, 470-566; written by python/src/tensor_io.py) as a
+    // weight node: header parsed as the reference parses it, payload and group scales copied to
+    // HBM once (INT4 stays packed) and owned by the node, the file unmapped again.  One node per
+    // file name (the reference's weight_cache_).
+    size_t mmap_weights(const std::string& filename);
+
     void execute();
     void* get_output(size_t node_id);          // host copy, synchronises
     void* get_device_output(size_t node_id);   // device pointer, no synchronisation
@@ -182,9 +189,23 @@ private:
     // activation quantization shared by the matmuls that read one FP16 node (keyed by node id)
     struct QuantCache { void* q = nullptr; void* scales = nullptr; size_t M = 0, K = 0; };
     std::unordered_map<size_t, QuantCache> quant_cache_;
+    std::unordered_map<std::string, size_t> weight_cache_;   // file name -> node id
     int32_t* index_scratch_ = nullptr;   // int32 copy of an EMBEDDING node's indices + one flag word
     size_t index_scratch_count_ = 0;
 };
+
+// Header of a CACT tensor file (graph_io.cpp:11-16, 497-566): 80 bytes, little endian: magic
+// "CACT"@0, version@4, flags@8, alignment@12, ndim@16, dims 4 x u64@20, precision@52,
+// data bytes@56, scales bytes@64, group size@72, group count@76; the header is padded to
+// `alignment`, the fp16 scales follow, then the payload at the next multiple of `alignment`.
+struct CactHeader {
+    uint32_t version = 0, alignment = 1, ndim = 0, precision = 0, group_size = 0, num_groups = 0;
+    uint64_t dims[4] = {0, 0, 0, 0};
+    uint64_t data_bytes = 0, scales_bytes = 0;
+    uint64_t scales_offset = 0, data_offset = 0;   // derived
+};
+// Throws std::runtime_error with the reference's messages (graph_io.cpp:498-500, 507-509, 561-563).
+CactHeader parse_cact_header(const void* bytes, size_t file_size);
 
 // INT8 KV cache resident in HBM: per layer keys/values int8 [slot, Hkv, D] and fp32 scales
 // [slot, Hkv, ceil(D/128)], slots 0..sink-1 = first tokens, the rest = most recent tokens

@@ -28,6 +28,9 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_embedding": (_l, [_vp, _sz, _sz]),
     "cactus_hip_graph_rms_norm": (_l, [_vp, _sz, _sz, _f]),
     "cactus_hip_graph_rope": (_l, [_vp, _sz, _f, _sz]),
+    "cactus_hip_graph_mmap_weights": (_l, [_vp, C.c_char_p]),
+    "cactus_hip_graph_node_info": (_i, [_vp, _sz, _szp, _szp, C.POINTER(C.c_int), _szp, _szp, C.POINTER(C.c_int)]),
+    "cactus_hip_cact_parse_header": (_i, [_vp, _sz, C.POINTER(C.c_uint64)]),
     "cactus_hip_graph_set_input": (_i, [_vp, _sz, _vp, _i]),
     "cactus_hip_graph_set_external_input": (_i, [_vp, _sz, _vp, _i]),
     "cactus_hip_graph_set_grouped_scales": (_i, [_vp, _sz, _sz, _sz, _vp]),
@@ -151,6 +154,22 @@ class CactusGraph:
     def rope(self, x, theta, position_offset=0):
         return self._same(_node(lib.cactus_hip_graph_rope(self._g, x, theta, position_offset)), x)
 
+    def mmap_weights(self, filename):
+        """A CACT tensor file as a weight node; returns the node id (shape / precision via node_info)."""
+        n = _node(lib.cactus_hip_graph_mmap_weights(self._g, str(filename).encode()))
+        info = self.node_info(n)
+        self._shapes[n] = (info["shape"], info["precision"])
+        return n
+
+    def node_info(self, n):
+        shape = (C.c_size_t * 4)()
+        ndim, gs, ng = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        prec, packed = C.c_int(), C.c_int()
+        _ok(lib.cactus_hip_graph_node_info(self._g, n, shape, C.byref(ndim), C.byref(prec), C.byref(gs), C.byref(ng),
+                                           C.byref(packed)))
+        return {"shape": tuple(shape[i] for i in range(ndim.value)), "precision": prec.value,
+                "group_size": gs.value, "num_groups": ng.value, "packed_int4": bool(packed.value)}
+
     def attention(self, q, k, v, scale, position_offset=0, window_size=0, is_causal=True):
         n = _node(lib.cactus_hip_graph_attention(self._g, q, k, v, scale, position_offset, window_size,
                                                  int(is_causal)))
@@ -205,6 +224,16 @@ class CactusGraph:
 
     def get_node_count(self):
         return lib.cactus_hip_graph_node_count(self._g)
+
+
+def parse_cact_header(data):
+    """MappedFile::parse_header on a bytes-like object (no GPU needed)."""
+    buf = bytes(data)
+    out = (C.c_uint64 * 14)()
+    _ok(lib.cactus_hip_cact_parse_header(buf, len(buf), out))
+    keys = ("version", "alignment", "ndim", "d0", "d1", "d2", "d3", "precision", "data_bytes", "scales_bytes",
+            "group_size", "num_groups", "scales_offset", "data_offset")
+    return dict(zip(keys, [int(v) for v in out]))
 
 
 class KVCache:

@@ -52,6 +52,16 @@ long   cactus_hip_graph_reshape(void* graph, size_t input, const size_t* shape, 
 long   cactus_hip_graph_embedding(void* graph, size_t table, size_t indices);
 long   cactus_hip_graph_rms_norm(void* graph, size_t input, size_t weight, float epsilon);
 long   cactus_hip_graph_rope(void* graph, size_t input, float theta, size_t position_offset);
+/* CactusGraph::mmap_weights (graph.h:435; graph_io.cpp:48-72): a CACT tensor file becomes a weight
+ * node (payload and group scales copied to HBM once, INT4 kept packed); the same file name gives
+ * the same node.  node_info reports what was loaded (shape4: room for 4 dims). */
+long   cactus_hip_graph_mmap_weights(void* graph, const char* filename);
+int    cactus_hip_graph_node_info(void* graph, size_t node, size_t* shape4, size_t* ndim, int* precision,
+                                  size_t* group_size, size_t* num_groups, int* packed_int4);
+/* MappedFile::parse_header (graph_io.cpp:497-566) on a byte buffer, no GPU involved.  out14 =
+ * version, alignment, ndim, dims[4], precision, data_bytes, scales_bytes, group_size, num_groups,
+ * scales_offset, data_offset.  -1 + cactus_hip_last_error() on the reference's error conditions. */
+int    cactus_hip_cact_parse_header(const void* bytes, size_t size, uint64_t* out14);
 int    cactus_hip_graph_set_input(void* graph, size_t node, const void* host_data, int precision);
 int    cactus_hip_graph_set_external_input(void* graph, size_t node, void* host_data, int precision);
 int    cactus_hip_graph_set_grouped_scales(void* graph, size_t node, size_t group_size, size_t num_groups,

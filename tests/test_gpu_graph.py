@@ -464,3 +464,62 @@ def test_appended_chunk_larger_than_window_is_rejected(G):
     assert cache.get_effective_seq_len() == 4 and cache.get_total_seq_len() == 4
     g.close()
     cache.close()
+
+
+# ------------------------------------------------------------------------- weight files
+@pytest.mark.parametrize("name", ["tensor_io_a.npz", "tensor_io_b.npz", "tensor_io_pad.npz"])
+@pytest.mark.parametrize("kind", ["file_int8", "file_int4", "file_fp16"])
+def test_mmap_weights_of_reference_written_files(G, name, kind, tmp_path):
+    """graph_io.cpp:48-72, 470-566: a file written by the reference's python/src/tensor_io.py
+    (tests/golden holds the file bytes) becomes a weight node, and a matmul against it equals the
+    oracle on the payload an independent parser extracts."""
+    import os
+    from tests.helpers import parse_cact
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", name))
+    raw = d[kind].tobytes()
+    path = tmp_path / (kind + ".weights")
+    path.write_bytes(raw)
+    ref = parse_cact(raw)
+    N, K = ref["shape"]
+    g = G.CactusGraph()
+    w = g.mmap_weights(path)
+    assert g.mmap_weights(path) == w                       # one node per file name
+    info = g.node_info(w)
+    assert info["shape"] == (N, K)
+    assert info["packed_int4"] == (kind == "file_int4")
+    assert info["precision"] == (G.FP16 if kind == "file_fp16" else G.INT8)
+    rng = np.random.default_rng(N + K)
+    M = 3
+    x = rand_act_f16(rng, M, K)
+    xin = g.input((M, K), G.FP16)
+    y = g.matmul(xin, w, True)
+    g.set_input(xin, x)
+    g.execute()
+    got = u16(g.get_output(y))
+    if kind == "file_fp16":
+        want = O.matmul_f16(x, ref["data"].view(np.uint16).reshape(N, K))
+        gf, wf = got.view(np.float16).astype(np.float64), want.view(np.float16).astype(np.float64)
+        assert np.abs(gf - wf).max() <= 2e-2 * max(1.0, np.abs(wf).max())
+    else:
+        assert info["group_size"] == 128 and info["num_groups"] == K // 128
+        q, s = O.quantize_activations(x)
+        Bs = ref["scales"].view(np.uint16).reshape(N, K // 128)
+        if kind == "file_int4":
+            want = O.matmul_int4(q, s, ref["data"].reshape(N, K // 2), Bs, 128)
+        else:
+            want = O.matmul_int8(q, s, ref["data"].view(np.int8).reshape(N, K), Bs, 128)
+        assert (got == want).all()
+    g.soft_reset()                                          # weights loaded from files survive
+    assert g.node_info(w)["shape"] == (N, K)
+    g.close()
+
+
+def test_mmap_weights_errors(G, tmp_path):
+    g = G.CactusGraph()
+    with pytest.raises(G.CactusHipError, match="Cannot open file for mapping"):
+        g.mmap_weights(tmp_path / "missing.weights")
+    bad = tmp_path / "bad.weights"
+    bad.write_bytes(b"NOPE" + bytes(200))
+    with pytest.raises(G.CactusHipError, match="missing CACT magic"):
+        g.mmap_weights(bad)
+    g.close()
