@@ -535,6 +535,20 @@ int cactus_hip_add_f16_clipped_dev(const cactus_half_t* a, const cactus_half_t* 
     return binary_dev(4, "add_clipped: null operand or launch failure", a, b, out, n, stream);
 }
 
+int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows, size_t vocab_size,
+                                     void* stream) {
+    if (rows == 0) return CACTUS_HIP_OK;
+    if (!logits || !output) return fail(CACTUS_HIP_EINVAL, "sample_greedy: null operand");
+    if (vocab_size == 0) {   // kernel_nn.cpp:452-455: token 0
+        HIP_TRY(hipMemsetAsync(output, 0, rows * sizeof(uint32_t), S(stream)));
+        return CACTUS_HIP_OK;
+    }
+    if (rows > 0x7FFFFFFFull) return fail(CACTUS_HIP_EINVAL, "sample_greedy: too many rows");
+    hipError_t e = launch_argmax(logits, output, rows, vocab_size, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "sample_greedy launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_indices_to_int32_dev(const void* indices, int precision, int32_t* output, size_t count, void* stream) {
     if (count == 0) return CACTUS_HIP_OK;
     if (!indices || !output) return fail(CACTUS_HIP_EINVAL, "indices_to_int32: null operand");

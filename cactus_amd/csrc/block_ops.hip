@@ -446,7 +446,46 @@ __global__ __launch_bounds__(256) void indices_to_i32_kernel(const void* __restr
     }
 }
 
+// Greedy branch of cactus_sample_f16 (kernel_nn.cpp:450-466): the first index whose value is
+// strictly greater than every earlier one, starting from element 0 -- so ties go to the lowest
+// index, NaNs are never chosen, and a NaN in element 0 keeps index 0.  One workgroup per row.
+__global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* __restrict__ logits, uint32_t* __restrict__ out,
+                                                      size_t vocab) {
+    __shared__ float s_val[16];
+    __shared__ uint32_t s_idx[16];
+    const uint16_t* row = logits + (size_t)blockIdx.x * vocab;
+    const float first = h2f(row[0]);
+    float best = first;
+    uint32_t bi = 0;
+    if (first == first) {   // not NaN
+        for (size_t i = threadIdx.x; i < vocab; i += 1024) {
+            const float v = h2f(row[i]);
+            if (v > best) { best = v; bi = (uint32_t)i; }   // per thread i increases: first maximum kept
+        }
+    }
+    auto better = [](float v, uint32_t i, float bv, uint32_t bidx) { return v > bv || (v == bv && i < bidx); };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const uint32_t oi = __shfl_xor(bi, o);
+        if (better(ov, oi, best, bi)) { best = ov; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (better(s_val[w], s_idx[w], best, bi)) { best = s_val[w]; bi = s_idx[w]; }
+        out[blockIdx.x] = bi;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab, hipStream_t st) {
+    argmax_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, out, vocab);
+    return hipGetLastError();
+}
 
 hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, size_t n, hipStream_t st) {
     indices_to_i32_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, is_f32 ? 1 : 0, dst, n);

@@ -117,6 +117,7 @@ hipError_t launch_binary(int op, const uint16_t* a, const uint16_t* b, uint16_t*
 hipError_t launch_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices, uint16_t* out,
                                  size_t num_indices, size_t vocab, size_t hidden, size_t group_size, int* bad,
                                  hipStream_t st);
+hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab, hipStream_t st);
 hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, size_t n, hipStream_t st);
 hipError_t launch_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out, size_t num_indices,
                                 size_t vocab, size_t hidden, int* bad, hipStream_t st);

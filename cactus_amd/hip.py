@@ -76,6 +76,7 @@ SIGNATURES = {
     "cactus_hip_silu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_gelu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_quantize_kv_pair_fp16_to_int8_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp]),
+    "cactus_hip_sample_greedy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "cactus_hip_indices_to_int32_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
     "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "cactus_hip_embedding_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
@@ -346,6 +347,15 @@ def multiply(a, b, out=None):
 
 def divide(a, b, out=None):
     return _binary(lib.cactus_hip_divide_f16_dev, a, b, out)
+
+
+def sample_greedy(logits, out=None):
+    """First index of the row maximum of fp16 [rows, vocab] -> int32 [rows] (the greedy sampler)."""
+    _dev(logits, torch.float16)
+    rows, vocab = logits.shape
+    o = out if out is not None else torch.empty((rows,), dtype=torch.int32, device=logits.device)
+    _check(lib.cactus_hip_sample_greedy_f16_dev(_p(logits), _p(o), rows, vocab, _stream()))
+    return o
 
 
 def embedding(table, indices, scales=None, group_size=128, out=None):

@@ -219,6 +219,13 @@ int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_hal
  * (:243-254), FP16 rows are copied (:301-316).  indices: device int32[num_indices].  An index
  * outside [0, vocab_size) writes nothing for that row and stores 1 to *bad_index_flag (device
  * int, may be NULL; the caller clears it) -- the reference throws there (:261-263). */
+/* The greedy branch of cactus_sample_f16 (kernel.h; kernel_nn.cpp:446-466: temperature 0, no
+ * top-p / top-k): output[r] = first index of the maximum of logits[r, :] (NaNs never win; a NaN
+ * in element 0 gives 0; vocab_size 0 gives 0).  The stochastic branches (:468-651: host RNG,
+ * process-wide token history) are not provided. */
+int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows,
+                                     size_t vocab_size, void* stream);
+
 /* The index conversion of compute_embedding_node (graph_ops_tensor.cpp:257-275: indices held as
  * FP32 or INT8 values, `static_cast<size_t>(indices[i])`): precision 2 = float, 0 = int8; values
  * that are not a valid index (negative, NaN) become -1. */

@@ -55,6 +55,8 @@ def _load():
     lib.oracle_embedding_int8.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz]
     lib.oracle_embedding_f16.restype = C.c_int
     lib.oracle_embedding_f16.argtypes = [vp, vp, vp, sz, sz, sz]
+    lib.oracle_sample_greedy_f16.restype = C.c_uint32
+    lib.oracle_sample_greedy_f16.argtypes = [vp, sz]
     return lib
 
 
@@ -250,3 +252,9 @@ def embedding(table, indices, scales=None, group_size=128):
     if rc != 0:
         raise IndexError("Embedding index out of bounds")
     return out
+
+
+def sample_greedy(logits):
+    logits = _c(logits, np.uint16)
+    return np.array([lib.oracle_sample_greedy_f16(_p(r), r.size) for r in logits.reshape(-1, logits.shape[-1])],
+                    np.uint32)

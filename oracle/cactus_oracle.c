@@ -809,3 +809,15 @@ int oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* 
     }
     return 0;
 }
+
+/* Greedy branch of cactus_sample_f16: cactus/kernel/kernel_nn.cpp:450-466 */
+uint32_t oracle_sample_greedy_f16(const uint16_t* logits, size_t vocab_size) {
+    if (vocab_size == 0) return 0;
+    size_t best_idx = 0;
+    float best_val = oracle_h2f(logits[0]);
+    for (size_t i = 1; i < vocab_size; i++) {
+        const float val = oracle_h2f(logits[i]);
+        if (val > best_val) { best_val = val; best_idx = i; }
+    }
+    return (uint32_t)best_idx;
+}

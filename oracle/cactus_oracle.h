@@ -105,6 +105,7 @@ void oracle_add_f16_clipped(const uint16_t* a, const uint16_t* b, uint16_t* out,
 int  oracle_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices,
                            uint16_t* out, size_t num_indices, size_t vocab_size, size_t hidden_dim,
                            size_t group_size);
+uint32_t oracle_sample_greedy_f16(const uint16_t* logits, size_t vocab_size);
 int  oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out,
                           size_t num_indices, size_t vocab_size, size_t hidden_dim);
 

@@ -250,3 +250,25 @@ def test_quantize_kv_pair_equals_two_calls(H):
     assert np.array_equal(kc[4:7].cpu().numpy(), okq) and np.array_equal(vc[4:7].cpu().numpy(), ovq)
     assert np.array_equal(ks[4:7].cpu().numpy(), oks) and np.array_equal(vs[4:7].cpu().numpy(), ovs)
     assert not kc[:4].any() and not kc[7:].any()
+
+
+# --------------------------------------------------------------------------- greedy sampler
+@pytest.mark.parametrize("rows,vocab", [(1, 151936), (3, 1000), (5, 1), (2, 1025), (256, 4096)])
+def test_sample_greedy_first_maximum(H, rows, vocab):
+    """kernel_nn.cpp:450-466: strict '>' scan from element 0 -- ties to the lowest index."""
+    rng = np.random.default_rng(rows + vocab)
+    x = halves(rng, (rows, vocab), 3.0)
+    if vocab >= 1000:
+        x[0, 700] = x[0, 77] = np.float16(60000.0)         # tie: index 77 wins
+        x[-1, 5] = np.float16(np.nan)                      # NaNs are never greater
+        if rows > 1:
+            x[1, :] = np.float16(-np.inf)                  # nothing exceeds element 0
+    got = H.sample_greedy(dev(x)).cpu().numpy().astype(np.uint32)
+    assert np.array_equal(got, O.sample_greedy(x))
+    if vocab >= 1000:
+        assert got[0] == 77
+
+
+def test_sample_greedy_nan_first_element(H):
+    x = np.array([[np.nan, 5.0, 7.0, 1.0]], np.float16)
+    assert H.sample_greedy(dev(x)).cpu().tolist() == [0] and O.sample_greedy(x).tolist() == [0]
