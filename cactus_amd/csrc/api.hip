@@ -314,6 +314,20 @@ int cactus_hip_quantize_kv_pair_fp16_to_int8_dev(const cactus_half_t* k_src, con
     return CACTUS_HIP_OK;
 }
 
+int cactus_hip_kv_append_batched_dev(const cactus_half_t* k_new, const cactus_half_t* v_new, int8_t* k_cache,
+                                     int8_t* v_cache, float* k_scales, float* v_scales, size_t batch_size,
+                                     size_t kv_heads, size_t head_dim, size_t group_size, const int32_t* slots,
+                                     size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+                                     void* stream) {
+    if (batch_size * kv_heads * head_dim == 0) return CACTUS_HIP_OK;
+    if (!k_new || !v_new || !k_cache || !v_cache || !k_scales || !v_scales || !slots || group_size == 0)
+        return fail(CACTUS_HIP_EINVAL, "kv_append: bad operand");
+    hipError_t e = launch_kv_append(k_new, k_cache, k_scales, v_new, v_cache, v_scales, batch_size, kv_heads, head_dim,
+                                    group_size, slots, cache_batch_stride, scale_batch_stride, max_slots, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "kv_append launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_unpack_int4_to_int8_dev(const uint8_t* packed, int8_t* unpacked, size_t unpacked_count,
                                        void* stream) {
     if (unpacked_count == 0) return CACTUS_HIP_OK;
@@ -544,7 +558,28 @@ int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* outp
         return CACTUS_HIP_OK;
     }
     if (rows > 0x7FFFFFFFull) return fail(CACTUS_HIP_EINVAL, "sample_greedy: too many rows");
-    hipError_t e = launch_argmax(logits, output, rows, vocab_size, S(stream));
+    // 64 rows x 2 zeroed words per device for the split form (long rows, few of them); calls that
+    // overlap on one device must share a stream, as with the attention workspace
+    static std::mutex mu;
+    static std::unordered_map<int, unsigned long long*> scratch;
+    unsigned long long* sc = nullptr;
+    {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = scratch.find(dev);
+        if (it == scratch.end()) {
+            unsigned long long* p = nullptr;
+            if (hipMalloc(&p, 128 * sizeof(unsigned long long)) == hipSuccess &&
+                hipMemset(p, 0, 128 * sizeof(unsigned long long)) == hipSuccess)
+                scratch[dev] = p;
+            else
+                scratch[dev] = nullptr;
+            it = scratch.find(dev);
+        }
+        sc = it->second;
+    }
+    hipError_t e = launch_argmax(logits, output, rows, vocab_size, sc, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "sample_greedy launch", e);
     return CACTUS_HIP_OK;
 }

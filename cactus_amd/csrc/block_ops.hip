@@ -480,10 +480,66 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* __restrict
     }
 }
 
+// The same rule with a row spread over several workgroups (long rows, few of them).  A candidate
+// is packed as (order-preserving key of the value) << 32 | (0xFFFFFFFF - index), so a 64-bit max
+// prefers the larger value and, between equals, the lower index.  scratch[row] = {best, arrivals},
+// all zero between launches: the workgroup that arrives last decodes the winner, stores it and
+// zeroes the two words again.  A NaN in element 0 makes every workgroup contribute nothing: 0.
+__global__ __launch_bounds__(256) void argmax_split_kernel(const uint16_t* __restrict__ logits,
+                                                           uint32_t* __restrict__ out, size_t vocab,
+                                                           unsigned long long* __restrict__ scratch, int chunk) {
+    __shared__ unsigned long long s_best[4];
+    const size_t r = blockIdx.y;
+    const uint16_t* row = logits + r * vocab;
+    const float first = h2f(row[0]);
+    unsigned long long best = 0;
+    if (first == first) {
+        const size_t lo = (size_t)blockIdx.x * chunk, hi = min(vocab, lo + (size_t)chunk);
+        for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = h2f(row[i]);
+            if (v == v) {
+                const uint32_t b = __builtin_bit_cast(uint32_t, v);
+                const uint32_t key = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // -0 < +0 here; both are
+                const uint32_t keyz = (v == 0.0f) ? 0x80000000u : key;              // "equal" to the reference
+                const unsigned long long c = ((unsigned long long)keyz << 32) | (0xFFFFFFFFu - (uint32_t)i);
+                best = c > best ? c : best;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long ov = __shfl_xor(best, o);
+        best = ov > best ? ov : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) best = s_best[w] > best ? s_best[w] : best;
+        unsigned long long* slot = scratch + 2 * r;
+        if (best) atomicMax(slot, best);
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(slot + 1, 1ull) + 1;
+        if (arrived == gridDim.x) {
+            __threadfence();
+            const unsigned long long win = atomicExch(slot, 0ull);
+            atomicExch(slot + 1, 0ull);
+            out[r] = win ? 0xFFFFFFFFu - (uint32_t)(win & 0xFFFFFFFFull) : 0u;
+        }
+    }
+}
+
 }  // namespace
 
-hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab, hipStream_t st) {
-    argmax_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, out, vocab);
+// scratch: 2 zeroed 64-bit words per row (nullptr: one workgroup per row)
+hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab,
+                         unsigned long long* scratch, hipStream_t st) {
+    if (scratch != nullptr && vocab >= 16384 && rows <= 64) {
+        const int chunk = 4096;
+        argmax_split_kernel<<<dim3((unsigned)((vocab + chunk - 1) / chunk), (unsigned)rows), dim3(256), 0, st>>>(
+            logits, out, vocab, scratch, chunk);
+    } else {
+        argmax_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, out, vocab);
+    }
     return hipGetLastError();
 }
 

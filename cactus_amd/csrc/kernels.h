@@ -20,6 +20,11 @@ hipError_t launch_kv_quant(const uint16_t* src, int8_t* dst, float* scales, size
 hipError_t launch_kv_quant_pair(const uint16_t* k_src, int8_t* k_dst, float* k_scales, const uint16_t* v_src,
                                 int8_t* v_dst, float* v_scales, size_t seq, size_t heads, size_t D, size_t gs,
                                 hipStream_t st);
+// one new token per sequence, K and V, quantized straight into slot slots[b] of each sequence's cache
+hipError_t launch_kv_append(const uint16_t* k_src, int8_t* k_cache, float* k_scales, const uint16_t* v_src,
+                            int8_t* v_cache, float* v_scales, size_t batch, size_t heads, size_t D, size_t gs,
+                            const int32_t* slots, size_t cache_batch_stride, size_t scale_batch_stride,
+                            size_t max_slots, hipStream_t st);
 hipError_t launch_unpack_int4(const uint8_t* packed, int8_t* unpacked, size_t count, hipStream_t st);
 
 // matmul_skinny.hip: M <= 16, group_size == 128.  B is int8[N,K] or packed uint8[N,K/2].
@@ -117,7 +122,8 @@ hipError_t launch_binary(int op, const uint16_t* a, const uint16_t* b, uint16_t*
 hipError_t launch_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices, uint16_t* out,
                                  size_t num_indices, size_t vocab, size_t hidden, size_t group_size, int* bad,
                                  hipStream_t st);
-hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab, hipStream_t st);
+hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab,
+                         unsigned long long* scratch, hipStream_t st);
 hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, size_t n, hipStream_t st);
 hipError_t launch_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out, size_t num_indices,
                                 size_t vocab, size_t hidden, int* bad, hipStream_t st);

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const uint16_t* __restrict
 __global__ __launch_bounds__(256) void kv_quant_kernel(
     const uint16_t* __restrict__ src0, int8_t* __restrict__ dst0, float* __restrict__ scales0,
     const uint16_t* __restrict__ src1, int8_t* __restrict__ dst1, float* __restrict__ scales1,
-    size_t rows, size_t D, size_t gs, size_t G) {
+    size_t rows, size_t D, size_t gs, size_t G, const int32_t* __restrict__ slots, size_t heads,
+    size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots) {
     const uint16_t* __restrict__ src = blockIdx.y ? src1 : src0;
     int8_t* __restrict__ dst = blockIdx.y ? dst1 : dst0;
     float* __restrict__ scales = blockIdx.y ? scales1 : scales0;
@@ -119,9 +120,21 @@ __global__ __launch_bounds__(256) void kv_quant_kernel(
     const size_t cnt = live ? ((D - start < gs) ? D - start : gs) : 0;
     const size_t cnt8 = (cnt / 8) * 8;
     const uint16_t* s = src + row * D + start;
-    int8_t* d = dst + row * D + start;
+    // Destination: row for row, or (append form) source row (b, h) -> slot slots[b] of sequence
+    // b's cache; a slot outside [0, max_slots) stores nothing.
+    size_t doff = row * D + start, soff = row * G;
+    bool place = true;
+    if (slots != nullptr && live) {
+        const size_t b = row / heads, h = row - b * heads;
+        const long sl = slots[b];
+        place = sl >= 0 && (size_t)sl < max_slots;
+        const size_t slot = place ? (size_t)sl : 0;
+        doff = b * cache_batch_stride + (slot * heads + h) * D + start;
+        soff = b * scale_batch_stride + (slot * heads + h) * G;
+    }
+    int8_t* d = dst + doff;
     const bool vec = ((D & 7) == 0) && ((gs & 7) == 0) && ((((uintptr_t)src) & 15) == 0) &&
-                     ((((uintptr_t)dst) & 7) == 0);
+                     ((((uintptr_t)d) & 7) == 0);
 
     float m = 0.0f;
     for (size_t k0 = (size_t)j * 8; k0 < cnt; k0 += 128) {
@@ -136,7 +149,8 @@ __global__ __launch_bounds__(256) void kv_quant_kernel(
     float scale = m / 127.0f;
     if (scale < 1e-10f) scale = 1e-10f;
     const float inv = 1.0f / scale;
-    if (live && j == 0) scales[row * G + g] = scale;
+    if (live && place && j == 0) scales[soff + g] = scale;
+    if (!place) return;
 
     for (size_t k0 = (size_t)j * 8; k0 < cnt; k0 += 128) {
         if (vec && k0 + 8 <= cnt) {
@@ -215,7 +229,7 @@ hipError_t launch_kv_quant(const uint16_t* src, int8_t* dst, float* scales, size
     const size_t G = (D + gs - 1) / gs;
     const size_t items = rows * G;
     kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st>>>(src, dst, scales, nullptr, nullptr,
-                                                                             nullptr, rows, D, gs, G);
+                                                                             nullptr, rows, D, gs, G, nullptr, 1, 0, 0, 0);
     return hipGetLastError();
 }
 
@@ -226,8 +240,22 @@ hipError_t launch_kv_quant_pair(const uint16_t* k_src, int8_t* k_dst, float* k_s
     if (rows == 0 || D == 0) return hipSuccess;
     const size_t G = (D + gs - 1) / gs;
     const size_t items = rows * G;
-    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(k_src, k_dst, k_scales, v_src, v_dst,
-                                                                                v_scales, rows, D, gs, G);
+    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(
+        k_src, k_dst, k_scales, v_src, v_dst, v_scales, rows, D, gs, G, nullptr, 1, 0, 0, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_kv_append(const uint16_t* k_src, int8_t* k_cache, float* k_scales, const uint16_t* v_src,
+                            int8_t* v_cache, float* v_scales, size_t batch, size_t heads, size_t D, size_t gs,
+                            const int32_t* slots, size_t cache_batch_stride, size_t scale_batch_stride,
+                            size_t max_slots, hipStream_t st) {
+    const size_t rows = batch * heads;
+    if (rows == 0 || D == 0) return hipSuccess;
+    const size_t G = (D + gs - 1) / gs;
+    const size_t items = rows * G;
+    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(
+        k_src, k_cache, k_scales, v_src, v_cache, v_scales, rows, D, gs, G, slots, heads, cache_batch_stride,
+        scale_batch_stride, max_slots);
     return hipGetLastError();
 }
 

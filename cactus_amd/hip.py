@@ -77,6 +77,7 @@ SIGNATURES = {
     "cactus_hip_gelu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_quantize_kv_pair_fp16_to_int8_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp]),
     "cactus_hip_sample_greedy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "cactus_hip_kv_append_batched_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp, _sz, _sz, _sz, _vp]),
     "cactus_hip_indices_to_int32_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
     "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
     "cactus_hip_embedding_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp]),
@@ -293,6 +294,16 @@ def quantize_kv_pair(k, v, out_k, out_v, out_k_scales, out_v_scales, group_size=
                                                             _p(out_v_scales), S, Hh, D, group_size, _stream()))
 
 
+def kv_append_batched(k_new, v_new, k_cache, v_cache, k_scales, v_scales, slots, group_size=128):
+    """k_new / v_new fp16 [B, Hkv, D] quantized into slot slots[b] of caches int8 [B, slots, Hkv, D] and
+    scales fp32 [B, slots, Hkv, G]."""
+    _dev(k_new, torch.float16); _dev(v_new, torch.float16); _dev(slots, torch.int32)
+    B, Hh, D = k_new.shape
+    _check(lib.cactus_hip_kv_append_batched_dev(_p(k_new), _p(v_new), _p(k_cache), _p(v_cache), _p(k_scales),
+                                                _p(v_scales), B, Hh, D, group_size, _p(slots), k_cache.stride(0),
+                                                k_scales.stride(0), k_cache.shape[1], _stream()))
+
+
 def rope(x, theta, start_pos=0, out=None):
     """Half-split rotary embedding on fp16 [batch, seq, heads, head_dim]."""
     _dev(x, torch.float16)
@@ -358,14 +369,15 @@ def sample_greedy(logits, out=None):
     return o
 
 
-def embedding(table, indices, scales=None, group_size=128, out=None):
+def embedding(table, indices, scales=None, group_size=128, out=None, check=True):
     """Rows of an INT8 (per-group fp16 scales) or FP16 table; indices int32 [n].  Raises on an
-    index outside the table (after synchronising, like the reference's exception)."""
+    index outside the table (after synchronising, like the reference's exception); check=False
+    skips the flag and the synchronisation (e.g. under stream capture)."""
     _dev(indices, torch.int32)
     vocab, hidden = table.shape
     n = indices.numel()
     o = out if out is not None else torch.empty((n, hidden), dtype=torch.float16, device=table.device)
-    bad = torch.zeros((1,), dtype=torch.int32, device=table.device)
+    bad = torch.zeros((1,), dtype=torch.int32, device=table.device) if check else None
     if table.dtype == torch.int8:
         _dev(table, torch.int8); _dev(scales, torch.float16)
         _check(lib.cactus_hip_embedding_int8_dev(_p(table), _p(scales), _p(indices), _p(o), n, vocab, hidden,
@@ -374,7 +386,7 @@ def embedding(table, indices, scales=None, group_size=128, out=None):
         _dev(table, torch.float16)
         _check(lib.cactus_hip_embedding_f16_dev(_p(table), _p(indices), _p(o), n, vocab, hidden, _p(bad),
                                                 _stream()))
-    if int(bad.item()):
+    if check and int(bad.item()):
         raise CactusHipError("Embedding index out of bounds")
     return o
 

@@ -275,6 +275,19 @@ int cactus_hip_attention_hybrid_int8_fp16_batched_dev(
     float scale, const int32_t* position_offsets, size_t group_size,
     size_t cache_batch_stride, size_t scale_batch_stride, size_t max_cache_len, void* stream);
 
+/* Batched-decode append: one new token per independent sequence, K and V [B,Hkv,D] quantized
+ * (cactus_quantize_kv_fp16_to_int8 arithmetic) straight into slot slots[b] of sequence b's cache,
+ * caches addressed as in the batched attention above (per-sequence strides in elements; a slot is
+ * Hkv*D int8 values / Hkv*ceil(D/gs) scales).  A slot outside [0, max_slots) stores nothing.  No
+ * counterpart in the reference, whose cache is batch-1; with one sequence it is the append of
+ * engine_cache.cpp:234-267. */
+int cactus_hip_kv_append_batched_dev(const cactus_half_t* k_new, const cactus_half_t* v_new,
+                                     int8_t* k_cache, int8_t* v_cache, float* k_scales, float* v_scales,
+                                     size_t batch_size, size_t kv_heads, size_t head_dim,
+                                     size_t group_size, const int32_t* slots,
+                                     size_t cache_batch_stride, size_t scale_batch_stride,
+                                     size_t max_slots, void* stream);
+
 /* ------------------------------------------------ host-pointer drop-in family
  * Same argument lists as cactus/kernel/kernel.h, host memory in and out.      */
 

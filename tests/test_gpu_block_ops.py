@@ -253,13 +253,16 @@ def test_quantize_kv_pair_equals_two_calls(H):
 
 
 # --------------------------------------------------------------------------- greedy sampler
-@pytest.mark.parametrize("rows,vocab", [(1, 151936), (3, 1000), (5, 1), (2, 1025), (256, 4096)])
+@pytest.mark.parametrize("rows,vocab", [(1, 151936), (3, 1000), (5, 1), (2, 1025), (256, 4096), (3, 20000),
+                                        (64, 16384), (65, 16384)])
 def test_sample_greedy_first_maximum(H, rows, vocab):
     """kernel_nn.cpp:450-466: strict '>' scan from element 0 -- ties to the lowest index."""
     rng = np.random.default_rng(rows + vocab)
     x = halves(rng, (rows, vocab), 3.0)
     if vocab >= 1000:
         x[0, 700] = x[0, 77] = np.float16(60000.0)         # tie: index 77 wins
+        if vocab >= 20000:
+            x[0, 19000] = np.float16(60000.0)              # a tie in another workgroup's chunk
         x[-1, 5] = np.float16(np.nan)                      # NaNs are never greater
         if rows > 1:
             x[1, :] = np.float16(-np.inf)                  # nothing exceeds element 0
@@ -272,3 +275,34 @@ def test_sample_greedy_first_maximum(H, rows, vocab):
 def test_sample_greedy_nan_first_element(H):
     x = np.array([[np.nan, 5.0, 7.0, 1.0]], np.float16)
     assert H.sample_greedy(dev(x)).cpu().tolist() == [0] and O.sample_greedy(x).tolist() == [0]
+
+
+def test_sample_greedy_twice_in_a_row_and_all_equal(H):
+    """The split form cleans its scratch for the next call; equal values and signed zeros keep index 0."""
+    x = np.zeros((2, 40000), np.float16)
+    x[1, 1::2] = np.float16(-0.0)
+    for _ in range(3):
+        assert H.sample_greedy(dev(x)).cpu().tolist() == [0, 0]
+    x[0, 39999] = 1.0
+    assert H.sample_greedy(dev(x)).cpu().tolist() == [39999, 0]
+    x[:, 0] = np.float16(np.nan)
+    assert H.sample_greedy(dev(x)).cpu().tolist() == [0, 0]
+
+
+def test_kv_append_batched_equals_per_sequence_quantization(H):
+    """engine_cache.cpp:234-267 per sequence: the new token's K and V land in that sequence's slot."""
+    rng = np.random.default_rng(12)
+    B, slots, Hkv, D = 5, 9, 2, 128
+    k, v = halves(rng, (B, Hkv, D), 2.0), halves(rng, (B, Hkv, D), 2.0)
+    kc = torch.zeros((B, slots, Hkv, D), dtype=torch.int8, device="cuda"); vc = torch.zeros_like(kc)
+    ks = torch.zeros((B, slots, Hkv, 1), dtype=torch.float32, device="cuda"); vs = torch.zeros_like(ks)
+    where = np.array([0, 8, 3, 9, 5], np.int32)            # 9 is out of range: nothing stored
+    H.kv_append_batched(dev(k), dev(v), kc, vc, ks, vs, dev(where))
+    okq, oks = O.quantize_kv(k); ovq, ovs = O.quantize_kv(v)
+    kc, vc, ks, vs = kc.cpu().numpy(), vc.cpu().numpy(), ks.cpu().numpy(), vs.cpu().numpy()
+    for b in range(B):
+        if where[b] < slots:
+            assert np.array_equal(kc[b, where[b]], okq[b]) and np.array_equal(vc[b, where[b]], ovq[b])
+            assert np.array_equal(ks[b, where[b]], oks[b]) and np.array_equal(vs[b, where[b]], ovs[b])
+            kc[b, where[b]] = 0; vc[b, where[b]] = 0; ks[b, where[b]] = 0; vs[b, where[b]] = 0
+    assert not kc.any() and not vc.any() and not ks.any() and not vs.any()
