@@ -330,6 +330,13 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                                            (x, L["v"][0], L["v"][1], vo)], 128),
                             H.MatmulBatch([(xn2, L["gate"][0], L["gate"][1], go), (xn2, L["up"][0], L["up"][1], uo)], 128)))
 
+    shared = []
+    if batch > 4:
+        for L in Ls:
+            shared.append((H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko),
+                                           (L["v"][0], L["v"][1], vo)], 128),
+                           H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128)))
+
     def proj(inp, w, out):
         H.matmul_f16act(inp, w[0], w[1], 128, out=out)
 
@@ -342,8 +349,7 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                 batches[li][0].run()
             else:
                 q8, s8 = H.quantize_activations(x)
-                for name, out in (("q", qo), ("k", ko), ("v", vo)):
-                    H.matmul_int8(q8, s8, L[name][0], L[name][1], 128, out=out)
+                shared[li][0].run(q8, s8)
             H.qk_norm_rope(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), L["q_norm"], L["k_norm"], eps, theta,
                            pos, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
             a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
@@ -362,8 +368,7 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                 batches[li][1].run()
             else:
                 q8, s8 = H.quantize_activations(xn2)
-                H.matmul_int8(q8, s8, L["gate"][0], L["gate"][1], 128, out=go)
-                H.matmul_int8(q8, s8, L["up"][0], L["up"][1], 128, out=uo)
+                shared[li][1].run(q8, s8)
             H.silu_multiply(go, uo, out=act)
             proj(act, L["down"], do)
             nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm

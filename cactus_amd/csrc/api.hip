@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -254,6 +255,55 @@ int cactus_hip_matmul_int8_f16act_batch_dev(const cactus_hip_matmul_problem* pro
 int cactus_hip_matmul_int4_f16act_batch_dev(const cactus_hip_matmul_problem* problems, size_t count,
                                             size_t group_size, void* stream) {
     return matmul_q_f16act_batch(true, problems, count, group_size, stream);
+}
+
+namespace {
+int matmul_q_shared(bool int4, const int8_t* A, const float* As, const cactus_hip_matmul_weights* ws, size_t count,
+                    size_t M, size_t K, size_t gs, void* stream) {
+    if (count == 0 || M == 0) return CACTUS_HIP_OK;
+    if (!ws) return fail(CACTUS_HIP_EINVAL, "matmul_shared: null weight list");
+    for (size_t i = 0; i < count; i++)
+        if (ws[i].N && (!ws[i].B || !ws[i].B_scales || !ws[i].C)) return fail(CACTUS_HIP_EINVAL, "matmul_shared: null operand");
+    // one launch when the pipelined kernel takes the shape, otherwise one call per weight
+    if (M > 16 && gs == 128 && K > 0 && A && As) {
+        size_t i = 0;
+        bool all = true;
+        while (i < count && all) {
+            const size_t n = std::min<size_t>(8, count - i);
+            if (!gemm_batch_ok(n, K)) { all = false; break; }
+            GemmProblem pr[8];
+            bool fits = true;
+            for (size_t j = 0; j < n; j++) {
+                pr[j] = GemmProblem{ws[i + j].B, ws[i + j].B_scales, ws[i + j].C, ws[i + j].N};
+                if (ws[i + j].N * (int4 ? K / 2 : K) > (size_t(1) << 31)) fits = false;
+            }
+            if (!fits || M * K > (size_t(1) << 31)) { all = false; break; }
+            hipError_t e = launch_matmul_gemm_batch(int4, A, As, pr, n, M, K, S(stream));
+            if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_shared launch", e);
+            i += n;
+        }
+        if (all) return CACTUS_HIP_OK;
+        for (; i < count; i++) {
+            int rc = matmul_q(int4, A, As, ws[i].B, ws[i].B_scales, ws[i].C, nullptr, M, K, ws[i].N, gs, stream);
+            if (rc != CACTUS_HIP_OK) return rc;
+        }
+        return CACTUS_HIP_OK;
+    }
+    for (size_t i = 0; i < count; i++) {
+        int rc = matmul_q(int4, A, As, ws[i].B, ws[i].B_scales, ws[i].C, nullptr, M, K, ws[i].N, gs, stream);
+        if (rc != CACTUS_HIP_OK) return rc;
+    }
+    return CACTUS_HIP_OK;
+}
+}  // namespace
+
+int cactus_hip_matmul_int8_shared_dev(const int8_t* A, const float* A_scales, const cactus_hip_matmul_weights* weights,
+                                      size_t count, size_t M, size_t K, size_t group_size, void* stream) {
+    return matmul_q_shared(false, A, A_scales, weights, count, M, K, group_size, stream);
+}
+int cactus_hip_matmul_int4_shared_dev(const int8_t* A, const float* A_scales, const cactus_hip_matmul_weights* weights,
+                                      size_t count, size_t M, size_t K, size_t group_size, void* stream) {
+    return matmul_q_shared(true, A, A_scales, weights, count, M, K, group_size, stream);
 }
 
 int cactus_hip_matmul_f16_dev(const cactus_half_t* a, const cactus_half_t* bT, cactus_half_t* c,

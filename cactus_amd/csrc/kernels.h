@@ -63,6 +63,17 @@ hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales,
                               const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                               size_t K, size_t N, hipStream_t st);
 
+// Several weight matrices against one quantized activation matrix [M, K] (group 128), one launch.
+struct GemmProblem {
+    const void* B;
+    const uint16_t* Bs;
+    uint16_t* C;
+    size_t N;
+};
+bool gemm_batch_ok(size_t count, size_t K);
+hipError_t launch_matmul_gemm_batch(bool int4, const int8_t* A, const float* A_scales, const GemmProblem* problems,
+                                    size_t count, size_t M, size_t K, hipStream_t st);
+
 // matmul_generic.hip: any group_size (whole groups of K only), one thread per output.
 hipError_t launch_matmul_generic(bool int4, const int8_t* A, const float* A_scales, const void* B,
                                  const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,

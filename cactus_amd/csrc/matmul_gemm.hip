@@ -18,6 +18,7 @@
 // chunks 0-3 of an LDS row, high nibbles (odd k) chunks 4-7, each nibble moved to the top of
 // its byte (value * 16, sign included); the activation tile is de-interleaved the same way
 // and the factor 16 is folded into the scale.
+#include <cstring>
 #include <type_traits>
 #include "common.hip.h"
 #include "kernels.h"
@@ -244,11 +245,27 @@ __device__ __forceinline__ const T* scalar_ptr(const T* p) {
 }
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Several weight matrices that multiply the same activations (q/k/v, gate/up) in one launch: the
+// n-tiles of all of them are laid side by side; bn_end[i] = running count of n-tiles.
+constexpr int G2_MAXB = 8;
+struct GemmBatch {
+    int count;                 // 0: the single problem of the plain arguments
+    int bn_end[G2_MAXB];
+    const uint8_t* B[G2_MAXB];
+    const uint16_t* Bs[G2_MAXB];
+    uint16_t* C[G2_MAXB];
+    int N[G2_MAXB];
+};
+
 template <bool INT4>
 __global__ __launch_bounds__(512) void gemm2_kernel(
-    const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B,
-    const uint16_t* __restrict__ B_scales, uint16_t* __restrict__ C, int M, int K, int N, int G, int nbm,
-    int nwg) {
+    const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B_arg,
+    const uint16_t* __restrict__ B_scales_arg, uint16_t* __restrict__ C_arg, int M, int K, int N_arg, int G, int nbm,
+    int nwg, const GemmBatch bt) {
+    const uint8_t* __restrict__ B = B_arg;
+    const uint16_t* __restrict__ B_scales = B_scales_arg;
+    uint16_t* __restrict__ C = C_arg;
+    int N = N_arg;
     extern __shared__ __attribute__((aligned(16))) uint8_t g2_lds[];
     uint16_t* sc16 = reinterpret_cast<uint16_t*>(g2_lds + G2_STAGES * G2_STAGE);   // [G][128]
     G2_T(tr_entry);
@@ -261,7 +278,14 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     // XCD-aware, bijective remap of the workgroup id (ids congruent mod 8 share an XCD)
     const int orig = blockIdx.x, xcd = orig & 7, qn = nwg >> 3, rn = nwg & 7;
     const int wg = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (orig >> 3);
-    const int bm = wg % nbm, bn = wg / nbm;
+    const int bm = wg % nbm;
+    int bn = wg / nbm;
+    if (bt.count) {
+        int pi = 0;
+        while (pi + 1 < bt.count && bn >= bt.bn_end[pi]) pi++;
+        bn -= pi ? bt.bn_end[pi - 1] : 0;
+        B = bt.B[pi]; B_scales = bt.Bs[pi]; C = bt.C[pi]; N = bt.N[pi];
+    }
     const int m0 = bm * GM_BM, n0 = bn * GM_BN;
     const size_t brow_bytes = INT4 ? (size_t)K / 2 : (size_t)K;
 
@@ -649,11 +673,9 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
 #endif
 }
 
+// more than 64 KB of dynamic LDS has to be allowed once per device
 template <bool INT4>
-static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
-                               uint16_t* C, size_t M, size_t K, size_t N, int G, hipStream_t st) {
-    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
-    // more than 64 KB of dynamic LDS has to be allowed once per device
+static hipError_t gemm2_allow_lds() {
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -663,10 +685,48 @@ static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const voi
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
+    return hipSuccess;
+}
+
+template <bool INT4>
+static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
+                               uint16_t* C, size_t M, size_t K, size_t N, int G, hipStream_t st) {
+    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
+    hipError_t ea = gemm2_allow_lds<INT4>();
+    if (ea != hipSuccess) return ea;
     const int nbm = (int)((M + GM_BM - 1) / GM_BM), nbn = (int)((N + GM_BN - 1) / GM_BN);
     const int nwg = nbm * nbn;
+    GemmBatch none;
+    none.count = 0;
     gemm2_kernel<INT4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C,
-                                                                   (int)M, (int)K, (int)N, G, nbm, nwg);
+                                                                   (int)M, (int)K, (int)N, G, nbm, nwg, none);
+    return hipGetLastError();
+}
+
+template <bool INT4>
+static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, const GemmProblem* pr, size_t count,
+                                     size_t M, size_t K, int G, hipStream_t st) {
+    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
+    hipError_t e = gemm2_allow_lds<INT4>();
+    if (e != hipSuccess) return e;
+    GemmBatch bt;
+    memset(&bt, 0, sizeof bt);
+    bt.count = (int)count;
+    const int nbm = (int)((M + GM_BM - 1) / GM_BM);
+    size_t nbn = 0;
+    for (size_t i = 0; i < count; i++) {
+        nbn += (pr[i].N + GM_BN - 1) / GM_BN;
+        if (nbn * nbm >= (size_t(1) << 30)) return hipErrorInvalidValue;
+        bt.bn_end[i] = (int)nbn;
+        bt.B[i] = static_cast<const uint8_t*>(pr[i].B);
+        bt.Bs[i] = pr[i].Bs;
+        bt.C[i] = pr[i].C;
+        bt.N[i] = (int)pr[i].N;
+    }
+    const int nwg = nbm * (int)nbn;
+    if (nwg == 0) return hipSuccess;
+    gemm2_kernel<INT4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr, (int)M,
+                                                                   (int)K, 0, G, nbm, nwg, bt);
     return hipGetLastError();
 }
 
@@ -675,6 +735,21 @@ extern "C" int cactus_hip_debug_gemm_trace(unsigned long long* out512) {
     return (int)hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 512);
 }
 #endif
+
+// Up to 8 weight matrices against one quantized activation matrix, one launch.  false: the shape
+// is outside what the pipelined kernel takes (the caller launches them one by one).
+bool gemm_batch_ok(size_t count, size_t K) {
+    const size_t G = K / 128;
+    return count >= 1 && count <= (size_t)G2_MAXB && K % 128 == 0 &&
+           (size_t)G2_STAGES * G2_STAGE + G * GM_BN * 2 <= 160 * 1024;
+}
+hipError_t launch_matmul_gemm_batch(bool int4, const int8_t* A, const float* A_scales, const GemmProblem* pr,
+                                    size_t count, size_t M, size_t K, hipStream_t st) {
+    if (!gemm_batch_ok(count, K)) return hipErrorInvalidValue;
+    const int G = (int)(K / 128);
+    return int4 ? launch_gemm2_batch<true>(A, A_scales, pr, count, M, K, G, st)
+                : launch_gemm2_batch<false>(A, A_scales, pr, count, M, K, G, st);
+}
 
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
                               const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,

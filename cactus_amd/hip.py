@@ -38,6 +38,8 @@ SIGNATURES = {
     "cactus_hip_matmul_int4_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_f16act_batch_dev": (_i, [_vp, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_f16act_batch_dev": (_i, [_vp, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_shared_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_shared_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_group_sums_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_group_sums_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp]),
@@ -192,6 +194,29 @@ class MatmulBatch:
     def run(self):
         _check(self._fn(C.cast(self._arr, C.c_void_p), len(self._keep), self._gs, _stream()))
         return [e[3] for e in self._keep]
+
+
+class MatmulWeights(C.Structure):
+    _fields_ = [("B", C.c_void_p), ("B_scales", C.c_void_p), ("C", C.c_void_p), ("N", C.c_size_t)]
+
+
+class MatmulShared:
+    """Several weights against one quantized activation matrix: entries = [(B, B_scales, out)];
+    run(A, A_scales) enqueues them (one launch when M > 16)."""
+
+    def __init__(self, entries, group_size=128, int4=False):
+        self._keep = entries
+        self._arr = (MatmulWeights * len(entries))()
+        for i, (B, Bs, out) in enumerate(entries):
+            _dev(Bs, torch.float16); _dev(out, torch.float16)
+            self._arr[i] = MatmulWeights(B.data_ptr(), Bs.data_ptr(), out.data_ptr(), B.shape[0])
+        self._fn = lib.cactus_hip_matmul_int4_shared_dev if int4 else lib.cactus_hip_matmul_int8_shared_dev
+        self._gs = group_size
+
+    def run(self, A, A_scales):
+        _dev(A, torch.int8); _dev(A_scales, torch.float32)
+        M, K = A.shape
+        _check(self._fn(_p(A), _p(A_scales), self._arr, len(self._keep), M, K, self._gs, _stream()))
 
 
 def matmul_group_sums(A, B, group_size=128, int4=False):

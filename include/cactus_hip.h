@@ -123,6 +123,23 @@ int cactus_hip_matmul_int8_f16act_batch_dev(const cactus_hip_matmul_problem* pro
 int cactus_hip_matmul_int4_f16act_batch_dev(const cactus_hip_matmul_problem* problems, size_t count,
                                             size_t group_size, void* stream);
 
+/* Several weight matrices against ONE quantized activation matrix: the q/k/v (model_qwen.cpp:
+ * 55-57) or gate/up (:112-113) projections of a prefill or batched-decode step.  Results are those
+ * of one cactus_hip_matmul_int{8,4}_dev call per entry; for M > 16 and group_size 128 up to 8
+ * entries share a launch (small N leaves most of the chip idle when launched alone). */
+typedef struct cactus_hip_matmul_weights {
+    const void* B;                 /* int8[N, K] or packed uint8[N, K/2]  */
+    const cactus_half_t* B_scales; /* half[N, K/group_size]               */
+    cactus_half_t* C;              /* half[M, N] output                   */
+    size_t N;
+} cactus_hip_matmul_weights;
+int cactus_hip_matmul_int8_shared_dev(const int8_t* A, const float* A_scales,
+                                      const cactus_hip_matmul_weights* weights, size_t count, size_t M,
+                                      size_t K, size_t group_size, void* stream);
+int cactus_hip_matmul_int4_shared_dev(const int8_t* A, const float* A_scales,
+                                      const cactus_hip_matmul_weights* weights, size_t count, size_t M,
+                                      size_t K, size_t group_size, void* stream);
+
 /* cactus_matmul_f16 (kernel.h:49-50; kernel_gemm.cpp:102-126): C = A * B^T,
  * a half[M,K], b_transposed half[N,K].  Accumulates in fp32 (the reference
  * accumulates in fp16 lanes), so it is compared by tolerance. */

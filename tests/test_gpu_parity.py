@@ -459,3 +459,23 @@ def test_attention_long_context_properties(H):
                              torch.cat([ks[:8192]] * 2), torch.cat([vs[:8192]] * 2), empty, empty, 0.0,
                              is_causal=False)
     assert np.abs(f16(bits(one)) - f16(bits(two))).max() <= 1e-3
+
+
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,Ns", [(256, 1024, (2048, 1024, 1024)), (40, 512, (100, 272)), (300, 1024, (3072, 3072)),
+                                    (8, 1024, (256, 128)), (33, 768, (64,) * 9)])
+def test_matmul_shared_activations_one_launch_bit_exact(H, M, K, Ns, int4):
+    """q/k/v or gate/up on one quantized activation matrix (model_qwen.cpp:55-57, 112-113): the
+    batched launch equals one matmul per weight."""
+    if int4 and K % 256:
+        pytest.skip("packed units hold two groups")
+    rng = np.random.default_rng(M + K + sum(Ns) + int4)
+    x = rand_act_f16(rng, M, K)
+    q, s = O.quantize_activations(x)
+    ws = [(rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K) for N in Ns]
+    outs = [torch.full((M, N), 7.0, dtype=torch.float16, device="cuda") for N in Ns]
+    sh = H.MatmulShared([(dev(B), dev(Bs.view(np.float16)), o) for (B, Bs), o in zip(ws, outs)], 128, int4)
+    sh.run(dev(q), dev(s))
+    for (B, Bs), o in zip(ws, outs):
+        want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
+        assert np.array_equal(bits(o), want)
