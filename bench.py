@@ -452,6 +452,27 @@ def extra_table(H, gen, big):
         gb = byts / (ms * 1e-3) / 1e9
         rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
     ex["attn_decode_int8kv"] = rows
+    # the ops between the hot kernels of a decoder block, prefill-sized (4096 tokens of Qwen3-0.6B):
+    # HBM-bound; bytes = fp16 in + out (+ second input)
+    rows = {}
+    half = lambda *sh: (torch.rand(sh, device="cuda", generator=gen) * 2 - 1).half()
+    T, Hd, Hq, Hkv, D, F = 4096, 1024, 16, 8, 128, 3072
+    xa, xb, wn, o1, o2 = half(T, Hd), half(T, Hd), half(Hd), half(T, Hd), half(T, Hd)
+    q4, k4, qw, kw = half(1, T, Hq, D), half(1, T, Hkv, D), half(D), half(D)
+    oq, ok = torch.empty_like(q4), torch.empty_like(k4)
+    ga, up, oa = half(T, F), half(T, F), half(T, F)
+    H.rope_reserve(D, 1e6, T)
+    for name, fn, nbytes in (
+            ("rms_norm_4096x1024", lambda i: H.rms_norm(xa, wn, 1e-6, out=o1), 4 * T * Hd),
+            ("add_rms_norm_4096x1024", lambda i: H.add_rms_norm(xa, xb, wn, 1e-6, out_sum=o1, out_norm=o2), 8 * T * Hd),
+            ("qk_norm_rope_4096x(16+8)x128", lambda i: H.qk_norm_rope(q4, k4, qw, kw, 1e-6, 1e6, 0, out_q=oq, out_k=ok),
+             4 * T * (Hq + Hkv) * D),
+            ("silu_multiply_4096x3072", lambda i: H.silu_multiply(ga, up, out=oa), 6 * T * F)):
+        ms = time_graph(fn, 8)
+        gb = nbytes / (ms * 1e-3) / 1e9
+        rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
+    ex["block_ops_prefill"] = rows
+    del xa, xb, o1, o2, q4, k4, oq, ok, ga, up, oa
     torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512)}
