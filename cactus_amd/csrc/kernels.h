@@ -51,7 +51,6 @@ struct SkinnyProblem {
 hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* problems, size_t count, hipStream_t st);
 
 extern int g_skinny_ablate;
-extern int g_skinny_tpw;
 hipError_t skinny_read_trace(unsigned long long* out512);
 // Benchmark hook: variant = waves_per_workgroup*100 + ring_depth (0 = the default choice).
 hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A, const float* A_scales,

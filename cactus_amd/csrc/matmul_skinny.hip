@@ -324,20 +324,21 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused-quantization body (FP16 activations, M <= 4), several 16-row tiles per workgroup.
+// Fused-quantization body (FP16 activations, M <= 4), one tile of 16 * CT weight rows.
 //
-// The workgroup quantizes the activation rows into LDS once -- absmax, scale =
-// max(absmax/127, 1e-10), q = rne(clamp(x * (1/scale))), exactly as act_quant_rowwise_kernel --
-// and then walks `ntile` consecutive 16-row weight tiles.  The first ring of loads of tile i+1
-// (and its scales) is requested right after the last unit of tile i has been consumed, so the
-// memory pipe stays busy while tile i's barrier, fp32 chain and store run: the per-tile
-// latencies that bound a one-tile workgroup overlap with streaming.
+// The wave group quantizes the activation rows into LDS -- absmax, scale = max(absmax/127, 1e-10),
+// q = rne(clamp(x * (1/scale))), exactly as act_quant_rowwise_kernel -- while its first ring of
+// weight loads is in flight, streams the tile, then runs the fp32 chain.  (Walking several tiles
+// per wave group, with the next tile's loads under the epilogue, measured slower at every tile
+// count and cost 30 registers: 4 instead of 5 waves per SIMD.)
 template <bool INT4, int W, int P, int CT>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
-                                        uint16_t* __restrict__ C, int M, int K, int N, int tile0, int ntile) {
+                                        uint16_t* __restrict__ C, int M, int K, int N, int tl,
+                                        int t, float* __restrict__ sk_lds) {
+    // t: thread index among the W waves that share the tile; sk_lds: their LDS region.  A workgroup
+    // may hold several such wave groups (tiles of one problem, same barrier sequence).
     constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
-    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
     const int G = K / 128;
     constexpr int step = W * GPU_;
     const int SC = ((G + step - 1) / step) * step;
@@ -348,7 +349,6 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     int8_t* lds_a = reinterpret_cast<int8_t*>(scl + TR * GP);                    // [M][K]
     float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4]
 
-    const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -371,15 +371,12 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     struct Boff { unsigned o[CT]; };
     struct ScRegs { v4i v[CT]; };
     Unit ring[P];
-    auto tile_boff = [&](int tl) {   // tl past the last tile or row past N: out of range, reads zeros
-        Boff bo;
+    Boff boff;   // a row past N is out of range and reads zeros
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            const int n = tl * TR + ct * SK_TN + r;
-            bo.o[ct] = (tl < tile0 + ntile && n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
-        }
-        return bo;
-    };
+    for (int ct = 0; ct < CT; ct++) {
+        const int n = tl * TR + ct * SK_TN + r;
+        boff.o[ct] = (n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
+    }
     auto load_unit = [&](int u, const Boff& bo, Unit& R) {
         const unsigned uo = (u < nunits) ? (unsigned)u * 128u : SK_OOB;
 #pragma unroll
@@ -388,10 +385,11 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             R.b[ct][1] = buf_load<2>(brsrc, bo.o[ct] + uo, 64);
         }
     };
-    // this thread's chunks of 8 scales of tile tl (fast path: chunk t + j*W*64), else out of range
-    auto load_scales = [&](int tl) {
+    // this thread's chunks of 8 scales of the tile (fast path: chunk t + j*W*64), else out of range
+    const int n0 = tl * TR;
+    const bool fast = sc_fast_shape && n0 + TR <= N;
+    auto load_scales = [&]() {
         ScRegs sr;
-        const bool fast = sc_fast_shape && tl < tile0 + ntile && tl * TR + TR <= N;
 #pragma unroll
         for (int j = 0; j < CT; j++) {
             const int ch = t + j * W * 64;
@@ -457,10 +455,9 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     v4i a_stage[AST];
 #pragma unroll
     for (int j = 0; j < AST; j++) a_stage[j] = buf_load<0>(xrsrc, (unsigned)(t + j * W * 64) * 16u, 0);
-    Boff boff = tile_boff(tile0);
 #pragma unroll
     for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
-    ScRegs sc_regs = load_scales(tile0);
+    const ScRegs sc_regs = load_scales();
     {
         float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto row_of = [&](int i16) {   // M <= 4: compares instead of a division
@@ -518,90 +515,71 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     }
 
     const int rounds = (nunits + W * P - 1) / (W * P);
-    for (int sub = 0; sub < ntile; sub++) {
-        const int tl = tile0 + sub;
-        const int n0 = tl * TR;
-        for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
+    for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
 #pragma unroll
-            for (int p = 0; p < P; p++) {
-                const int ul = w + (rd * P + p) * W;
-                compute_unit(ul, ring[p]);
-                load_unit(ul + P * W, boff, ring[p]);
-            }
+        for (int p = 0; p < P; p++) {
+            const int ul = w + (rd * P + p) * W;
+            compute_unit(ul, ring[p]);
+            load_unit(ul + P * W, boff, ring[p]);
         }
+    }
 #pragma unroll
-        for (int p = 0; p < P; p++) compute_unit(w + ((rounds - 1) * P + p) * W, ring[p]);
+    for (int p = 0; p < P; p++) compute_unit(w + ((rounds - 1) * P + p) * W, ring[p]);
 
-        // next tile's first ring and scales go out now; past the last tile they read nothing
-        boff = tile_boff(tl + 1);
+    // the tile's scales -> LDS as fp32 (x 1/16 for INT4)
+    if (fast) {
 #pragma unroll
-        for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
-        const ScRegs sc_next = load_scales(tl + 1);
-
-        // this tile's scales -> LDS as fp32 (x 1/16 for INT4)
-        const bool fast = sc_fast_shape && n0 + TR <= N;
-        if (fast) {
+        for (int j = 0; j < CT; j++) {
+            const int ch = t + j * W * 64;
+            if (ch < TR * G / 8) {
+                const int row = (ch * 8) / G, g = (ch * 8) - row * G;
+                float* dst = scl + row * GP + g;
 #pragma unroll
-            for (int j = 0; j < CT; j++) {
-                const int ch = t + j * W * 64;
-                if (ch < TR * G / 8) {
-                    const int row = (ch * 8) / G, g = (ch * 8) - row * G;
-                    float* dst = scl + row * GP + g;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const uint32_t x = (uint32_t)sc_regs.v[j][i];
-                        const float lo = h2f((uint16_t)(x & 0xFFFFu)), hi = h2f((uint16_t)(x >> 16));
-                        dst[2 * i] = INT4 ? lo * 0.0625f : lo;
-                        dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
-                    }
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t x = (uint32_t)sc_regs.v[j][i];
+                    const float lo = h2f((uint16_t)(x & 0xFFFFu)), hi = h2f((uint16_t)(x >> 16));
+                    dst[2 * i] = INT4 ? lo * 0.0625f : lo;
+                    dst[2 * i + 1] = INT4 ? hi * 0.0625f : hi;
                 }
             }
-        } else {
-            for (int idx = t; idx < TR * G; idx += W * 64) {
-                const int row = idx / G, g = idx - row * G;
-                const float sv = h2f(B_scales[(size_t)min(n0 + row, N - 1) * G + g]);
-                scl[row * GP + g] = INT4 ? sv * 0.0625f : sv;
-            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    } else {
+        for (int idx = t; idx < TR * G; idx += W * 64) {
+            const int row = idx / G, g = idx - row * G;
+            const float sv = h2f(B_scales[(size_t)min(n0 + row, N - 1) * G + g]);
+            scl[row * GP + g] = INT4 ? sv * 0.0625f : sv;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
-        // wave ct runs the chains of column tile ct (W >= CT): thread (m, n) walks its groups in order
-        {
-            const int ct = w, e = lane;
-            if (ct < CT && e < M * 16) {
-                const float* sp = scl + (ct * SK_TN + (e & 15)) * GP;
-                const float* gp = gbuf + ((size_t)ct * M * 16 + e) * SCP;
-                float run = 0.0f;
-                int gl = 0;
-                for (; gl + 16 <= G; gl += 16) {   // eight ds_read_b128, then the serial fma chain
-                    v4f gv[4], sv[4];
+    // wave ct runs the chains of column tile ct (W >= CT): thread (m, n) walks its groups in order
+    const int ct = w, e = lane;
+    if (ct < CT && e < M * 16) {
+        const float* sp = scl + (ct * SK_TN + (e & 15)) * GP;
+        const float* gp = gbuf + ((size_t)ct * M * 16 + e) * SCP;
+        float run = 0.0f;
+        int gl = 0;
+        for (; gl + 16 <= G; gl += 16) {   // eight ds_read_b128, then the serial fma chain
+            v4f gv[4], sv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        gv[u] = *reinterpret_cast<const v4f*>(gp + gl + 4 * u);
-                        sv[u] = *reinterpret_cast<const v4f*>(sp + gl + 4 * u);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 16; u++) run = fmaf(gv[u >> 2][u & 3], sv[u >> 2][u & 3], run);
-                }
-                for (; gl < G; gl++) run = fmaf(gp[gl], sp[gl], run);
-                const int cm = e >> 4, cn = e & 15;
-                float rmax = wmax[cm];
-#pragma unroll
-                for (int ww = 1; ww < W; ww++) rmax = fmaxf(rmax, wmax[ww * 4 + cm]);
-                float as = rmax / 127.0f;
-                if (as < 1e-10f) as = 1e-10f;
-                if (scales_out != nullptr && tl == 0 && ct == 0 && cn == 0) scales_out[cm] = as;
-                if (n0 + ct * SK_TN + cn < N) C[(size_t)cm * N + n0 + ct * SK_TN + cn] = f2h_mul(run, as);
+            for (int u = 0; u < 4; u++) {
+                gv[u] = *reinterpret_cast<const v4f*>(gp + gl + 4 * u);
+                sv[u] = *reinterpret_cast<const v4f*>(sp + gl + 4 * u);
             }
+#pragma unroll
+            for (int u = 0; u < 16; u++) run = fmaf(gv[u >> 2][u & 3], sv[u >> 2][u & 3], run);
         }
-        if (sub + 1 < ntile) {   // group sums and scales are rewritten by the next tile
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        sc_regs = sc_next;
+        for (; gl < G; gl++) run = fmaf(gp[gl], sp[gl], run);
+        const int cm = e >> 4, cn = e & 15;
+        float rmax = wmax[cm];
+#pragma unroll
+        for (int ww = 1; ww < W; ww++) rmax = fmaxf(rmax, wmax[ww * 4 + cm]);
+        float as = rmax / 127.0f;
+        if (as < 1e-10f) as = 1e-10f;
+        if (scales_out != nullptr && tl == 0 && ct == 0 && cn == 0) scales_out[cm] = as;
+        if (n0 + ct * SK_TN + cn < N) C[(size_t)cm * N + n0 + ct * SK_TN + cn] = f2h_mul(run, as);
     }
 }
 
@@ -610,10 +588,9 @@ __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __res
                                                           float* __restrict__ scales_out,
                                                           const uint8_t* __restrict__ B,
                                                           const uint16_t* __restrict__ B_scales,
-                                                          uint16_t* __restrict__ C, int M, int K, int N, int tpw) {
-    const int tiles = (N + SK_TN * CT - 1) / (SK_TN * CT);
-    const int tile0 = (int)blockIdx.x * tpw;
-    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, tile0, min(tpw, tiles - tile0));
+                                                          uint16_t* __restrict__ C, int M, int K, int N) {
+    extern __shared__ __attribute__((aligned(16))) float fq_lds[];
+    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, (int)blockIdx.x, (int)threadIdx.x, fq_lds);
 }
 
 // Several independent FP16-activation matmuls (M <= 4 each) in one launch: the projections
@@ -624,8 +601,9 @@ __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __res
 constexpr int SK_MAXB = 16;
 struct SkinnyBatch {
     int count;
-    int tpw[SK_MAXB];               // tiles per workgroup, per problem
-    int tile_end[SK_MAXB];          // running sum of workgroups: ceil(tiles / tpw) per problem
+    int wt[SK_MAXB];                // sub-tiled launch: waves per tile (1, 2 or 4), per problem
+    int tile_end[SK_MAXB];          // running sum of workgroups per problem
+    int lds_floats[SK_MAXB];        // sub-tiled launch: floats of LDS per wave group
     const void* X[SK_MAXB];
     const void* B[SK_MAXB];
     const uint16_t* Bs[SK_MAXB];
@@ -649,12 +627,36 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     const int blk = (int)blockIdx.x;
     int pi = 0;
     while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
-    const int tpw = bt.tpw[pi];
-    const int tile0 = (blk - (pi ? bt.tile_end[pi - 1] : 0)) * tpw;
-    const int tiles = (bt.N[pi] + SK_TN * CT - 1) / (SK_TN * CT);
+    const int tile = blk - (pi ? bt.tile_end[pi - 1] : 0);
+    extern __shared__ __attribute__((aligned(16))) float fq_lds[];
     fq_body<INT4, W, P, CT>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                         reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
-                        bt.N[pi], tile0, min(tpw, tiles - tile0));
+                        bt.N[pi], tile, (int)threadIdx.x, fq_lds);
+}
+
+// The same launch with a workgroup of 4 waves split into 4 / wt wave groups, each on its own tile:
+// a short row (few units) cannot feed 4 waves, and with one wave per tile four times as many
+// independent tiles are in flight per CU, which is what hides the per-tile latencies of small K.
+// wt (waves per tile: 1, 2 or 4) is per problem; the wave groups of a workgroup work on tiles of
+// one problem, so they execute the same barriers.  A wave group past the problem's last tile runs
+// the body on an out-of-range tile: its loads return zeros and it stores nothing.
+template <bool INT4, int P>
+__global__ __launch_bounds__(256) void skinny_batch_sub_kernel(const SkinnyBatch bt) {
+    extern __shared__ __attribute__((aligned(16))) float fq_lds[];
+    const int blk = (int)blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
+    const int wt = bt.wt[pi];
+    const int wave = (int)threadIdx.x >> 6;
+    const int sub = wave / wt, per = 4 / wt;
+    const int t = (int)threadIdx.x - sub * wt * 64;
+    const int tile = (blk - (pi ? bt.tile_end[pi - 1] : 0)) * per + sub;
+    float* lds = fq_lds + (size_t)sub * bt.lds_floats[pi];
+    const uint16_t* X = reinterpret_cast<const uint16_t*>(bt.X[pi]);
+    const uint8_t* B = reinterpret_cast<const uint8_t*>(bt.B[pi]);
+    if (wt == 1) fq_body<INT4, 1, P, 1>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds);
+    else if (wt == 2) fq_body<INT4, 2, P, 1>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds);
+    else fq_body<INT4, 4, P, 1>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds);
 }
 
 int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
@@ -723,40 +725,33 @@ static size_t fq_lds_bytes(bool int4, int W, int CT, size_t M, size_t K) {
 #define SK_CT 1
 #endif
 
-// Waves per tile, MFMA column tiles per tile and tiles per workgroup for `rows16` groups of 16
-// weight rows whose longest row is K.
-// Waves: as many as the row can feed (about 4 units each), but with plenty of tiles fewer waves
-// per tile keep more independent tiles in flight and shorten the waits at the tile barriers
+// Waves per tile and MFMA column tiles per tile for `rows16` groups of 16 weight rows whose longest
+// row is K.  Waves: as many as the row can feed (about 4 units each), but with plenty of tiles fewer
+// waves per tile keep more independent tiles in flight and shorten the waits at the tile barriers
 // (16-shape sweep, 3840 tiles: 8 waves 3.5 TB/s, 4 waves 4.1, 2 waves 4.0, 1 wave 3.4).
-// Tiles per workgroup: the kernel can walk several tiles with the next tile's loads overlapping
-// this tile's epilogue, but on the same sweep that measured slower than one tile per workgroup
-// (4 waves: 4.3 TB/s at 1 tile, 3.9 at 2, 2.8 at 4; 8 waves: 3.8 at 2, 4.0 at 4) -- more
-// independent workgroups hide the per-tile latencies better -- so it stays 1.
-static void fq_shape(bool int4, size_t kmax, size_t rows16, int* W_out, int* ct_out, int* tpw_out) {
+static void fq_shape(bool int4, size_t kmax, size_t rows16, int* W_out, int* ct_out) {
     int W = skinny_waves(int4, kmax);
     int ct = SK_CT;
     if (W < ct) ct = 1;
     while (W > ct && (rows16 / ct) * (size_t)W > 16384) W /= 2;
     *W_out = W;
     *ct_out = ct;
-    *tpw_out = 1;
 }
 
-int g_skinny_tpw = 1;   // benchmarks only: tiles per workgroup of the 2xxxx variants
 int g_skinny_ct = 1;    // benchmarks only: column tiles per tile of the 2xxxx variants
 
-static hipError_t launch_fq(bool int4, int W, int ct, int tpw, const uint16_t* X, float* scales_out, const void* B,
+static hipError_t launch_fq(bool int4, int W, int ct, const uint16_t* X, float* scales_out, const void* B,
                             const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N, hipStream_t st) {
-    if (!skinny_fused_quant_ok(int4, M, K) || tpw < 1) return hipErrorInvalidValue;
+    if (!skinny_fused_quant_ok(int4, M, K)) return hipErrorInvalidValue;
     if (N * (int4 ? K / 2 : K) > (size_t(1) << 31)) return hipErrorInvalidValue;
     if (ct != SK_CT || W < 2 || fq_lds_bytes(int4, W, ct, M, K) > 64 * 1024) ct = 1;
     const size_t lds = fq_lds_bytes(int4, W, ct, M, K);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const size_t tiles = (N + SK_TN * ct - 1) / (SK_TN * ct);
-    const dim3 grid((unsigned)((tiles + tpw - 1) / tpw)), block(W * 64);
+    const dim3 grid((unsigned)tiles), block(W * 64);
 #define FQ_LAUNCH(I4, WW, CC)                                                                                     \
     skinny_fq_kernel<I4, WW, 4, CC><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C,       \
-                                                             (int)M, (int)K, (int)N, tpw)
+                                                             (int)M, (int)K, (int)N)
 #define FQ_CASE(WW)                                                        \
     case WW:                                                                \
         if (ct == 2 && WW >= 2) {                                           \
@@ -788,7 +783,7 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
         return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
                     : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
     if (variant >= 20000 && variant < 30000)   // fused quantization: A holds FP16 activations; W from the code
-        return launch_fq(int4, (variant - 20000) / 100, g_skinny_ct, g_skinny_tpw, reinterpret_cast<const uint16_t*>(A), nullptr, B,
+        return launch_fq(int4, (variant - 20000) / 100, g_skinny_ct, reinterpret_cast<const uint16_t*>(A), nullptr, B,
                          B_scales, C, M, K, N, st);
     switch (variant) {
         SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
@@ -803,9 +798,9 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
 hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
                                    const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
                                    hipStream_t st) {
-    int W, ct, tpw;
-    fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &ct, &tpw);
-    return launch_fq(int4, W, ct, tpw, X, scales_out, B, B_scales, C, M, K, N, st);
+    int W, ct;
+    fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &ct);
+    return launch_fq(int4, W, ct, X, scales_out, B, B_scales, C, M, K, N, st);
 }
 
 // Batched fused launch: every problem must satisfy skinny_fused_quant_ok and the alignment the
@@ -821,20 +816,14 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
         if (pr[i].K > kmax) kmax = pr[i].K;
     size_t total_tiles = 0;
     for (size_t i = 0; i < count; i++) total_tiles += (pr[i].N + SK_TN - 1) / SK_TN;
-    int W, ct, tpw;
-    fq_shape(int4, kmax, total_tiles, &W, &ct, &tpw);
+    int W, ct;
+    fq_shape(int4, kmax, total_tiles, &W, &ct);
 #ifdef SK_BATCH_W
     W = SK_BATCH_W;
-#endif
-#ifdef SK_BATCH_TPW
-    tpw = SK_BATCH_TPW;
 #endif
     if (ct == 2)
         for (size_t i = 0; i < count; i++)
             if (W < 2 || fq_lds_bytes(int4, W, 2, pr[i].M, pr[i].K) > 64 * 1024) ct = 1;
-#ifndef SK_TARGET_KB
-#define SK_TARGET_KB 0
-#endif
     // Longest rows first: a workgroup's run time grows with K, so the long ones start first and
     // the short ones fill the tail of the launch (16-shape sweep: 51 us against 56 in K*N order).
     size_t order[SK_MAXB];
@@ -847,20 +836,46 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
         const size_t l = fq_lds_bytes(int4, W, ct, q.M, q.K);
         if (l > 64 * 1024) return hipErrorInvalidValue;
         if (l > lds) lds = l;
-        const size_t ptiles = (q.N + SK_TN * ct - 1) / (SK_TN * ct);
-        int ptpw = tpw;
-        if (SK_TARGET_KB > 0) {   // equal bytes per workgroup: short rows take several tiles
-            const size_t tile_bytes = (size_t)SK_TN * ct * (int4 ? q.K / 2 : q.K);
-            ptpw = (int)std::max<size_t>(1, ((size_t)SK_TARGET_KB * 1024 + tile_bytes / 2) / tile_bytes);
-        }
-        bt.tpw[i] = ptpw;
-        tiles += (ptiles + ptpw - 1) / ptpw;   // workgroups
+        tiles += (q.N + SK_TN * ct - 1) / (SK_TN * ct);
         if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
         bt.tile_end[i] = (int)tiles;
         bt.X[i] = q.X; bt.B[i] = q.B; bt.Bs[i] = q.Bs; bt.C[i] = q.C;
         bt.M[i] = (int)q.M; bt.K[i] = (int)q.K; bt.N[i] = (int)q.N;
     }
     if (tiles == 0) return hipSuccess;
+    // Four waves per tile: the workgroup of 4 waves is cut into wave groups per problem, so that
+    // short rows (few units) get fewer waves per tile and more tiles in flight.
+#ifndef SK_SUB_K1
+#define SK_SUB_K1 0      // weight rows up to this many bytes take one wave per tile
+#endif
+#ifndef SK_SUB_K2
+#define SK_SUB_K2 1024   // ... up to this, two waves per tile
+#endif
+    if (W == 4 && ct == 1 && SK_SUB_K2 > 0) {
+        size_t blocks = 0, lds_sub = 0;
+        for (size_t i = 0; i < count; i++) {
+            const SkinnyProblem& q = pr[order[i]];
+            const size_t kb = int4 ? q.K / 2 : q.K;
+            const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
+            const size_t l = (fq_lds_bytes(int4, wt, 1, q.M, q.K) + 15) & ~(size_t)15;
+            bt.wt[i] = wt;
+            bt.lds_floats[i] = (int)(l / sizeof(float));
+            lds_sub = std::max(lds_sub, l * (4 / wt));
+            const size_t ptiles = (q.N + SK_TN - 1) / SK_TN, per = 4 / wt;
+            blocks += (ptiles + per - 1) / per;
+            bt.tile_end[i] = (int)blocks;
+        }
+        if (lds_sub <= 64 * 1024) {
+            if (int4) skinny_batch_sub_kernel<true, SK_BATCH_P><<<dim3((unsigned)blocks), dim3(256), lds_sub, st>>>(bt);
+            else skinny_batch_sub_kernel<false, SK_BATCH_P><<<dim3((unsigned)blocks), dim3(256), lds_sub, st>>>(bt);
+            return hipGetLastError();
+        }
+        size_t tt = 0;   // does not fit: one tile per workgroup
+        for (size_t i = 0; i < count; i++) {
+            tt += (pr[order[i]].N + SK_TN - 1) / SK_TN;
+            bt.tile_end[i] = (int)tt;
+        }
+    }
     const dim3 grid((unsigned)tiles), block(W * 64);
 #define FQB_CASE(WW)                                                                                      \
     case WW:                                                                                               \
