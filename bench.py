@@ -234,11 +234,13 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pm = json.load(f)
-        if pm.get("kernel") == "skinny_batch_kernel" and pm.get("algorithmic_bytes_per_launch") == step_bytes:
+        # the summary is of this command (default shapes): its write figure is the sweep's outputs
+        if str(pm.get("kernel", "")).startswith("skinny_batch") and \
+                pm.get("algorithmic_bytes_per_launch", step_bytes) == step_bytes:
             traffic = pm.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roofline = {"bound": "hbm", "kernel": "skinny_batch_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch)",
+    roofline = {"bound": "hbm", "kernel": "skinny_batch_sub_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "bytes_per_launch": step_bytes, "us_per_launch": round(ev_ms * 1e3, 2)}

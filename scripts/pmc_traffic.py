@@ -18,7 +18,7 @@ def mean_counter(path, kernel, counter):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-def main(fetch_csv, write_csv=None, kernel="skinny_batch_kernel"):
+def main(fetch_csv, write_csv=None, kernel="skinny_batch"):
     f, nf = mean_counter(fetch_csv, kernel, "FETCH_SIZE")
     out = {"kernel": kernel, "launches": nf, "FETCH_SIZE_KiB_raw": f,
            "read_bytes_per_launch": None if f is None else int(f * 1024 * 2),
