@@ -677,7 +677,10 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, c
     if (N * (INT4 ? K / 2 : K) > (size_t(1) << 31) || M * K > (size_t(1) << 31)) return hipErrorInvalidValue;
     // chunk of groups whose sums fit a 16 KB (M <= 4) / 32 KB LDS budget: a multiple of W units
     const int step = W * GPU_;
-    int SC = (int)(((M > 4 ? 32 : 16) * 1024) / (M * 64));
+#ifndef SK_GS_KB
+#define SK_GS_KB 72
+#endif
+    int SC = (int)(((M > 4 ? SK_GS_KB : 16) * 1024) / (M * 64));
     SC = (SC / step) * step;
     if (SC < step) SC = step;
     while (SC % 4) SC += step;   // chunk starts stay 16-byte aligned in the fp32 LDS rows
@@ -687,6 +690,18 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, c
     if (ALDS) lds += ((M * K + 15) & ~(size_t)15);
     if (ALDS && (SC < Gr || lds > 64 * 1024)) return hipErrorInvalidValue;   // single chunk only
     const dim3 grid((unsigned)((N + SK_TN - 1) / SK_TN)), block(W * 64);
+    if (lds > 64 * 1024) {   // more than 64 KB of dynamic LDS has to be allowed once per device
+        static bool attr_set[2][64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[gsums != nullptr][dev]) {
+            const void* fn = gsums != nullptr ? reinterpret_cast<const void*>(skinny_kernel<INT4, W, P, ALDS, true>)
+                                              : reinterpret_cast<const void*>(skinny_kernel<INT4, W, P, ALDS, false>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set[gsums != nullptr][dev] = true;
+        }
+    }
     if (gsums != nullptr)
         skinny_kernel<INT4, W, P, ALDS, true><<<grid, block, lds, st>>>(
             A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
