@@ -325,6 +325,9 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
     oo, go, uo, do, logits = half(batch, Hd), half(batch, F), half(batch, F), half(batch, Hd), half(batch, V)
     qr, kr, h2, xn2, act = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hd), half(batch, Hd), half(batch, F)
     ao = [None]
+    i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
+    xq, xs, xq2, xs2, aq, asc = i8(batch, Hd), f32(batch), i8(batch, Hd), f32(batch), i8(batch, F), f32(batch)
     batches = []
     if batch <= 4:
         for L in Ls:
@@ -344,14 +347,16 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
 
     def step():
         H.embedding(head[0], tok, head[1], 128, out=h0, check=False)
-        H.rms_norm(h0, Ls[0]["in_norm"], eps, out=x)
+        if batch <= 4:
+            H.rms_norm(h0, Ls[0]["in_norm"], eps, out=x)
+        else:
+            H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
         res = h0
         for li, L in enumerate(Ls):
             if batch <= 4:
                 batches[li][0].run()
             else:
-                q8, s8 = H.quantize_activations(x)
-                shared[li][0].run(q8, s8)
+                shared[li][0].run(xq, xs)      # quantized by the norm launch that produced it
             H.qk_norm_rope(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), L["q_norm"], L["k_norm"], eps, theta,
                            pos, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
             a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
@@ -365,16 +370,21 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                 H.kv_append_batched(kr.view(batch, Hkv, D), vo.view(batch, Hkv, D), kc[li], vc[li], ksc[li], vsc[li],
                                     lens)
             proj(a.view(batch, Hq * D), L["o"], oo)
-            H.add_rms_norm(res, oo, L["post_norm"], eps, out_sum=h2, out_norm=xn2)
-            if batch <= 4:
-                batches[li][1].run()
-            else:
-                q8, s8 = H.quantize_activations(xn2)
-                shared[li][1].run(q8, s8)
-            H.silu_multiply(go, uo, out=act)
-            proj(act, L["down"], do)
             nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
-            H.add_rms_norm(h2, do, nxt, eps, out_sum=hid, out_norm=x)   # residual add + the next norm
+            if batch <= 4:
+                H.add_rms_norm(res, oo, L["post_norm"], eps, out_sum=h2, out_norm=xn2)
+                batches[li][1].run()
+                H.silu_multiply(go, uo, out=act)
+                proj(act, L["down"], do)
+                H.add_rms_norm(h2, do, nxt, eps, out_sum=hid, out_norm=x)   # residual add + the next norm
+            else:   # norm / activation launches that also quantize the next matmul's input rows
+                H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
+                shared[li][1].run(xq2, xs2)
+                H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
+                H.matmul_int8(aq, asc, L["down"][0], L["down"][1], 128, out=do)
+                last = li + 1 == layers   # the lm_head below takes the FP16 row
+                H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq,
+                                     out_scales=xs)
             res = hid
         proj(x, head, logits)
         H.sample_greedy(logits, out=tok)
@@ -476,6 +486,22 @@ def extra_table(H, gen, big):
     ex["block_ops_prefill"] = rows
     del xa, xb, o1, o2, q4, k4, oq, ok, ga, up, oa
     torch.cuda.empty_cache()
+    # decode tail at the Qwen3 vocabulary: the stochastic sampler (engine defaults: temperature
+    # 0.6, top-p 0.95, top-k 20) against the greedy one, and the entropy figure
+    rows = {}
+    for batch in (1, 256):
+        lg = (torch.randn((batch, 151936), device="cuda", generator=gen) * 3).half()
+        dr = torch.rand((batch,), device="cuda", generator=gen)
+        smp = H.Sampler(batch, 151936)
+        tok = torch.empty((batch,), dtype=torch.int32, device="cuda")
+        ent = torch.empty((batch,), dtype=torch.float32, device="cuda")
+        ms_s = time_graph(lambda i: smp.sample(lg, 0.6, 0.95, 20, dr, out=tok, check=False), 8)
+        ms_g = time_graph(lambda i: H.sample_greedy(lg, out=tok), 8)
+        ms_e = time_graph(lambda i: H.logits_entropy(lg, out=ent), 8)
+        rows[f"b{batch}_v151936"] = {"sample_topk20_topp_us": round(ms_s * 1e3, 2), "greedy_us": round(ms_g * 1e3, 2),
+                                     "entropy_us": round(ms_e * 1e3, 2)}
+        del lg, smp
+    ex["decode_tail"] = rows
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512)}
     return ex

@@ -599,6 +599,44 @@ int cactus_hip_add_f16_clipped_dev(const cactus_half_t* a, const cactus_half_t* 
     return binary_dev(4, "add_clipped: null operand or launch failure", a, b, out, n, stream);
 }
 
+int cactus_hip_add_rms_norm_quant_f16_dev(const cactus_half_t* input, const cactus_half_t* addend,
+                                          const cactus_half_t* weight, cactus_half_t* sum_output,
+                                          cactus_half_t* norm_output, int8_t* q_output, float* scales_output,
+                                          size_t rows, size_t dims, float eps, void* stream) {
+    if (rows == 0 || dims == 0) return CACTUS_HIP_OK;
+    if (!input || !weight || !q_output || !scales_output) return fail(CACTUS_HIP_EINVAL, "add_rms_norm_quant: null operand");
+    if (addend && !sum_output) return fail(CACTUS_HIP_EINVAL, "add_rms_norm_quant: addend without sum_output");
+    if (dims > 16384) return fail(CACTUS_HIP_EINVAL, "add_rms_norm_quant: rows longer than 16384");
+    hipError_t e = launch_row_quant(0, input, addend, weight, addend ? sum_output : nullptr, norm_output, q_output,
+                                    scales_output, rows, dims, eps, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "add_rms_norm_quant launch", e);
+    return CACTUS_HIP_OK;
+}
+
+static int act_mul_quant_dev(int mode, const char* what, const cactus_half_t* gate, const cactus_half_t* up,
+                             cactus_half_t* act_output, int8_t* q_output, float* scales_output, size_t rows,
+                             size_t dims, void* stream) {
+    if (rows == 0 || dims == 0) return CACTUS_HIP_OK;
+    if (!gate || !up || !q_output || !scales_output) return fail(CACTUS_HIP_EINVAL, what);
+    if (dims > 16384) return fail(CACTUS_HIP_EINVAL, "activation x up + quant: rows longer than 16384");
+    hipError_t e = launch_row_quant(mode, gate, up, nullptr, nullptr, act_output, q_output, scales_output, rows, dims,
+                                    0.0f, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, what, e);
+    return CACTUS_HIP_OK;
+}
+int cactus_hip_silu_multiply_quant_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           cactus_half_t* act_output, int8_t* q_output, float* scales_output,
+                                           size_t rows, size_t dims, void* stream) {
+    return act_mul_quant_dev(1, "silu_multiply_quant: null operand or launch failure", gate, up, act_output, q_output,
+                             scales_output, rows, dims, stream);
+}
+int cactus_hip_gelu_multiply_quant_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           cactus_half_t* act_output, int8_t* q_output, float* scales_output,
+                                           size_t rows, size_t dims, void* stream) {
+    return act_mul_quant_dev(2, "gelu_multiply_quant: null operand or launch failure", gate, up, act_output, q_output,
+                             scales_output, rows, dims, stream);
+}
+
 int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows, size_t vocab_size,
                                      void* stream) {
     if (rows == 0) return CACTUS_HIP_OK;
@@ -631,6 +669,55 @@ int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* outp
     }
     hipError_t e = launch_argmax(logits, output, rows, vocab_size, sc, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "sample_greedy launch", e);
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_sample_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows, size_t vocab_size,
+                              float temperature, float top_p, size_t top_k, const float* draws, uint32_t* history,
+                              uint32_t* history_counts, cactus_half_t* workspace, int* status, void* stream) {
+    if (temperature == 0.0f && top_p <= 0.0f && top_k == 0)   // kernel_nn.cpp:451
+        return cactus_hip_sample_greedy_f16_dev(logits, output, rows, vocab_size, stream);
+    if (rows == 0) return CACTUS_HIP_OK;
+    if (!logits || !output) return fail(CACTUS_HIP_EINVAL, "sample: null operand");
+    if (vocab_size == 0) {   // every row: no maximum above -inf, token 0 (kernel_nn.cpp:590-595)
+        HIP_TRY(hipMemsetAsync(output, 0, rows * sizeof(uint32_t), S(stream)));
+        return CACTUS_HIP_OK;
+    }
+    if (!draws || !workspace) return fail(CACTUS_HIP_EINVAL, "sample: draws and workspace are required");
+    if ((history == nullptr) != (history_counts == nullptr))
+        return fail(CACTUS_HIP_EINVAL, "sample: history and history_counts go together");
+    hipError_t e = launch_sample(logits, workspace, output, status, rows, vocab_size, temperature, top_p, top_k, draws,
+                                 history, history_counts, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "sample launch", e);
+    return CACTUS_HIP_OK;
+}
+
+size_t cactus_hip_sample_max_survivors(void) { return 4096; }
+
+/* std::mt19937(seed) followed by std::uniform_real_distribution<float>(0, 1) as libstdc++ evaluates
+ * it: the first tempered output u, float(u) / 2^32, and the float below 1 when that rounds to 1. */
+float cactus_hip_sample_uniform(uint32_t seed) {
+    uint32_t mt[398];
+    mt[0] = seed;
+    for (uint32_t i = 1; i < 398; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i;
+    uint32_t y = (mt[0] & 0x80000000u) | (mt[1] & 0x7FFFFFFFu);
+    y = mt[397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9D2C5680u;
+    y ^= (y << 15) & 0xEFC60000u;
+    y ^= y >> 18;
+    float r = (float)y / 4294967296.0f;
+    if (r >= 1.0f) r = 0x1.fffffep-1f;
+    return r;
+}
+
+int cactus_hip_logits_entropy_f16_dev(const cactus_half_t* logits, float* output, size_t rows, size_t vocab_size,
+                                      void* stream) {
+    if (rows == 0) return CACTUS_HIP_OK;
+    if (!logits || !output) return fail(CACTUS_HIP_EINVAL, "logits_entropy: null operand");
+    if (vocab_size == 0) return fail(CACTUS_HIP_EINVAL, "logits_entropy: empty row");
+    hipError_t e = launch_entropy(logits, output, rows, vocab_size, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "logits_entropy launch", e);
     return CACTUS_HIP_OK;
 }
 

@@ -74,7 +74,7 @@ __device__ __forceinline__ uint16_t rms_out(uint16_t xb, uint16_t wb, float inv,
         const h16 p = bits2h(xb) * inv_h;
         return h2bits(p * bits2h(wb));
     }
-    return f2h(h2f(xb) * inv * h2f(wb));
+    return f2h_mul(h2f(xb) * inv, h2f(wb));   // all fp32, one conversion at the end (kernel_nn.cpp tail)
 }
 
 // ADD: the row normalized is a + b (one fp16 add per element, as cactus_add_f16), which is also
@@ -308,7 +308,7 @@ __device__ __forceinline__ uint16_t unary_one(uint16_t hb, bool vector_part) {
     if (OP == OP_SILU) {
         const float e = vector_part ? fast_exp(-x) : expf(-x);
         const float sig = 1.0f / (1.0f + e);
-        return f2h(x * sig);
+        return f2h_mul(x, sig);   // fp32 product, then fp32 -> fp16: two roundings (vmulq_f32 + vcvt_f16_f32)
     } else {
         if (vector_part) {
             const float x3 = (x * x) * x;
@@ -316,13 +316,13 @@ __device__ __forceinline__ uint16_t unary_one(uint16_t hb, bool vector_part) {
             inner = 0.7978845608028654f * inner;
             const float th = fast_tanh(inner);
             const float hx = 0.5f * x, ot = 1.0f + th;
-            return f2h(hx * ot);
+            return f2h_mul(hx, ot);
         }
         const float c1 = 0.044715f * x, c2 = c1 * x, x3 = c2 * x;
         const float sum = x + x3;
         const float inner = 0.7978845608028654f * sum;
         const float hx = 0.5f * x, ot = 1.0f + tanhf(inner);
-        return f2h(hx * ot);
+        return f2h_mul(hx, ot);
     }
 }
 
@@ -355,6 +355,77 @@ __global__ __launch_bounds__(256) void unary_kernel(const uint16_t* __restrict__
     } else {
         for (size_t i = c * 8; i < c * 8 + 8 && i < n; i++)
             out[i] = times(unary_one<OP>(in[i], i < vend), MUL ? mul[i] : (uint16_t)0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Row producer + activation quantization in one launch: the matmul that follows a norm or an
+// activation in a decoder block quantizes its FP16 input row by row (graph_ops_nn.cpp:35-66), and
+// at decode sizes that quantization is a launch of its own.  One 256-thread workgroup per row:
+//   MODE 0: y = rms_norm(a [+ b]) * w      (the sum is also written to sum_out when b is given)
+//   MODE 1: y = silu(a) * b                MODE 2: y = gelu(a) * b
+// each with the arithmetic of the kernels above, then scale = max(absmax(y) / 127, 1e-10) and
+// q = sat8(round(clamp(y * (1 / scale)))) -- ties to even for the row's whole groups of 8, away
+// from zero for its last dims % 8 elements, as cactus_fp16_to_int8 (kernel_quants.cpp:158-194).
+// LDS: the input row (MODE 0) and the produced row, binary16.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void row_quant_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                        const uint16_t* __restrict__ w, uint16_t* __restrict__ sum_out,
+                                                        uint16_t* __restrict__ y_out, int8_t* __restrict__ q_out,
+                                                        float* __restrict__ scales_out, int dims, float eps,
+                                                        size_t total_vend) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t rq_lds[];   // [2][dims]
+    __shared__ float red[4];
+    __shared__ float s_inv;
+    uint16_t* xin = rq_lds;
+    uint16_t* yb = rq_lds + dims;
+    const int t = threadIdx.x;
+    const size_t row = blockIdx.x, off = row * (size_t)dims;
+    float m = 0.0f;
+    if (MODE == 0) {
+        for (int i = t; i < dims; i += 256) {
+            const uint16_t v = b ? h2bits(bits2h(a[off + i]) + bits2h(b[off + i])) : a[off + i];
+            xin[i] = v;
+            if (sum_out) sum_out[off + i] = v;
+        }
+        __syncthreads();
+        if (t < 16) {
+            const float inv = row_inv_rms([&](int i) -> uint16_t { return xin[i]; }, dims, eps, t, 0);
+            if (t == 0) s_inv = inv;
+        }
+        __syncthreads();
+        const float inv = s_inv;
+        const h16 inv_h = (h16)inv;
+        const int simd_end = dims & ~7;
+        for (int i = t; i < dims; i += 256) {
+            const uint16_t y = rms_out(xin[i], w[i], inv, inv_h, i < simd_end);
+            yb[i] = y;
+            m = fmaxf(m, fabsf(h2f(y)));
+        }
+    } else {
+        for (int i = t; i < dims; i += 256) {
+            const uint16_t act = unary_one<MODE == 1 ? OP_SILU : OP_GELU>(a[off + i], off + i < total_vend);
+            const uint16_t y = h2bits(bits2h(act) * bits2h(b[off + i]));
+            yb[i] = y;
+            m = fmaxf(m, fabsf(h2f(y)));
+        }
+    }
+    m = wave_max(m);
+    if ((t & 63) == 0) red[t >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float scale = m / 127.0f;
+    if (scale < 1e-10f) scale = 1e-10f;
+    if (t == 0) scales_out[row] = scale;
+    const float iq = 1.0f / scale;
+    const int q8 = dims & ~7;
+    for (int i = t; i < dims; i += 256) {     // each thread re-reads the elements it produced
+        const uint16_t y = yb[i];
+        float q = h2f(y) * iq;
+        q = fmaxf(fminf(q, 127.0f), -128.0f);
+        q_out[off + i] = (int8_t)((i < q8) ? clamp_i8(rne_i32(q)) : (int)roundf(q));
+        if (y_out) y_out[off + i] = y;
     }
 }
 
@@ -607,6 +678,22 @@ hipError_t launch_unary_mul(int op, const uint16_t* in, const uint16_t* mul, uin
     const dim3 grid((unsigned)(((n + 7) / 8 + 255) / 256)), block(256);
     if (op == OP_SILU) unary_kernel<OP_SILU, true><<<grid, block, 0, st>>>(in, mul, out, n);
     else if (op == OP_GELU) unary_kernel<OP_GELU, true><<<grid, block, 0, st>>>(in, mul, out, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// mode 0: rms norm of a (+ b if given), 1: silu(a) * b, 2: gelu(a) * b; then row quantization
+hipError_t launch_row_quant(int mode, const uint16_t* a, const uint16_t* b, const uint16_t* w, uint16_t* sum_out,
+                            uint16_t* y_out, int8_t* q_out, float* scales_out, size_t rows, size_t dims, float eps,
+                            hipStream_t st) {
+    if (rows == 0 || dims == 0) return hipSuccess;
+    if (rows > 0x7FFFFFFFull || dims > 16384) return hipErrorInvalidValue;   // two binary16 rows in LDS
+    const dim3 grid((unsigned)rows), block(256);
+    const size_t lds = 2 * dims * sizeof(uint16_t);
+    const size_t vend = (rows * dims) & ~(size_t)7;
+    if (mode == 0) row_quant_kernel<0><<<grid, block, lds, st>>>(a, b, w, sum_out, y_out, q_out, scales_out, (int)dims, eps, vend);
+    else if (mode == 1) row_quant_kernel<1><<<grid, block, lds, st>>>(a, b, w, sum_out, y_out, q_out, scales_out, (int)dims, eps, vend);
+    else if (mode == 2) row_quant_kernel<2><<<grid, block, lds, st>>>(a, b, w, sum_out, y_out, q_out, scales_out, (int)dims, eps, vend);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -1,0 +1,310 @@
+// Stochastic token sampler and logits entropy on the device: the decode tail after lm_head.
+//
+// Roofline: launch latency / one pass over a logits row (2 B per element, read three to five times
+// from L2); the sequential parts (softmax sums in the reference's element order) run on one lane
+// over the few survivors of top-k.
+//
+// sample_kernel follows cactus_sample_f16 (cactus/kernel/kernel_nn.cpp:468-651) step by step, one
+// 1024-thread workgroup per logits row:
+//   1. scaled = half(logit * half(1/temperature))                     (:482-496; the bias written
+//      at :473-480 is overwritten by both branches and never has an effect)
+//   2. repetition penalty 1.1 for every occurrence of a token in the history (:502-513)
+//   3. top-k: values below the k-th largest become -inf (:515-535) -- the k-th largest of 16-bit
+//      values comes from two 256-bin histograms of an order-preserving key (exact, no sort)
+//   4. the survivors are gathered in index order (at most SAMPLE_CAP of them)
+//   5. top-p over the survivors in descending order (:537-588): fp32 exp / sum / cumulative sum in
+//      that order; entries from the first position > 0 whose cumulative mass exceeds top_p are cut.
+//      Equal logits keep ascending index order (std::sort leaves their order unspecified).
+//   6. softmax over what is left in index order, inverse-CDF draw against `draws[row]`, the two
+//      fallbacks, and the history update (:590-650)
+// exp is evaluated in double and rounded to float (the reference calls its platform's expf).
+#include "common.hip.h"
+#include "kernels.h"
+
+namespace cactus_hip {
+
+constexpr int SAMPLE_CAP = 4096;        // survivors of top-k held in LDS
+constexpr int SAMPLE_HISTORY = 128;     // kernel_nn.cpp:499
+constexpr uint16_t H_NEG_INF = 0xFC00;
+
+// larger value <=> larger key; -0 and +0 share a key
+__device__ __forceinline__ uint32_t order_key(uint16_t b) {
+    if (b == 0x8000) b = 0;
+    return (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
+}
+__device__ __forceinline__ uint16_t hmul(uint16_t a, uint16_t b) { return f2h(h2f(a) * h2f(b)); }
+__device__ __forceinline__ float exp_f(float x) { return (float)exp((double)x); }
+
+__global__ __launch_bounds__(1024) void sample_kernel(
+    const uint16_t* __restrict__ logits, uint16_t* __restrict__ work, uint32_t* __restrict__ out,
+    int* __restrict__ status, int vocab, int use_temp, uint16_t inv_temp, float top_p, int top_k,
+    const float* __restrict__ draws, uint32_t* __restrict__ history, uint32_t* __restrict__ hist_counts) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wcount[16];
+    __shared__ uint16_t sv_bits[SAMPLE_CAP];
+    __shared__ uint32_t sv_idx[SAMPLE_CAP];
+    __shared__ uint16_t order[SAMPLE_CAP];
+    __shared__ float pr[SAMPLE_CAP];
+    __shared__ float wmax[16];
+    __shared__ int s_hb, s_k2, s_kth, s_cut, s_token, s_push;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const size_t row = blockIdx.x;
+    const uint16_t* L = logits + row * (size_t)vocab;
+    uint16_t* F = work + row * (size_t)vocab;
+    uint32_t* H = history ? history + row * SAMPLE_HISTORY : nullptr;
+    const int hc = H ? min((int)hist_counts[row], SAMPLE_HISTORY) : 0;
+
+    // 1. temperature
+    for (int i = t; i < vocab; i += 1024) F[i] = use_temp ? hmul(L[i], inv_temp) : L[i];
+    __syncthreads();
+
+    // 2. repetition penalty: the first occurrence of a token applies it once per occurrence
+    if (t < hc) {
+        const uint32_t tok = H[t];
+        bool first = true;
+        int cnt = 0;
+        for (int j = 0; j < hc; j++) {
+            const bool same = H[j] == tok;
+            if (same && j < t) first = false;
+            cnt += same;
+        }
+        if (first && tok < (uint32_t)vocab) {
+            const uint16_t pinv = f2h(1.0f / 1.1f), pen = f2h(1.1f);
+            uint16_t v = F[tok];
+            for (int c = 0; c < cnt; c++) v = (h2f(v) > 0.0f) ? hmul(v, pinv) : hmul(v, pen);
+            F[tok] = v;
+        }
+    }
+    __syncthreads();
+
+    // 3. top-k threshold
+    if (top_k > 0 && top_k < vocab) {
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        for (int i = t; i < vocab; i += 1024) atomicAdd(&hist[order_key(F[i]) >> 8], 1u);
+        __syncthreads();
+        if (t == 0) {
+            uint32_t cum = 0;
+            int b = 255;
+            for (; b > 0; b--) {
+                if (cum + hist[b] >= (uint32_t)top_k) break;
+                cum += hist[b];
+            }
+            s_hb = b;
+            s_k2 = top_k - (int)cum;     // rank wanted inside bin b (>= 1)
+        }
+        __syncthreads();
+        const int hb = s_hb;
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        for (int i = t; i < vocab; i += 1024) {
+            const uint32_t k = order_key(F[i]);
+            if ((int)(k >> 8) == hb) atomicAdd(&hist[k & 255], 1u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint32_t cum = 0;
+            int b = 255;
+            for (; b > 0; b--) {
+                if (cum + hist[b] >= (uint32_t)s_k2) break;
+                cum += hist[b];
+            }
+            s_kth = (hb << 8) | b;
+        }
+        __syncthreads();
+        const uint32_t kth = (uint32_t)s_kth;
+        for (int i = t; i < vocab; i += 1024)
+            if (order_key(F[i]) < kth) F[i] = H_NEG_INF;
+        __syncthreads();
+    }
+
+    // 4. survivors in index order: wave w owns one contiguous range
+    const int per = (((vocab + 15) / 16) + 63) & ~63;
+    const int lo = w * per, hi = min(vocab, lo + per);
+    {
+        uint32_t c = 0;
+        for (int i0 = lo; i0 < hi; i0 += 64) {
+            const int i = i0 + lane;
+            const bool alive = i < hi && F[i] != H_NEG_INF;
+            c += (uint32_t)__popcll(__ballot(alive));
+        }
+        if (lane == 0) wcount[w] = c;
+    }
+    __syncthreads();
+    uint32_t base = 0, n_all = 0;
+    for (int j = 0; j < 16; j++) {
+        if (j < w) base += wcount[j];
+        n_all += wcount[j];
+    }
+    if (n_all > (uint32_t)SAMPLE_CAP) {      // uniform over the workgroup
+        if (t == 0) { out[row] = 0xFFFFFFFFu; if (status) atomicExch(status, 1); }
+        return;
+    }
+    const int n = (int)n_all;
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const uint16_t v = i < hi ? F[i] : H_NEG_INF;
+        const bool alive = i < hi && v != H_NEG_INF;
+        const unsigned long long m = __ballot(alive);
+        if (alive) {
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            sv_bits[pos] = v;
+            sv_idx[pos] = (uint32_t)i;
+        }
+        base += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+
+    // 5. top-p
+    if (top_p > 0.0f && top_p < 1.0f && n > 0) {
+        for (int s = t; s < n; s += 1024) {
+            const uint32_t ks = order_key(sv_bits[s]);
+            int rank = 0;
+            for (int j = 0; j < n; j++) {
+                const uint32_t kj = order_key(sv_bits[j]);
+                rank += (kj > ks) || (kj == ks && j < s);
+            }
+            order[rank] = (uint16_t)s;
+        }
+        __syncthreads();
+        const float mx = h2f(sv_bits[order[0]]);
+        for (int r = t; r < n; r += 1024) pr[r] = exp_f(h2f(sv_bits[order[r]]) - mx);
+        __syncthreads();
+        if (t == 0) {
+            float sum = 0.0f;
+            for (int r = 0; r < n; r++) sum += pr[r];
+            float cum = 0.0f;
+            int cut = n;
+            for (int r = 0; r < n; r++) {
+                cum += pr[r] / sum;
+                if (cum > top_p && r > 0) { cut = r; break; }
+            }
+            s_cut = cut;
+        }
+        __syncthreads();
+        const int cut = s_cut;
+        for (int r = cut + t; r < n; r += 1024) sv_bits[order[r]] = H_NEG_INF;
+        __syncthreads();
+    }
+
+    // 6. softmax in index order and the draw
+    float m = -INFINITY;
+    for (int s = t; s < n; s += 1024)
+        if (sv_bits[s] != H_NEG_INF) m = fmaxf(m, h2f(sv_bits[s]));
+    m = wave_max(m);
+    if (lane == 0) wmax[w] = m;
+    __syncthreads();
+    m = wmax[0];
+    for (int j = 1; j < 16; j++) m = fmaxf(m, wmax[j]);
+    for (int s = t; s < n; s += 1024)
+        pr[s] = (sv_bits[s] == H_NEG_INF) ? 0.0f : exp_f(h2f(sv_bits[s]) - m);
+    __syncthreads();
+    if (t == 0) {
+        int token = 0, push = 0;
+        if (n > 0 && m != -INFINITY) {
+            float sum = 0.0f;
+            for (int s = 0; s < n; s++) sum += pr[s];
+            if (sum != 0.0f) {
+                const float sample = draws[row];
+                push = 1;
+                int found = -1;
+                if (sample <= 0.0f) {
+                    found = 0;               // the running sum is >= 0 at element 0 already
+                } else {
+                    float cum = 0.0f;
+                    for (int s = 0; s < n; s++) {
+                        cum += pr[s] / sum;
+                        if (cum >= sample) { found = (int)sv_idx[s]; break; }
+                    }
+                    if (found < 0) {
+                        for (int s = n - 1; s >= 0; s--)
+                            if (pr[s] / sum > 0.0f) { found = (int)sv_idx[s]; break; }
+                    }
+                    if (found < 0) found = 0;
+                }
+                token = found;
+            }
+        }
+        out[row] = (uint32_t)token;
+        s_token = token;
+        s_push = push;
+    }
+    __syncthreads();
+    if (H && s_push) {     // kernel_nn.cpp:627-630: append, dropping the oldest beyond 128
+        const uint32_t tok = (uint32_t)s_token;
+        if (hc < SAMPLE_HISTORY) {
+            if (t == 0) { H[hc] = tok; hist_counts[row] = (uint32_t)(hc + 1); }
+        } else {
+            uint32_t nxt = 0;
+            if (t < SAMPLE_HISTORY - 1) nxt = H[t + 1];
+            __syncthreads();
+            if (t < SAMPLE_HISTORY - 1) H[t] = nxt;
+            if (t == SAMPLE_HISTORY - 1) H[t] = tok;
+        }
+    }
+}
+
+// engine_model.cpp:255-290: entropy of softmax(logits) in double, divided by log(vocab).  The
+// reference adds in element order; here partial sums are combined as a tree (the float result
+// differs by at most an ulp).
+__global__ __launch_bounds__(1024) void entropy_kernel(const uint16_t* __restrict__ logits, float* __restrict__ out,
+                                                       int vocab) {
+    __shared__ double red[16];
+    __shared__ float wmax[16];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint16_t* L = logits + (size_t)blockIdx.x * vocab;
+    float m = -INFINITY;
+    for (int i = t; i < vocab; i += 1024) m = fmaxf(m, h2f(L[i]));
+    m = wave_max(m);
+    if (lane == 0) wmax[w] = m;
+    __syncthreads();
+    m = wmax[0];
+    for (int j = 1; j < 16; j++) m = fmaxf(m, wmax[j]);
+    auto block_sum = [&](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        double s = 0.0;
+        for (int j = 0; j < 16; j++) s += red[j];
+        return s;
+    };
+    double se = 0.0;
+    for (int i = t; i < vocab; i += 1024) se += exp((double)(h2f(L[i]) - m));
+    se = block_sum(se);
+    const double lse = (double)m + log(se);
+    double ent = 0.0;
+    for (int i = t; i < vocab; i += 1024) {
+        const double lp = (double)h2f(L[i]) - lse;
+        const double p = exp(lp);
+        if (p > 1e-10) ent -= p * lp;
+    }
+    ent = block_sum(ent);
+    if (t == 0) out[blockIdx.x] = (float)(ent / log((double)vocab));
+}
+
+hipError_t launch_sample(const uint16_t* logits, uint16_t* work, uint32_t* out, int* status, size_t rows,
+                         size_t vocab, float temperature, float top_p, size_t top_k, const float* draws,
+                         uint32_t* history, uint32_t* hist_counts, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (vocab == 0 || vocab > 0x7FFFFFFFull || rows > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const int use_temp = temperature > 0.0f;
+    // half(1 / temperature) as the reference's static_cast<__fp16> gives it (round to nearest even)
+    const _Float16 it = use_temp ? (_Float16)(1.0f / temperature) : (_Float16)0.0f;
+    uint16_t itb;
+    __builtin_memcpy(&itb, &it, 2);
+    const int k = top_k > vocab ? (int)vocab : (int)top_k;
+    sample_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, work, out, status, (int)vocab, use_temp, itb,
+                                                               top_p, k, draws, history, hist_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_entropy(const uint16_t* logits, float* out, size_t rows, size_t vocab, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    if (vocab == 0 || vocab > 0x7FFFFFFFull || rows > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    entropy_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, out, (int)vocab);
+    return hipGetLastError();
+}
+
+}  // namespace cactus_hip

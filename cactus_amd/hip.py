@@ -76,9 +76,16 @@ SIGNATURES = {
     "cactus_hip_add_rms_norm_f16_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _f, _vp]),
     "cactus_hip_qk_norm_rope_f16_dev": (_i, [_vp] * 6 + [_sz] * 5 + [_f, _sz, _f, _vp]),
     "cactus_hip_silu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_add_rms_norm_quant_f16_dev": (_i, [_vp] * 7 + [_sz, _sz, _f, _vp]),
+    "cactus_hip_silu_multiply_quant_f16_dev": (_i, [_vp] * 5 + [_sz, _sz, _vp]),
+    "cactus_hip_gelu_multiply_quant_f16_dev": (_i, [_vp] * 5 + [_sz, _sz, _vp]),
     "cactus_hip_gelu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_quantize_kv_pair_fp16_to_int8_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp]),
     "cactus_hip_sample_greedy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "cactus_hip_sample_f16_dev": (_i, [_vp, _vp, _sz, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cactus_hip_sample_max_survivors": (_sz, []),
+    "cactus_hip_sample_uniform": (_f, [C.c_uint32]),
+    "cactus_hip_logits_entropy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
     "cactus_hip_kv_append_batched_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp, _sz, _sz, _sz, _vp]),
     "cactus_hip_indices_to_int32_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
     "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
@@ -291,6 +298,43 @@ def add_rms_norm(a, b, weight, eps=1e-5, out_sum=None, out_norm=None):
     return s, n
 
 
+def add_rms_norm_quant(a, b, weight, eps=1e-5, out_sum=None, out_norm=None, out_q=None, out_scales=None,
+                       want_norm=False):
+    """rms_norm(a + b, weight) (b may be None) and its row-wise INT8 quantization, one launch.
+    Returns (sum or None, norm or None, q int8 [rows, dims], scales fp32 [rows])."""
+    _dev(a, torch.float16); _dev(weight, torch.float16)
+    rows, dims = a.shape
+    s = None
+    if b is not None:
+        _dev(b, torch.float16)
+        s = out_sum if out_sum is not None else torch.empty_like(a)
+    n = out_norm if out_norm is not None else (torch.empty_like(a) if want_norm else None)
+    q = out_q if out_q is not None else torch.empty((rows, dims), dtype=torch.int8, device=a.device)
+    sc = out_scales if out_scales is not None else torch.empty((rows,), dtype=torch.float32, device=a.device)
+    _check(lib.cactus_hip_add_rms_norm_quant_f16_dev(_p(a), _p(b), _p(weight), _p(s), _p(n), _p(q), _p(sc), rows, dims,
+                                                     float(eps), _stream()))
+    return s, n, q, sc
+
+
+def _act_multiply_quant(fn, gate, up, out_act, out_q, out_scales, want_act):
+    _dev(gate, torch.float16); _dev(up, torch.float16)
+    rows, dims = gate.shape
+    act = out_act if out_act is not None else (torch.empty_like(gate) if want_act else None)
+    q = out_q if out_q is not None else torch.empty((rows, dims), dtype=torch.int8, device=gate.device)
+    sc = out_scales if out_scales is not None else torch.empty((rows,), dtype=torch.float32, device=gate.device)
+    _check(fn(_p(gate), _p(up), _p(act), _p(q), _p(sc), rows, dims, _stream()))
+    return act, q, sc
+
+
+def silu_multiply_quant(gate, up, out_act=None, out_q=None, out_scales=None, want_act=False):
+    """silu(gate) * up of [rows, dims] and its row-wise INT8 quantization, one launch."""
+    return _act_multiply_quant(lib.cactus_hip_silu_multiply_quant_f16_dev, gate, up, out_act, out_q, out_scales, want_act)
+
+
+def gelu_multiply_quant(gate, up, out_act=None, out_q=None, out_scales=None, want_act=False):
+    return _act_multiply_quant(lib.cactus_hip_gelu_multiply_quant_f16_dev, gate, up, out_act, out_q, out_scales, want_act)
+
+
 def qk_norm_rope(q, k, q_weight, k_weight, eps, theta, start_pos=0, out_q=None, out_k=None):
     """Per-head RMS norm then RoPE of q [batch, seq, Hq, D] and k [batch, seq, Hkv, D], one launch."""
     _dev(q, torch.float16); _dev(k, torch.float16)
@@ -391,6 +435,52 @@ def sample_greedy(logits, out=None):
     rows, vocab = logits.shape
     o = out if out is not None else torch.empty((rows,), dtype=torch.int32, device=logits.device)
     _check(lib.cactus_hip_sample_greedy_f16_dev(_p(logits), _p(o), rows, vocab, _stream()))
+    return o
+
+
+def sample_uniform(seed):
+    """The uniform draw the reference takes from std::mt19937(seed) (host computation)."""
+    return float(lib.cactus_hip_sample_uniform(seed & 0xFFFFFFFF))
+
+
+class Sampler:
+    """cactus_sample_f16 for `rows` independent sequences: keeps each row's token history (the
+    reference's process-wide history of the last 128 sampled tokens), the workspace and the status
+    flag on the device.  draws: float32 [rows] uniform numbers (sample_uniform(seed) per row)."""
+
+    def __init__(self, rows, vocab, device="cuda"):
+        self.rows, self.vocab = rows, vocab
+        self.history = torch.zeros((rows, 128), dtype=torch.int32, device=device)
+        self.counts = torch.zeros((rows,), dtype=torch.int32, device=device)
+        self.work = torch.empty((rows, vocab), dtype=torch.float16, device=device)
+        self.status = torch.zeros((1,), dtype=torch.int32, device=device)
+
+    def sample(self, logits, temperature, top_p, top_k, draws, out=None, check=True):
+        _dev(logits, torch.float16)
+        rows, vocab = logits.shape
+        if (rows, vocab) != (self.rows, self.vocab):
+            raise ValueError("Sampler: logits shape does not match")
+        _dev(draws, torch.float32)
+        o = out if out is not None else torch.empty((rows,), dtype=torch.int32, device=logits.device)
+        _check(lib.cactus_hip_sample_f16_dev(_p(logits), _p(o), rows, vocab, temperature, top_p, top_k, _p(draws),
+                                             _p(self.history), _p(self.counts), _p(self.work), _p(self.status),
+                                             _stream()))
+        if check and int(self.status.item()) != 0:
+            self.status.zero_()
+            raise RuntimeError("sample: more than %d logits survive top-k in a row"
+                               % lib.cactus_hip_sample_max_survivors())
+        return o
+
+    def history_of(self, row):
+        return self.history[row, : int(self.counts[row].item())].cpu().tolist()
+
+
+def logits_entropy(logits, out=None):
+    """Entropy of softmax(row) / log(vocab) per row of fp16 [rows, vocab] -> float32 [rows]."""
+    _dev(logits, torch.float16)
+    rows, vocab = logits.shape
+    o = out if out is not None else torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    _check(lib.cactus_hip_logits_entropy_f16_dev(_p(logits), _p(o), rows, vocab, _stream()))
     return o
 
 

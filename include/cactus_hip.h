@@ -231,6 +231,24 @@ int cactus_hip_silu_multiply_f16_dev(const cactus_half_t* gate, const cactus_hal
 int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
                                      cactus_half_t* output, size_t num_elements, void* stream);
 
+/* A row producer followed by the activation quantization of the matmul that consumes it
+ * (quantize_activations_fp16_to_int8, graph_ops_nn.cpp:35-66), one launch, one workgroup per row:
+ * results equal cactus_hip_add_rms_norm_f16_dev / cactus_hip_silu_multiply_f16_dev /
+ * cactus_hip_gelu_multiply_f16_dev followed by cactus_hip_quantize_activations_dev bit for bit.
+ * addend may be NULL (plain norm; sum_output unused); norm_output / act_output may be NULL when
+ * only the quantized row is needed.  dims <= 16384. */
+int cactus_hip_add_rms_norm_quant_f16_dev(const cactus_half_t* input, const cactus_half_t* addend,
+                                          const cactus_half_t* weight, cactus_half_t* sum_output,
+                                          cactus_half_t* norm_output, int8_t* q_output,
+                                          float* scales_output, size_t rows, size_t dims, float eps,
+                                          void* stream);
+int cactus_hip_silu_multiply_quant_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           cactus_half_t* act_output, int8_t* q_output,
+                                           float* scales_output, size_t rows, size_t dims, void* stream);
+int cactus_hip_gelu_multiply_quant_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           cactus_half_t* act_output, int8_t* q_output,
+                                           float* scales_output, size_t rows, size_t dims, void* stream);
+
 /* compute_embedding_node (graph_ops_tensor.cpp:226-320): output row i = row indices[i] of the
  * table; INT8 rows with per-group fp16 scales dequantize as half(float(q) * float(scale))
  * (:243-254), FP16 rows are copied (:301-316).  indices: device int32[num_indices].  An index
@@ -239,9 +257,41 @@ int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_hal
 /* The greedy branch of cactus_sample_f16 (kernel.h; kernel_nn.cpp:446-466: temperature 0, no
  * top-p / top-k): output[r] = first index of the maximum of logits[r, :] (NaNs never win; a NaN
  * in element 0 gives 0; vocab_size 0 gives 0).  The stochastic branches (:468-651: host RNG,
- * process-wide token history) are not provided. */
+ * process-wide token history) are cactus_hip_sample_f16_dev below. */
 int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows,
                                      size_t vocab_size, void* stream);
+
+/* cactus_sample_f16 (kernel.h:130-133; kernel_nn.cpp:446-651) for `rows` independent logits rows
+ * (the reference samples one row per call, compute_sample_node graph_ops_sample.cpp:24-32):
+ * temperature scaling in fp16, repetition penalty 1.1 per occurrence in the row's token history,
+ * top-k, top-p, softmax and the inverse-CDF draw, in the reference's order of fp32 operations.
+ *   - temperature == 0 && top_p <= 0 && top_k == 0 is the greedy branch (draws, history and
+ *     workspace may then be NULL).
+ *   - draws: device float[rows], the uniform number of each row (the reference draws it from
+ *     std::mt19937(random_seed), :617-620: cactus_hip_sample_uniform gives that number for a seed).
+ *   - history: device uint32[rows, 128] and history_counts: device uint32[rows] stand for the
+ *     reference's process-wide `token_history` (:498-500), one per row; the sampled token is
+ *     appended (oldest dropped beyond 128).  Both NULL: no penalty, nothing recorded.
+ *   - the logit bias arguments of the reference are not taken: it overwrites the biased values
+ *     before use (:473-496), so they never change a result.
+ *   - workspace: device half[rows, vocab_size] scratch.
+ *   - at most cactus_hip_sample_max_survivors() logits of a row may survive top-k (ties with the
+ *     k-th value included; top_k == 0 keeps all finite ones): a row with more gets token
+ *     0xFFFFFFFF and *status (device int, may be NULL, cleared by the caller) is set to 1.
+ *   - equal logits keep ascending index order in the top-p pass (the reference leaves it to
+ *     std::sort); exp is computed in double and rounded (the reference uses its libm's expf). */
+int cactus_hip_sample_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows,
+                              size_t vocab_size, float temperature, float top_p, size_t top_k,
+                              const float* draws, uint32_t* history, uint32_t* history_counts,
+                              cactus_half_t* workspace, int* status, void* stream);
+size_t cactus_hip_sample_max_survivors(void);
+float cactus_hip_sample_uniform(uint32_t seed);   /* host computation, no device work */
+
+/* The confidence figure of Model::decode (engine_model.cpp:255-290): entropy of softmax(row) in
+ * double precision divided by log(vocab_size), one float per row.  The reference adds in element
+ * order; partial sums are combined as a tree here (the float result may differ in the last bit). */
+int cactus_hip_logits_entropy_f16_dev(const cactus_half_t* logits, float* output, size_t rows,
+                                      size_t vocab_size, void* stream);
 
 /* The index conversion of compute_embedding_node (graph_ops_tensor.cpp:257-275: indices held as
  * FP32 or INT8 values, `static_cast<size_t>(indices[i])`): precision 2 = float, 0 = int8; values

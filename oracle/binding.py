@@ -57,6 +57,12 @@ def _load():
     lib.oracle_embedding_f16.argtypes = [vp, vp, vp, sz, sz, sz]
     lib.oracle_sample_greedy_f16.restype = C.c_uint32
     lib.oracle_sample_greedy_f16.argtypes = [vp, sz]
+    lib.oracle_sample_f16.restype = C.c_uint32
+    lib.oracle_sample_f16.argtypes = [vp, sz, C.c_float, C.c_float, sz, C.c_float, vp, vp]
+    lib.oracle_sample_uniform.restype = C.c_float
+    lib.oracle_sample_uniform.argtypes = [C.c_uint32]
+    lib.oracle_logits_entropy_f16.restype = C.c_float
+    lib.oracle_logits_entropy_f16.argtypes = [vp, sz]
     return lib
 
 
@@ -258,3 +264,24 @@ def sample_greedy(logits):
     logits = _c(logits, np.uint16)
     return np.array([lib.oracle_sample_greedy_f16(_p(r), r.size) for r in logits.reshape(-1, logits.shape[-1])],
                     np.uint32)
+
+
+def sample(logits, temperature, top_p, top_k, draw, history=None):
+    """One row.  history: list of earlier tokens (the reference's process-wide token_history); the
+    updated list is returned beside the token."""
+    logits = _c(logits, np.uint16).reshape(-1)
+    h = np.zeros(128, np.uint32)
+    n = 0 if history is None else len(history)
+    h[:n] = history if n else []
+    cnt = C.c_size_t(n)
+    tok = lib.oracle_sample_f16(_p(logits), logits.size, temperature, top_p, top_k, draw, _p(h), C.byref(cnt))
+    return int(tok), h[:cnt.value].tolist()
+
+
+def sample_uniform(seed):
+    return float(lib.oracle_sample_uniform(seed & 0xFFFFFFFF))
+
+
+def logits_entropy(logits):
+    logits = _c(logits, np.uint16).reshape(-1)
+    return float(lib.oracle_logits_entropy_f16(_p(logits), logits.size))

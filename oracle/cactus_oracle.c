@@ -821,3 +821,149 @@ uint32_t oracle_sample_greedy_f16(const uint16_t* logits, size_t vocab_size) {
     }
     return (uint32_t)best_idx;
 }
+
+/* ---------------------------------------------------------------------------------------
+ * Stochastic branch of cactus_sample_f16: cactus/kernel/kernel_nn.cpp:468-651.
+ * PARITY UNPINNED beyond reading: the reference has no known-answer test for it.  Two points
+ * are implementation-defined in the reference and fixed here: std::sort's order of equal
+ * logits in the top-p pass (:546; here equal values keep ascending index order) and
+ * std::exp(float) (here this host's libm expf).
+ *
+ * history / hist_count: the reference's process-wide `token_history` (:498-500), passed in and
+ * updated in place (at most 128 entries, oldest first). */
+static int sample_desc_cmp(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x < y) - (x > y);
+}
+typedef struct { float v; uint32_t idx; } sample_pair;
+static int sample_pair_cmp(const void* a, const void* b) {
+    const sample_pair* x = (const sample_pair*)a; const sample_pair* y = (const sample_pair*)b;
+    if (x->v > y->v) return -1;
+    if (x->v < y->v) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+static void sample_push(uint32_t* history, size_t* hist_count, uint32_t tok) {   /* :627-630 */
+    if (!history) return;
+    if (*hist_count >= 128) {
+        memmove(history, history + 1, 127 * sizeof(uint32_t));
+        history[127] = tok;
+        *hist_count = 128;
+    } else {
+        history[(*hist_count)++] = tok;
+    }
+}
+
+uint32_t oracle_sample_f16(const uint16_t* logits, size_t vocab_size, float temperature, float top_p,
+                           size_t top_k, float sample, uint32_t* history, size_t* hist_count) {
+    if (temperature == 0.0f && top_p <= 0.0f && top_k == 0) return oracle_sample_greedy_f16(logits, vocab_size);
+    const float NEG_INF = -INFINITY;
+    float* f = (float*)malloc((vocab_size + 1) * sizeof(float));   /* fp16 values held as floats */
+    /* :469-496 -- the bias written at :473-480 is overwritten by both branches of :482-496 */
+    if (temperature > 0) {
+        const float inv_temp = oracle_h2f(oracle_f2h(1.0f / temperature));
+        for (size_t i = 0; i < vocab_size; i++) f[i] = oracle_h2f(oracle_f2h(oracle_h2f(logits[i]) * inv_temp));
+    } else {
+        for (size_t i = 0; i < vocab_size; i++) f[i] = oracle_h2f(logits[i]);
+    }
+    /* :502-513 repetition penalty, once per occurrence in the history */
+    if (history && *hist_count > 0) {
+        const float pinv = oracle_h2f(oracle_f2h(1.0f / 1.1f)), pen = oracle_h2f(oracle_f2h(1.1f));
+        for (size_t h = 0; h < *hist_count; h++) {
+            const uint32_t tok = history[h];
+            if (tok < vocab_size) f[tok] = oracle_h2f(oracle_f2h(f[tok] > 0.0f ? f[tok] * pinv : f[tok] * pen));
+        }
+    }
+    /* :515-535 top-k: everything below the k-th largest value becomes -inf */
+    if (top_k > 0 && top_k < vocab_size) {
+        float* s = (float*)malloc(vocab_size * sizeof(float));
+        memcpy(s, f, vocab_size * sizeof(float));
+        qsort(s, vocab_size, sizeof(float), sample_desc_cmp);
+        const float kth = s[top_k - 1];
+        free(s);
+        for (size_t i = 0; i < vocab_size; i++) if (f[i] < kth) f[i] = NEG_INF;
+    }
+    /* :537-588 top-p over the survivors in descending order */
+    if (top_p > 0.0f && top_p < 1.0f) {
+        sample_pair* sp = (sample_pair*)malloc((vocab_size + 1) * sizeof(sample_pair));
+        size_t n = 0;
+        for (size_t i = 0; i < vocab_size; i++) if (f[i] != NEG_INF) { sp[n].v = f[i]; sp[n].idx = (uint32_t)i; n++; }
+        qsort(sp, n, sizeof(sample_pair), sample_pair_cmp);
+        const float mx = n ? sp[0].v : 0.0f;
+        float* pr = (float*)malloc((n + 1) * sizeof(float));
+        float sum = 0.0f;
+        for (size_t i = 0; i < n; i++) { pr[i] = expf(sp[i].v - mx); sum += pr[i]; }
+        for (size_t i = 0; i < n; i++) pr[i] /= sum;
+        float cum = 0.0f;
+        int reached = 0;
+        for (size_t i = 0; i < n; i++) {
+            cum += pr[i];
+            if (cum > top_p && i > 0) reached = 1;
+            if (reached) f[sp[i].idx] = NEG_INF;
+        }
+        free(pr);
+        free(sp);
+    }
+    /* :590-615 softmax over what is left */
+    uint32_t result = 0;
+    int push = 0;
+    float mx = vocab_size ? f[0] : NEG_INF;
+    for (size_t i = 1; i < vocab_size; i++) if (mx < f[i]) mx = f[i];
+    if (vocab_size == 0 || mx == NEG_INF) { free(f); return 0; }
+    float* probs = (float*)malloc(vocab_size * sizeof(float));
+    float sum = 0.0f;
+    for (size_t i = 0; i < vocab_size; i++) {
+        if (f[i] == NEG_INF) probs[i] = 0.0f;
+        else { probs[i] = expf(f[i] - mx); sum += probs[i]; }
+    }
+    if (sum == 0.0f) { free(probs); free(f); return 0; }
+    for (size_t i = 0; i < vocab_size; i++) probs[i] /= sum;
+    /* :617-650 inverse-CDF draw, then the two fallbacks */
+    float cum = 0.0f;
+    size_t i = 0;
+    for (; i < vocab_size; i++) {
+        cum += probs[i];
+        if (cum >= sample) { result = (uint32_t)i; push = 1; break; }
+    }
+    if (!push) {
+        for (size_t j = vocab_size; j > 0; j--) if (probs[j - 1] > 0.0f) { result = (uint32_t)(j - 1); push = 1; break; }
+    }
+    if (!push) { result = 0; push = 1; }
+    sample_push(history, hist_count, result);
+    free(probs);
+    free(f);
+    return result;
+}
+
+/* The draw of kernel_nn.cpp:617-620 for a given nonzero seed: std::mt19937(seed), then
+ * std::uniform_real_distribution<float>(0, 1) as libstdc++ implements it (one 32-bit output,
+ * float(u) / 2^32, a result of 1 replaced by the float below 1). */
+float oracle_sample_uniform(uint32_t seed) {
+    uint32_t mt[624];
+    mt[0] = seed;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    uint32_t y = (mt[0] & 0x80000000u) | (mt[1] & 0x7FFFFFFFu);
+    y = mt[397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908B0DFu : 0u);
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9D2C5680u;
+    y ^= (y << 15) & 0xEFC60000u;
+    y ^= y >> 18;
+    float r = (float)y / 4294967296.0f;
+    if (r >= 1.0f) r = nextafterf(1.0f, 0.0f);
+    return r;
+}
+
+/* Normalised entropy of the last logits row: cactus/engine/engine_model.cpp:255-290 */
+float oracle_logits_entropy_f16(const uint16_t* logits, size_t vocab_size) {
+    float mx = oracle_h2f(logits[0]);
+    for (size_t i = 1; i < vocab_size; i++) { const float v = oracle_h2f(logits[i]); if (mx < v) mx = v; }
+    double sum_exp = 0.0;
+    for (size_t i = 0; i < vocab_size; i++) sum_exp += exp((double)(oracle_h2f(logits[i]) - mx));
+    const double lse = (double)mx + log(sum_exp);
+    double entropy = 0.0;
+    for (size_t i = 0; i < vocab_size; i++) {
+        const double lp = (double)oracle_h2f(logits[i]) - lse;
+        const double p = exp(lp);
+        if (p > 1e-10) entropy -= p * lp;
+    }
+    return (float)(entropy / log((double)vocab_size));
+}

@@ -106,6 +106,10 @@ int  oracle_embedding_int8(const int8_t* emb, const uint16_t* scales, const int3
                            uint16_t* out, size_t num_indices, size_t vocab_size, size_t hidden_dim,
                            size_t group_size);
 uint32_t oracle_sample_greedy_f16(const uint16_t* logits, size_t vocab_size);
+uint32_t oracle_sample_f16(const uint16_t* logits, size_t vocab_size, float temperature, float top_p,
+                           size_t top_k, float sample, uint32_t* history, size_t* hist_count);
+float oracle_sample_uniform(uint32_t seed);
+float oracle_logits_entropy_f16(const uint16_t* logits, size_t vocab_size);
 int  oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out,
                           size_t num_indices, size_t vocab_size, size_t hidden_dim);
 

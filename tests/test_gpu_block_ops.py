@@ -239,6 +239,63 @@ def test_activation_multiply_equals_the_two_calls(H, name, n):
     assert np.array_equal(got[:vend], O.binary("multiply", getattr(O, name)(g).view(np.float16), u)[:vend])
 
 
+@pytest.mark.parametrize("rows,dims", [(1, 1024), (16, 1024), (256, 1024), (5, 640), (3, 100), (2, 7), (4, 4096)])
+@pytest.mark.parametrize("with_add", [True, False])
+def test_add_rms_norm_quant_equals_norm_then_activation_quant(H, rows, dims, with_add):
+    """The norm that feeds q/k/v or gate/up and the row quantization of that matmul's input
+    (graph_ops_nn.cpp:35-66), one launch: sum, norm, int8 row and scale all bit-exact."""
+    rng = np.random.default_rng(rows * 7 + dims + with_add)
+    a, b = halves(rng, (rows, dims), 2.0), halves(rng, (rows, dims), 2.0)
+    w = (1.0 + 0.1 * rng.standard_normal(dims)).astype(np.float16)
+    if rows > 1:
+        a[1] = 0; b[1] = 0                                    # an all-zero row: scale floor 1e-10
+    s, n, q, sc = H.add_rms_norm_quant(dev(a), dev(b) if with_add else None, dev(w), 1e-6, want_norm=True)
+    want_s = O.binary("add", a, b) if with_add else a.view(np.uint16)
+    want_n = O.rms_norm(want_s, w, 1e-6)
+    wq, ws = O.quantize_activations(want_n)
+    if with_add:
+        assert np.array_equal(bits(s), want_s)
+    else:
+        assert s is None
+    assert np.array_equal(bits(n), want_n)
+    assert np.array_equal(q.cpu().numpy(), wq) and np.array_equal(sc.cpu().numpy(), ws)
+    # the norm output is optional
+    _, n2, q2, sc2 = H.add_rms_norm_quant(dev(a), dev(b) if with_add else None, dev(w), 1e-6)
+    assert n2 is None and torch.equal(q2, q) and torch.equal(sc2, sc)
+
+
+@pytest.mark.parametrize("name", ["silu", "gelu"])
+@pytest.mark.parametrize("rows,dims", [(1, 3072), (16, 3072), (256, 3072), (3, 2048), (5, 13), (2, 100)])
+def test_activation_multiply_quant_equals_the_three_calls(H, name, rows, dims):
+    """act(gate) * up and the row quantization of the down projection's input, one launch."""
+    rng = np.random.default_rng(rows + dims)
+    g, u = halves(rng, (rows, dims), 3.0), halves(rng, (rows, dims), 1.0)
+    act, q, sc = getattr(H, name + "_multiply_quant")(dev(g), dev(u), want_act=True)
+    want_act = bits(getattr(H, name + "_multiply")(dev(g), dev(u)))      # verified against the oracle above
+    assert np.array_equal(bits(act), want_act)
+    wq, ws = O.quantize_activations(want_act)
+    assert np.array_equal(q.cpu().numpy(), wq) and np.array_equal(sc.cpu().numpy(), ws)
+    if (rows * dims) % 8 == 0:                                            # no libm tail: the oracle end to end
+        oa = O.binary("multiply", getattr(O, name)(g.reshape(-1)).view(np.float16), u.reshape(-1)).reshape(rows, dims)
+        assert np.array_equal(want_act, oa)
+    act2, q2, _ = getattr(H, name + "_multiply_quant")(dev(g), dev(u))
+    assert act2 is None and torch.equal(q2, q)
+
+
+def test_row_quant_argument_errors(H):
+    import ctypes as C
+    x = dev(np.zeros((1, 8), np.float16))
+    q = torch.empty((1, 8), dtype=torch.int8, device="cuda")
+    sc = torch.empty((1,), dtype=torch.float32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    # an addend needs somewhere to put the sum
+    assert H.lib.cactus_hip_add_rms_norm_quant_f16_dev(p(x), p(x), p(x), None, None, p(q), p(sc), 1, 8, 1e-6, None) != 0
+    assert H.lib.cactus_hip_add_rms_norm_quant_f16_dev(p(x), None, p(x), None, None, None, p(sc), 1, 8, 1e-6, None) != 0
+    assert H.lib.cactus_hip_silu_multiply_quant_f16_dev(p(x), None, None, p(q), p(sc), 1, 8, None) != 0
+    assert H.lib.cactus_hip_add_rms_norm_quant_f16_dev(p(x), None, p(x), None, None, p(q), p(sc), 1, 20000, 1e-6, None) != 0
+    assert H.lib.cactus_hip_add_rms_norm_quant_f16_dev(None, None, None, None, None, None, None, 0, 8, 1e-6, None) == 0
+
+
 def test_quantize_kv_pair_equals_two_calls(H):
     """engine_cache.cpp:253-263: K then V, written straight into cache-slot views."""
     rng = np.random.default_rng(4)
