@@ -9,6 +9,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
 #include <cstring>
 
 #include "../../include/cactus_hip.h"
@@ -253,6 +255,93 @@ void CactusGraph::set_packed_int4(size_t node_id, const void* packed, size_t pac
     b.packed_int4_size = packed_bytes;
     b.device_valid = true;
     is_weight_[node_id] = true;
+}
+
+ModelConfig parse_model_config(const std::string& text) {   // engine_model.cpp:410-538
+    ModelConfig c;
+    auto trim = [](std::string v) {
+        const size_t a = v.find_first_not_of(" \t");
+        if (a == std::string::npos) return std::string();
+        const size_t b = v.find_last_not_of(" \t");
+        return v.substr(a, b - a + 1);
+    };
+    auto u32 = [](const std::string& v) { return static_cast<uint32_t>(std::stoul(v)); };
+    auto flag = [](const std::string& v) { return v == "true" || v == "1"; };
+    size_t pos = 0;
+    while (pos <= text.size()) {
+        size_t nl = text.find('\n', pos);
+        if (nl == std::string::npos) nl = text.size();
+        const std::string line = text.substr(pos, nl - pos);
+        pos = nl + 1;
+        if (line.empty() || line[0] == '#') continue;
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        const std::string key = trim(line.substr(0, eq)), value = trim(line.substr(eq + 1));
+        if (key == "vocab_size") c.vocab_size = u32(value);
+        else if (key == "bos_token_id") c.bos_token_id = u32(value);
+        else if (key == "eos_token_id") c.eos_token_id = u32(value);
+        else if (key == "num_layers") c.num_layers = u32(value);
+        else if (key == "hidden_dim") c.hidden_dim = u32(value);
+        else if (key == "ffn_intermediate_dim") c.ffn_intermediate_dim = u32(value);
+        else if (key == "attention_heads") c.attention_heads = u32(value);
+        else if (key == "attention_kv_heads") c.attention_kv_heads = u32(value);
+        else if (key == "attention_head_dim") c.attention_head_dim = u32(value);
+        else if (key == "layer_norm_eps") c.layer_norm_eps = std::stof(value);
+        else if (key == "rope_theta") c.rope_theta = std::stof(value);
+        else if (key == "num_experts") c.num_experts = u32(value);
+        else if (key == "num_shared_experts") c.num_shared_experts = u32(value);
+        else if (key == "num_top_experts") c.num_top_experts = u32(value);
+        else if (key == "moe_every_n_layers") c.moe_every_n_layers = u32(value);
+        else if (key == "tie_word_embeddings") c.tie_word_embeddings = flag(value);
+        else if (key == "conv_L_cache") c.conv_L_cache = u32(value);
+        else if (key == "precision") c.precision = value == "INT8" ? 0 : (value == "FP16" ? 1 : 2);
+        else if (key == "model_type") {
+            if (value == "gemma" || value == "GEMMA") c.model_type = 1;
+            else if (value == "lfm2" || value == "LFM2") c.model_type = 5;
+            else if (value == "smol" || value == "SMOL" || value == "Smol") c.model_type = 2;
+            else if (value == "bert" || value == "BERT") c.model_type = 3;
+            else if (value == "whisper" || value == "WHISPER") c.model_type = 7;
+            else c.model_type = 0;
+        } else if (key == "model_variant") {
+            std::string v = value;
+            std::transform(v.begin(), v.end(), v.begin(), [](unsigned char ch) { return (char)std::tolower(ch); });
+            c.model_variant = v == "vlm" ? 1 : (v == "extract" ? 2 : (v == "rag" ? 3 : 0));
+        } else if (key == "layer_types") {   // ['conv', 'full_attention', ...] -> items
+            c.layer_types.clear();
+            std::string item;
+            auto flush = [&] {
+                const std::string it = trim(item);
+                if (!it.empty()) c.layer_types.push_back(it);
+                item.clear();
+            };
+            for (char ch : value) {
+                if (ch == '[' || ch == ']' || ch == '\'' || ch == '"') continue;
+                if (ch == ',') flush();
+                else item.push_back(ch);
+            }
+            flush();
+        }
+    }
+    switch (c.model_type) {   // engine_model.cpp:512-536
+        case 1: c.default_temperature = 1.0f; c.default_top_p = 0.95f; c.default_top_k = 64; break;
+        case 2: c.default_temperature = 0.2f; c.default_top_p = 0.95f; c.default_top_k = 20; break;
+        case 5: c.default_temperature = 0.3f; c.default_top_p = 0.95f; c.default_top_k = 20; break;
+        case 0: c.default_temperature = 0.6f; c.default_top_p = 0.95f; c.default_top_k = 20; break;
+        case 7: c.default_temperature = 0.0f; c.default_top_p = 0.0f; c.default_top_k = 0; break;
+        default: break;
+    }
+    return c;
+}
+
+ModelConfig load_model_config(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("Failed to open config file: " + path);
+    std::string text;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, n);
+    fclose(f);
+    return parse_model_config(text);
 }
 
 CactHeader parse_cact_header(const void* bytes, size_t file_size) {   // graph_io.cpp:497-566
@@ -1012,6 +1101,30 @@ int cactus_hip_cact_parse_header(const void* bytes, size_t size, uint64_t* out12
         for (int i = 0; i < 12; i++) out12[i] = v[i];
         out12[12] = h.scales_offset;
         out12[13] = h.data_offset;
+        return 0;
+    });
+}
+int cactus_hip_model_config_load(const char* path, cactus_hip_model_config* out) {
+    return guarded<int>(-1, [&] {
+        if (!path || !out) throw std::runtime_error("model_config_load: null argument");
+        const cactus_hip::ModelConfig c = cactus_hip::load_model_config(path);
+        memset(out, 0, sizeof *out);
+        out->vocab_size = c.vocab_size; out->bos_token_id = c.bos_token_id; out->eos_token_id = c.eos_token_id;
+        out->num_layers = c.num_layers; out->hidden_dim = c.hidden_dim;
+        out->ffn_intermediate_dim = c.ffn_intermediate_dim; out->attention_heads = c.attention_heads;
+        out->attention_kv_heads = c.attention_kv_heads; out->attention_head_dim = c.attention_head_dim;
+        out->layer_norm_eps = c.layer_norm_eps; out->rope_theta = c.rope_theta;
+        out->num_experts = c.num_experts; out->num_shared_experts = c.num_shared_experts;
+        out->num_top_experts = c.num_top_experts; out->moe_every_n_layers = c.moe_every_n_layers;
+        out->tie_word_embeddings = c.tie_word_embeddings ? 1 : 0;
+        out->model_type = c.model_type; out->model_variant = c.model_variant; out->precision = c.precision;
+        out->default_temperature = c.default_temperature; out->default_top_p = c.default_top_p;
+        out->default_top_k = c.default_top_k; out->conv_L_cache = c.conv_L_cache;
+        out->num_layer_types = (uint32_t)c.layer_types.size();
+        std::string joined;
+        for (size_t i = 0; i < c.layer_types.size(); i++) joined += (i ? "," : "") + c.layer_types[i];
+        if (joined.size() >= sizeof out->layer_types) throw std::runtime_error("model_config_load: layer_types too long");
+        memcpy(out->layer_types, joined.c_str(), joined.size() + 1);
         return 0;
     });
 }

@@ -207,6 +207,28 @@ struct CactHeader {
 // Throws std::runtime_error with the reference's messages (graph_io.cpp:498-500, 507-509, 561-563).
 CactHeader parse_cact_header(const void* bytes, size_t file_size);
 
+// The decoder-side fields of the reference's Config (cactus/engine/engine.h:43-116) with its
+// defaults, filled from a model folder's config.txt as Config::from_json reads it
+// (engine_model.cpp:403-539): `key = value` lines, '#' comments, unknown keys ignored, sampling
+// defaults chosen by model type.  The vision / image preprocessing keys are accepted and skipped.
+struct ModelConfig {
+    uint32_t vocab_size = 151936, bos_token_id = 151643, eos_token_id = 151645, num_layers = 28;
+    uint32_t hidden_dim = 1024, ffn_intermediate_dim = 3072, attention_heads = 16, attention_kv_heads = 8;
+    uint32_t attention_head_dim = 128;
+    float layer_norm_eps = 1e-6f, rope_theta = 1000000.0f;
+    uint32_t num_experts = 0, num_shared_experts = 0, num_top_experts = 0, moe_every_n_layers = 0;
+    bool tie_word_embeddings = true;
+    int model_type = 0;      // QWEN 0, GEMMA 1, SMOL 2, NOMIC 3, LFM2 5, WHISPER 7 (engine.h:92)
+    int model_variant = 0;   // DEFAULT 0, VLM 1, EXTRACT 2, RAG 3
+    int precision = 2;       // INT8 0, FP16 1, FP32 2 (engine.h:104-105)
+    float default_temperature = 0.6f, default_top_p = 0.95f;
+    uint32_t default_top_k = 20;
+    uint32_t conv_L_cache = 0;
+    std::vector<std::string> layer_types;
+};
+ModelConfig parse_model_config(const std::string& text);
+ModelConfig load_model_config(const std::string& path);   // throws when the file cannot be opened
+
 // INT8 KV cache resident in HBM: per layer keys/values int8 [slot, Hkv, D] and fp32 scales
 // [slot, Hkv, ceil(D/128)], slots 0..sink-1 = first tokens, the rest = most recent tokens
 // (engine.h:324-381, engine_cache.cpp:11-51, 101-337).

@@ -3,6 +3,7 @@ reference's CactusGraph / KVCache for the hot path (cactus_amd/csrc/graph.h).  H
 numpy; node ids are the graph's own.  Method names and argument meaning follow
 cactus/graph/graph.h:386-500 and cactus/engine/engine.h:324-381."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -31,6 +32,7 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_mmap_weights": (_l, [_vp, C.c_char_p]),
     "cactus_hip_graph_node_info": (_i, [_vp, _sz, _szp, _szp, C.POINTER(C.c_int), _szp, _szp, C.POINTER(C.c_int)]),
     "cactus_hip_cact_parse_header": (_i, [_vp, _sz, C.POINTER(C.c_uint64)]),
+    "cactus_hip_model_config_load": (_i, [C.c_char_p, _vp]),
     "cactus_hip_graph_set_input": (_i, [_vp, _sz, _vp, _i]),
     "cactus_hip_graph_set_external_input": (_i, [_vp, _sz, _vp, _i]),
     "cactus_hip_graph_set_grouped_scales": (_i, [_vp, _sz, _sz, _sz, _vp]),
@@ -234,6 +236,31 @@ def parse_cact_header(data):
     keys = ("version", "alignment", "ndim", "d0", "d1", "d2", "d3", "precision", "data_bytes", "scales_bytes",
             "group_size", "num_groups", "scales_offset", "data_offset")
     return dict(zip(keys, [int(v) for v in out]))
+
+
+class _ModelConfigStruct(C.Structure):
+    _fields_ = ([(n, C.c_uint32) for n in ("vocab_size", "bos_token_id", "eos_token_id", "num_layers", "hidden_dim",
+                                           "ffn_intermediate_dim", "attention_heads", "attention_kv_heads",
+                                           "attention_head_dim")] +
+                [("layer_norm_eps", C.c_float), ("rope_theta", C.c_float)] +
+                [(n, C.c_uint32) for n in ("num_experts", "num_shared_experts", "num_top_experts",
+                                           "moe_every_n_layers")] +
+                [(n, C.c_int) for n in ("tie_word_embeddings", "model_type", "model_variant", "precision")] +
+                [("default_temperature", C.c_float), ("default_top_p", C.c_float)] +
+                [(n, C.c_uint32) for n in ("default_top_k", "conv_L_cache", "num_layer_types")] +
+                [("layer_types", C.c_char * 2048)])
+
+
+def load_model_config(path):
+    """config.txt of a converted model folder -> dict (Config::from_json, engine_model.cpp:403-539)."""
+    st = _ModelConfigStruct()
+    _ok(lib.cactus_hip_model_config_load(os.fsencode(path), C.byref(st)))
+    out = {n: getattr(st, n) for n, _ in _ModelConfigStruct._fields_}
+    out["tie_word_embeddings"] = bool(out["tie_word_embeddings"])
+    lt = out.pop("layer_types").decode()
+    out["layer_types"] = lt.split(",") if lt else []
+    out.pop("num_layer_types")
+    return out
 
 
 class KVCache:

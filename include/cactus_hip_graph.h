@@ -62,6 +62,25 @@ int    cactus_hip_graph_node_info(void* graph, size_t node, size_t* shape4, size
  * version, alignment, ndim, dims[4], precision, data_bytes, scales_bytes, group_size, num_groups,
  * scales_offset, data_offset.  -1 + cactus_hip_last_error() on the reference's error conditions. */
 int    cactus_hip_cact_parse_header(const void* bytes, size_t size, uint64_t* out14);
+/* Config::from_json (cactus/engine/engine_model.cpp:403-539; fields and defaults of
+ * cactus/engine/engine.h:43-116): the `key = value` lines of a model folder's config.txt.  Only the
+ * fields a decoder needs are returned; the vision / image keys are accepted and ignored.
+ * layer_types holds the items joined by ','.  -1 when the file cannot be opened or a number does
+ * not parse (the reference returns false / throws from std::stoul). */
+typedef struct cactus_hip_model_config {
+    uint32_t vocab_size, bos_token_id, eos_token_id, num_layers, hidden_dim, ffn_intermediate_dim;
+    uint32_t attention_heads, attention_kv_heads, attention_head_dim;
+    float layer_norm_eps, rope_theta;
+    uint32_t num_experts, num_shared_experts, num_top_experts, moe_every_n_layers;
+    int tie_word_embeddings;
+    int model_type;      /* QWEN 0, GEMMA 1, SMOL 2, NOMIC 3, LFM2 5, WHISPER 7 */
+    int model_variant;   /* DEFAULT 0, VLM 1, EXTRACT 2, RAG 3 */
+    int precision;       /* INT8 0, FP16 1, FP32 2 */
+    float default_temperature, default_top_p;
+    uint32_t default_top_k, conv_L_cache, num_layer_types;
+    char layer_types[2048];
+} cactus_hip_model_config;
+int    cactus_hip_model_config_load(const char* path, cactus_hip_model_config* out);
 int    cactus_hip_graph_set_input(void* graph, size_t node, const void* host_data, int precision);
 int    cactus_hip_graph_set_external_input(void* graph, size_t node, void* host_data, int precision);
 int    cactus_hip_graph_set_grouped_scales(void* graph, size_t node, size_t group_size, size_t num_groups,

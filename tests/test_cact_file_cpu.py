@@ -47,3 +47,41 @@ def test_header_errors(G):
         G.parse_cact_header(b"XXXX" + raw[4:])
     with pytest.raises(G.CactusHipError, match="data extends beyond file size"):
         G.parse_cact_header(raw[:-1])
+
+
+# --------------------------------------------------------------------------- config.txt
+def test_model_config_files_written_by_the_reference_formatter():
+    """tests/golden/config_*.txt were written with python/src/tensor_io.py:format_config_value the way
+    python/src/cli.py:186-189 writes a model folder's config.txt; the parser follows
+    Config::from_json (cactus/engine/engine_model.cpp:403-539)."""
+    import cactus_amd.graph as G
+    here = os.path.dirname(os.path.abspath(__file__))
+    c = G.load_model_config(os.path.join(here, "golden", "config_lfm2.txt"))
+    assert (c["vocab_size"], c["hidden_dim"], c["num_layers"], c["attention_heads"], c["attention_kv_heads"],
+            c["attention_head_dim"], c["ffn_intermediate_dim"]) == (65536, 2048, 16, 32, 8, 64, 8192)
+    assert c["model_type"] == 5 and c["precision"] == 0 and c["conv_L_cache"] == 3 and c["tie_word_embeddings"]
+    assert c["layer_types"] == ["conv", "conv", "full_attention", "conv", "conv", "full_attention"]
+    assert c["layer_norm_eps"] == np.float32(1e-5) and c["rope_theta"] == 1e6
+    assert (c["bos_token_id"], c["eos_token_id"]) == (1, 7)
+    # LFM2 sampling defaults (engine_model.cpp:520-523)
+    assert (c["default_temperature"], c["default_top_p"], c["default_top_k"]) == (np.float32(0.3), np.float32(0.95), 20)
+    q = G.load_model_config(os.path.join(here, "golden", "config_qwen.txt"))
+    assert q["model_type"] == 0 and q["precision"] == 1 and not q["tie_word_embeddings"] and q["layer_types"] == []
+    assert (q["default_temperature"], q["default_top_k"]) == (np.float32(0.6), 20)
+
+
+def test_model_config_defaults_comments_and_errors(tmp_path):
+    import cactus_amd.graph as G
+    p = tmp_path / "config.txt"
+    p.write_text("# comment\n\n  model_type =  gemma \nunknown_key=5\nno equals sign here\n"
+                 "layer_types = ['conv', \"full_attention\"]\nvision_hidden_dim=768\ntie_word_embeddings=1\n")
+    c = G.load_model_config(str(p))
+    # untouched fields keep the reference's defaults (engine.h:44-59)
+    assert (c["vocab_size"], c["num_layers"], c["hidden_dim"], c["attention_head_dim"]) == (151936, 28, 1024, 128)
+    assert c["model_type"] == 1 and (c["default_temperature"], c["default_top_k"]) == (1.0, 64)
+    assert c["layer_types"] == ["conv", "full_attention"] and c["precision"] == 2
+    with pytest.raises(Exception, match="Failed to open config file"):
+        G.load_model_config(str(tmp_path / "missing.txt"))
+    p.write_text("vocab_size=abc\n")           # std::stoul throws in the reference
+    with pytest.raises(Exception):
+        G.load_model_config(str(p))
