@@ -335,6 +335,14 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                                            (x, L["v"][0], L["v"][1], vo)], 128),
                             H.MatmulBatch([(xn2, L["gate"][0], L["gate"][1], go), (xn2, L["up"][0], L["up"][1], uo)], 128)))
 
+    produced = []
+    if batch <= 4:   # norm / activation folded into the launch of the matmuls that read it
+        for L in Ls:
+            produced.append((H.MatmulProduced([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko),
+                                               (L["v"][0], L["v"][1], vo)], 128),
+                             H.MatmulProduced([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128),
+                             H.MatmulProduced([(L["down"][0], L["down"][1], do)], 128)))
+        head_p = H.MatmulProduced([(head[0], head[1], logits)], 128)
     shared = []
     if batch > 4:
         for L in Ls:
@@ -348,13 +356,18 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
     def step():
         H.embedding(head[0], tok, head[1], 128, out=h0, check=False)
         if batch <= 4:
-            H.rms_norm(h0, Ls[0]["in_norm"], eps, out=x)
+            pass                         # the first norm rides in layer 0's q/k/v launch
         else:
             H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
         res = h0
         for li, L in enumerate(Ls):
             if batch <= 4:
-                batches[li][0].run()
+                # residual add of the previous block + this block's input norm + q/k/v, one launch
+                if li == 0:
+                    produced[li][0].run_norm(h0, None, L["in_norm"], eps)
+                else:
+                    produced[li][0].run_norm(h2, do, L["in_norm"], eps, hid)
+                    res = hid
             else:
                 shared[li][0].run(xq, xs)      # quantized by the norm launch that produced it
             H.qk_norm_rope(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), L["q_norm"], L["k_norm"], eps, theta,
@@ -372,11 +385,8 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
             proj(a.view(batch, Hq * D), L["o"], oo)
             nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
             if batch <= 4:
-                H.add_rms_norm(res, oo, L["post_norm"], eps, out_sum=h2, out_norm=xn2)
-                batches[li][1].run()
-                H.silu_multiply(go, uo, out=act)
-                proj(act, L["down"], do)
-                H.add_rms_norm(h2, do, nxt, eps, out_sum=hid, out_norm=x)   # residual add + the next norm
+                produced[li][1].run_norm(res, oo, L["post_norm"], eps, h2)   # add + norm + gate/up
+                produced[li][2].run_act(go, uo, "silu")                      # silu x up + down
             else:   # norm / activation launches that also quantize the next matmul's input rows
                 H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
                 shared[li][1].run(xq2, xs2)
@@ -385,8 +395,11 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                 last = li + 1 == layers   # the lm_head below takes the FP16 row
                 H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq,
                                      out_scales=xs)
-            res = hid
-        proj(x, head, logits)
+                res = hid
+        if batch <= 4:   # last residual add + final norm + lm_head
+            head_p.run_norm(h2, do, final_norm, eps, hid)
+        else:
+            proj(x, head, logits)
         H.sample_greedy(logits, out=tok)
 
     step()

@@ -297,6 +297,80 @@ int matmul_q_shared(bool int4, const int8_t* A, const float* As, const cactus_hi
 }
 }  // namespace
 
+namespace {
+// kind 1: rows = rms_norm(x [+ x2]) * w (sum -> sum_out); 2: silu(x) * x2; 3: gelu(x) * x2
+int matmul_q_produced(bool int4, int kind, const cactus_half_t* x, const cactus_half_t* x2, const cactus_half_t* w,
+                      cactus_half_t* sum_out, float eps, const cactus_hip_matmul_weights* wt, size_t count, size_t M,
+                      size_t K, size_t gs, void* stream) {
+    if (M == 0 || K == 0) return CACTUS_HIP_OK;
+    if (!x || (count && !wt)) return fail(CACTUS_HIP_EINVAL, "matmul with produced activations: null operand");
+    if (kind == 1 && !w) return fail(CACTUS_HIP_EINVAL, "matmul_norm: null norm weight");
+    if (kind == 1 && x2 && !sum_out) return fail(CACTUS_HIP_EINVAL, "matmul_norm: addend without sum_output");
+    if (kind != 1 && !x2) return fail(CACTUS_HIP_EINVAL, "matmul_act: null up operand");
+    if (K > 16384) return fail(CACTUS_HIP_EINVAL, "matmul with produced activations: rows longer than 16384");
+    for (size_t i = 0; i < count; i++)
+        if (wt[i].N && (!wt[i].B || !wt[i].B_scales || !wt[i].C))
+            return fail(CACTUS_HIP_EINVAL, "matmul with produced activations: null weight entry");
+    bool fused = gs == 128 && K % 128 == 0 && count >= 1 && count <= 16 && aligned(x, 16) &&
+                 (!x2 || aligned(x2, 16)) && (!w || aligned(w, 16)) && (!sum_out || aligned(sum_out, 16)) &&
+                 K < (size_t(1) << 30) && skinny_fq_pro_ok(int4, kind, M, K);
+    for (size_t i = 0; fused && i < count; i++)
+        fused = wt[i].N > 0 && wt[i].N < (size_t(1) << 30) && aligned(wt[i].B, 16);
+    if (fused) {
+        SkinnyProblem pr[16];
+        for (size_t i = 0; i < count; i++) pr[i] = SkinnyProblem{x, wt[i].B, wt[i].B_scales, wt[i].C, M, K, wt[i].N};
+        hipError_t e = launch_matmul_skinny_fq_batch_pro(int4, kind, pr, count, x2, w, kind == 1 && x2 ? sum_out : nullptr,
+                                                         eps, S(stream));
+        if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul with produced activations launch", e);
+        return CACTUS_HIP_OK;
+    }
+    // otherwise: the rows are produced and quantized by one launch, then multiplied
+    const size_t qbytes = (M * K + 255) & ~size_t(255);
+    void* ws = nullptr;
+    int rc = workspace(qbytes + M * sizeof(float), &ws);
+    if (rc != CACTUS_HIP_OK) return rc;
+    int8_t* q = static_cast<int8_t*>(ws);
+    float* qs = reinterpret_cast<float*>(static_cast<char*>(ws) + qbytes);
+    hipError_t e = launch_row_quant(kind - 1, x, x2, w, kind == 1 && x2 ? sum_out : nullptr, nullptr, q, qs, M, K, eps,
+                                    S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "row producer + quantization launch", e);
+    return matmul_q_shared(int4, q, qs, wt, count, M, K, gs, stream);
+}
+}  // namespace
+
+int cactus_hip_matmul_int8_norm_f16act_dev(const cactus_half_t* input, const cactus_half_t* addend,
+                                           const cactus_half_t* norm_weight, cactus_half_t* sum_output, float eps,
+                                           const cactus_hip_matmul_weights* weights, size_t count, size_t M, size_t K,
+                                           size_t group_size, void* stream) {
+    return matmul_q_produced(false, 1, input, addend, norm_weight, sum_output, eps, weights, count, M, K, group_size, stream);
+}
+int cactus_hip_matmul_int4_norm_f16act_dev(const cactus_half_t* input, const cactus_half_t* addend,
+                                           const cactus_half_t* norm_weight, cactus_half_t* sum_output, float eps,
+                                           const cactus_hip_matmul_weights* weights, size_t count, size_t M, size_t K,
+                                           size_t group_size, void* stream) {
+    return matmul_q_produced(true, 1, input, addend, norm_weight, sum_output, eps, weights, count, M, K, group_size, stream);
+}
+int cactus_hip_matmul_int8_silu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count, size_t M, size_t K,
+                                           size_t group_size, void* stream) {
+    return matmul_q_produced(false, 2, gate, up, nullptr, nullptr, 0.0f, weights, count, M, K, group_size, stream);
+}
+int cactus_hip_matmul_int4_silu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count, size_t M, size_t K,
+                                           size_t group_size, void* stream) {
+    return matmul_q_produced(true, 2, gate, up, nullptr, nullptr, 0.0f, weights, count, M, K, group_size, stream);
+}
+int cactus_hip_matmul_int8_gelu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count, size_t M, size_t K,
+                                           size_t group_size, void* stream) {
+    return matmul_q_produced(false, 3, gate, up, nullptr, nullptr, 0.0f, weights, count, M, K, group_size, stream);
+}
+int cactus_hip_matmul_int4_gelu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count, size_t M, size_t K,
+                                           size_t group_size, void* stream) {
+    return matmul_q_produced(true, 3, gate, up, nullptr, nullptr, 0.0f, weights, count, M, K, group_size, stream);
+}
+
 int cactus_hip_matmul_int8_shared_dev(const int8_t* A, const float* A_scales, const cactus_hip_matmul_weights* weights,
                                       size_t count, size_t M, size_t K, size_t group_size, void* stream) {
     return matmul_q_shared(false, A, A_scales, weights, count, M, K, group_size, stream);

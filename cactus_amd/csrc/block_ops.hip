@@ -14,15 +14,11 @@
 //   embedding  cactus/graph/graph_ops_tensor.cpp:226-320
 #include "common.hip.h"
 #include "kernels.h"
+#include "block_math.hip.h"
 
 namespace cactus_hip {
 
 namespace {
-
-typedef _Float16 h16;
-
-__device__ __forceinline__ h16 bits2h(uint16_t b) { return __builtin_bit_cast(h16, b); }
-__device__ __forceinline__ uint16_t h2bits(h16 h) { return __builtin_bit_cast(uint16_t, h); }
 
 // ---------------------------------------------------------------------------------------
 // RMS norm.  16 lanes per row, 16 rows per 256-thread workgroup.  Lane l owns the reference's
@@ -33,49 +29,6 @@ __device__ __forceinline__ uint16_t h2bits(h16 h) { return __builtin_bit_cast(ui
 // output multiplies in fp16, (x * half(inv)) * w with both products rounded; the tail computes
 // x*inv*w in fp32 and rounds once.
 // ---------------------------------------------------------------------------------------
-
-// 1 / rms of one row, computed by the 16 lanes [base, base + 16) of a wave; `elem(i)` returns the
-// binary16 bits of element i.  Loads run 8 ahead of the fma chain.
-template <typename Elem>
-__device__ __forceinline__ float row_inv_rms(Elem elem, int dims, float eps, int l, int base) {
-    const int simd_end = dims & ~7;
-    float acc = 0.0f;
-    int i = l;
-    for (; i + 7 * 16 < simd_end; i += 8 * 16) {
-        uint16_t v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = elem(i + 16 * u);
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const float f = h2f(v[u]);
-            acc = fmaf(f, f, acc);
-        }
-    }
-    for (; i < simd_end; i += 16) {
-        const float f = h2f(elem(i));
-        acc = fmaf(f, f, acc);
-    }
-    const float a0 = __shfl(acc, base + (l & 3)), a1 = __shfl(acc, base + 4 + (l & 3));
-    const float a2 = __shfl(acc, base + 8 + (l & 3)), a3 = __shfl(acc, base + 12 + (l & 3));
-    const float t = ((a0 + a1) + a2) + a3;
-    const float t0 = __shfl(t, base), t1 = __shfl(t, base + 1), t2 = __shfl(t, base + 2), t3 = __shfl(t, base + 3);
-    float ss = (t0 + t1) + (t2 + t3);
-    for (int k = simd_end; k < dims; k++) {
-        const float f = h2f(elem(k));
-        ss = fmaf(f, f, ss);
-    }
-    const float rms = __builtin_sqrtf(ss / (float)dims + eps);
-    return 1.0f / rms;
-}
-
-// normalized element i: fp16 products in the vector part, one fp32 expression in the tail
-__device__ __forceinline__ uint16_t rms_out(uint16_t xb, uint16_t wb, float inv, h16 inv_h, bool vector_part) {
-    if (vector_part) {
-        const h16 p = bits2h(xb) * inv_h;
-        return h2bits(p * bits2h(wb));
-    }
-    return f2h_mul(h2f(xb) * inv, h2f(wb));   // all fp32, one conversion at the end (kernel_nn.cpp tail)
-}
 
 // ADD: the row normalized is a + b (one fp16 add per element, as cactus_add_f16), which is also
 // written to sum_out: the residual add and the norm that follows it in a decoder block
@@ -269,60 +222,6 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
             orow[i] = f2h(pa - pb);
             orow[half_dim + i] = f2h(pd + pe);
         }
-    }
-}
-
-// polynomial e^x of the vector paths (kernel_utils.h:108-141)
-__device__ __forceinline__ float fast_exp(float x) {
-    x = fmaxf(x, -87.0f);
-    x = fminf(x, 87.0f);
-    const float z = x * 1.4426950408889634f;
-    int zi = (int)z;   // toward zero
-    float zf = z - (float)zi;
-    if (zf < 0.0f) { zi -= 1; zf += 1.0f; }
-    const float zl = zf * 0.6931471805599453f;
-    float p = 0.009618129842071803f;
-    p = fmaf(p, zl, 0.05550410866482158f);
-    p = fmaf(p, zl, 0.2402265069591007f);
-    p = fmaf(p, zl, 0.6931471805599453f);
-    p = fmaf(p, zl, 1.0f);
-    return p * __builtin_bit_cast(float, (uint32_t)(zi + 127) << 23);
-}
-
-// rational tanh of the vector paths (kernel_utils.h:143-163)
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float x2 = x * x;
-    const float num = 27.0f + x2;
-    const float den = fmaf(9.0f, x2, 27.0f);
-    float r = x * (num / den);
-    if (x > 4.5f) r = 1.0f;
-    if (x < -4.5f) r = -1.0f;
-    return r;
-}
-
-enum { OP_SILU = 0, OP_GELU = 1 };
-
-template <int OP>
-__device__ __forceinline__ uint16_t unary_one(uint16_t hb, bool vector_part) {
-    const float x = h2f(hb);
-    if (OP == OP_SILU) {
-        const float e = vector_part ? fast_exp(-x) : expf(-x);
-        const float sig = 1.0f / (1.0f + e);
-        return f2h_mul(x, sig);   // fp32 product, then fp32 -> fp16: two roundings (vmulq_f32 + vcvt_f16_f32)
-    } else {
-        if (vector_part) {
-            const float x3 = (x * x) * x;
-            float inner = fmaf(0.044715f, x3, x);
-            inner = 0.7978845608028654f * inner;
-            const float th = fast_tanh(inner);
-            const float hx = 0.5f * x, ot = 1.0f + th;
-            return f2h_mul(hx, ot);
-        }
-        const float c1 = 0.044715f * x, c2 = c1 * x, x3 = c2 * x;
-        const float sum = x + x3;
-        const float inner = 0.7978845608028654f * sum;
-        const float hx = 0.5f * x, ot = 1.0f + tanhf(inner);
-        return f2h_mul(hx, ot);
     }
 }
 

@@ -50,6 +50,13 @@ struct SkinnyProblem {
 };
 hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* problems, size_t count, hipStream_t st);
 
+// The same launch with the activation rows produced in the prologue (all problems read them):
+// kind 1 rms_norm(X [+ x2]) * w with the sum written to sum_out, 2 silu(X) * x2, 3 gelu(X) * x2.
+bool skinny_fq_pro_ok(bool int4, int kind, size_t M, size_t K);
+hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyProblem* problems, size_t count,
+                                             const uint16_t* x2, const uint16_t* w, uint16_t* sum_out, float eps,
+                                             hipStream_t st);
+
 extern int g_skinny_ablate;
 hipError_t skinny_read_trace(unsigned long long* out512);
 // Benchmark hook: variant = waves_per_workgroup*100 + ring_depth (0 = the default choice).

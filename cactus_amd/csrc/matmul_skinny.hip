@@ -31,6 +31,7 @@
 #include <algorithm>
 #include "common.hip.h"
 #include "kernels.h"
+#include "block_math.hip.h"
 
 #include <cstring>
 
@@ -331,11 +332,60 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
 // weight loads is in flight, streams the tile, then runs the fp32 chain.  (Walking several tiles
 // per wave group, with the next tile's loads under the epilogue, measured slower at every tile
 // count and cost 30 registers: 4 instead of 5 waves per SIMD.)
-template <bool INT4, int W, int P, int CT>
+//
+// PRO: where the activation rows come from.
+//   0  X as given.
+//   1  rms_norm(X [+ x2]) * w -- the residual add and norm in front of q/k/v or gate/up
+//      (model_qwen.cpp:51-53, 125-127) with the arithmetic of rms_norm_kernel: the summed rows go
+//      to LDS, the 16-lane groups of wave 0 run the accumulation chain of one row each, every
+//      thread then normalizes its own pieces in place.  Tile 0 also writes the sum to sum_out.
+//   2  silu(X) * x2    3  gelu(X) * x2 -- the activation in front of the down projection
+//      (model_qwen.cpp:114-116), element-wise on the way in (unary_kernel<OP, true>'s arithmetic).
+// Every workgroup recomputes the row: a few hundred nanoseconds against a launch of its own.
+struct FqPro {
+    const uint16_t* x2 = nullptr;
+    const uint16_t* w = nullptr;
+    uint16_t* sum_out = nullptr;
+    float eps = 0.0f;
+};
+
+__device__ __forceinline__ v4i add8_bits(v4i a, v4i b) {
+    v4i o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t lo = h2bits(bits2h((uint16_t)((uint32_t)a[e] & 0xFFFFu)) + bits2h((uint16_t)((uint32_t)b[e] & 0xFFFFu)));
+        const uint32_t hi = h2bits(bits2h((uint16_t)((uint32_t)a[e] >> 16)) + bits2h((uint16_t)((uint32_t)b[e] >> 16)));
+        o[e] = (int)(lo | (hi << 16));
+    }
+    return o;
+}
+__device__ __forceinline__ v4i rms_out8_bits(v4i x, v4i w, float inv, h16 inv_h) {
+    v4i o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t lo = rms_out((uint16_t)((uint32_t)x[e] & 0xFFFFu), (uint16_t)((uint32_t)w[e] & 0xFFFFu), inv, inv_h, true);
+        const uint32_t hi = rms_out((uint16_t)((uint32_t)x[e] >> 16), (uint16_t)((uint32_t)w[e] >> 16), inv, inv_h, true);
+        o[e] = (int)(lo | (hi << 16));
+    }
+    return o;
+}
+template <int OP>
+__device__ __forceinline__ v4i act_mul8_bits(v4i g, v4i u) {
+    v4i o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t lo = h2bits(bits2h(unary_one<OP>((uint16_t)((uint32_t)g[e] & 0xFFFFu), true)) * bits2h((uint16_t)((uint32_t)u[e] & 0xFFFFu)));
+        const uint32_t hi = h2bits(bits2h(unary_one<OP>((uint16_t)((uint32_t)g[e] >> 16), true)) * bits2h((uint16_t)((uint32_t)u[e] >> 16)));
+        o[e] = (int)(lo | (hi << 16));
+    }
+    return o;
+}
+
+template <bool INT4, int W, int P, int CT, int PRO = 0>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
                                         uint16_t* __restrict__ C, int M, int K, int N, int tl,
-                                        int t, float* __restrict__ sk_lds) {
+                                        int t, float* __restrict__ sk_lds, const FqPro pro = FqPro()) {
     // t: thread index among the W waves that share the tile; sk_lds: their LDS region.  A workgroup
     // may hold several such wave groups (tiles of one problem, same barrier sequence).
     constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
@@ -348,6 +398,8 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     float* scl = sk_lds + (size_t)CT * M * 16 * SCP;                             // [TR][GP] fp32 scales
     int8_t* lds_a = reinterpret_cast<int8_t*>(scl + TR * GP);                    // [M][K]
     float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4]
+    float* s_inv = wmax + W * 4;                                                            // [4]      (PRO 1)
+    uint16_t* lds_x = reinterpret_cast<uint16_t*>(s_inv + 4);                               // [M][K]   (PRO 1)
 
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -453,11 +505,89 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     constexpr int AST = 2;   // 16-byte pieces per thread held in registers (an M = 1 row of K <= 8192 fits)
     const int npieces = M * K / 8;
     v4i a_stage[AST];
+    v4i b_stage[PRO ? AST : 1], w_stage[PRO == 1 ? AST : 1];
+    const __amdgpu_buffer_rsrc_t x2rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pro.x2), 0, pro.x2 ? 2 * M * K : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(pro.w), 0, pro.w ? 2 * K : 0, 0x00020000);
+    const int kp = K / 8;    // pieces per row
+    auto wpiece = [&](int i16) {   // piece of the norm weight row under piece i16 (M <= 4: no division)
+        int c = i16;
+        c -= (M > 1 && c >= kp) ? kp : 0;
+        c -= (M > 2 && c >= kp) ? kp : 0;
+        c -= (M > 3 && c >= kp) ? kp : 0;
+        return c;
+    };
 #pragma unroll
-    for (int j = 0; j < AST; j++) a_stage[j] = buf_load<0>(xrsrc, (unsigned)(t + j * W * 64) * 16u, 0);
+    for (int j = 0; j < AST; j++) {
+        const int i16 = t + j * W * 64;
+        a_stage[j] = buf_load<0>(xrsrc, (unsigned)i16 * 16u, 0);
+        if constexpr (PRO != 0) b_stage[j] = buf_load<0>(x2rsrc, (unsigned)i16 * 16u, 0);   // no x2: zeros
+        if constexpr (PRO == 1) w_stage[j] = buf_load<0>(wrsrc, i16 < npieces ? (unsigned)wpiece(i16) * 16u : SK_OOB, 0);
+    }
 #pragma unroll
     for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
     const ScRegs sc_regs = load_scales();
+    if constexpr (PRO == 2 || PRO == 3) {
+#pragma unroll
+        for (int j = 0; j < AST; j++) a_stage[j] = act_mul8_bits<PRO == 2 ? OP_SILU : OP_GELU>(a_stage[j], b_stage[j]);
+    }
+    if constexpr (PRO == 1) {
+        const char* Xb = reinterpret_cast<const char*>(X);
+        const char* X2b = reinterpret_cast<const char*>(pro.x2);
+        const char* Wb = reinterpret_cast<const char*>(pro.w);
+        auto stage_sum = [&](int i16, v4i x, v4i d) {
+            const v4i sv = pro.x2 ? add8_bits(x, d) : x;
+            *reinterpret_cast<v4i*>(lds_x + (size_t)i16 * 8) = sv;
+            if (pro.sum_out != nullptr && tl == 0) *reinterpret_cast<v4i*>(pro.sum_out + (size_t)i16 * 8) = sv;
+        };
+#pragma unroll
+        for (int j = 0; j < AST; j++) {
+            const int i16 = t + j * W * 64;
+            if (i16 < npieces) stage_sum(i16, a_stage[j], b_stage[j]);
+        }
+#pragma unroll 1
+        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64)
+            stage_sum(i16, ldg(Xb + (size_t)i16 * 16), pro.x2 ? ldg(X2b + (size_t)i16 * 16) : zero4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (w == 0 && (lane >> 4) < M) {      // one 16-lane group per row
+            const uint16_t* xr = lds_x + (size_t)(lane >> 4) * K;
+            const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, K, pro.eps, lane & 15, lane & ~15);
+            if ((lane & 15) == 0) s_inv[lane >> 4] = inv;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        auto norm_piece = [&](int i16, v4i wv) {
+            const int row = (M > 1 && i16 >= kp) + (M > 2 && i16 >= 2 * kp) + (M > 3 && i16 >= 3 * kp);
+            const float inv = s_inv[row];
+            v4i* px = reinterpret_cast<v4i*>(lds_x + (size_t)i16 * 8);
+            const v4i y = rms_out8_bits(*px, wv, inv, (h16)inv);
+            *px = y;
+            return y;
+        };
+#pragma unroll
+        for (int j = 0; j < AST; j++) {
+            const int i16 = t + j * W * 64;
+            if (i16 < npieces) a_stage[j] = norm_piece(i16, w_stage[j]);
+            else a_stage[j] = zero4;
+        }
+#pragma unroll 1
+        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) norm_piece(i16, ldg(Wb + (size_t)wpiece(i16) * 16));
+    }
+    // the finished activation piece i16 beyond the register stage
+    auto late_piece = [&](int i16) -> v4i {
+        if constexpr (PRO == 1) {
+            return *reinterpret_cast<const v4i*>(lds_x + (size_t)i16 * 8);
+        } else if constexpr (PRO == 2 || PRO == 3) {
+            return act_mul8_bits<PRO == 2 ? OP_SILU : OP_GELU>(ldg(reinterpret_cast<const char*>(X) + (size_t)i16 * 16),
+                                                               ldg(reinterpret_cast<const char*>(pro.x2) + (size_t)i16 * 16));
+        } else {
+            return ldg(reinterpret_cast<const char*>(X) + (size_t)i16 * 16);
+        }
+    };
     {
         float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         auto row_of = [&](int i16) {   // M <= 4: compares instead of a division
@@ -470,11 +600,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
 #pragma unroll
             for (int m = 0; m < 4; m++) mx[m] = (row == m) ? fmaxf(mx[m], v) : mx[m];
         };
-        const char* Xb = reinterpret_cast<const char*>(X);
 #pragma unroll
         for (int j = 0; j < AST; j++) fold(t + j * W * 64, a_stage[j]);
 #pragma unroll 1
-        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) fold(i16, ldg(Xb + (size_t)i16 * 16));
+        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) fold(i16, late_piece(i16));
 #pragma unroll
         for (int m = 0; m < 4; m++)
             if (m < M) mx[m] = wave_max(mx[m]);
@@ -508,7 +637,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             if (i16 < npieces) quant_piece(i16, a_stage[j]);
         }
 #pragma unroll 1
-        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) quant_piece(i16, ldg(Xb + (size_t)i16 * 16));
+        for (int i16 = t + AST * W * 64; i16 < npieces; i16 += W * 64) quant_piece(i16, late_piece(i16));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -609,6 +738,7 @@ struct SkinnyBatch {
     const uint16_t* Bs[SK_MAXB];
     uint16_t* C[SK_MAXB];
     int M[SK_MAXB], K[SK_MAXB], N[SK_MAXB];
+    FqPro pro;                      // producer prologue operands (shared by every problem of the launch)
 };
 
 template <bool INT4, int W, int P, int CT>
@@ -640,7 +770,7 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
 // wt (waves per tile: 1, 2 or 4) is per problem; the wave groups of a workgroup work on tiles of
 // one problem, so they execute the same barriers.  A wave group past the problem's last tile runs
 // the body on an out-of-range tile: its loads return zeros and it stores nothing.
-template <bool INT4, int P>
+template <bool INT4, int P, int PRO = 0>
 __global__ __launch_bounds__(256) void skinny_batch_sub_kernel(const SkinnyBatch bt) {
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
     const int blk = (int)blockIdx.x;
@@ -654,9 +784,9 @@ __global__ __launch_bounds__(256) void skinny_batch_sub_kernel(const SkinnyBatch
     float* lds = fq_lds + (size_t)sub * bt.lds_floats[pi];
     const uint16_t* X = reinterpret_cast<const uint16_t*>(bt.X[pi]);
     const uint8_t* B = reinterpret_cast<const uint8_t*>(bt.B[pi]);
-    if (wt == 1) fq_body<INT4, 1, P, 1>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds);
-    else if (wt == 2) fq_body<INT4, 2, P, 1>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds);
-    else fq_body<INT4, 4, P, 1>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds);
+    if (wt == 1) fq_body<INT4, 1, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, bt.pro);
+    else if (wt == 2) fq_body<INT4, 2, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, bt.pro);
+    else fq_body<INT4, 4, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, bt.pro);
 }
 
 int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
@@ -908,6 +1038,66 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     }
 #undef FQB_CASE
     return hipGetLastError();
+}
+
+// The batched fused launch with a producer prologue: every problem reads the same activation rows,
+// which each workgroup derives from the operands in front of the matmul.  kind 1: rms_norm(X [+ x2])
+// * w (the sum also goes to sum_out), 2: silu(X) * x2, 3: gelu(X) * x2.  Always the wave-group
+// kernel (per-problem waves per tile).
+hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyProblem* pr, size_t count,
+                                             const uint16_t* x2, const uint16_t* w, uint16_t* sum_out, float eps,
+                                             hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    if (count > (size_t)SK_MAXB || kind < 1 || kind > 3) return hipErrorInvalidValue;
+    if (kind == 1 && w == nullptr) return hipErrorInvalidValue;
+    if (kind != 1 && x2 == nullptr) return hipErrorInvalidValue;
+    SkinnyBatch bt;
+    memset(&bt, 0, sizeof bt);
+    bt.count = (int)count;
+    bt.pro.x2 = x2; bt.pro.w = w; bt.pro.sum_out = sum_out; bt.pro.eps = eps;
+    size_t order[SK_MAXB];
+    for (size_t i = 0; i < count; i++) order[i] = i;
+    size_t blocks = 0, lds_sub = 0;
+    for (size_t i = 0; i < count; i++) {
+        const SkinnyProblem& q = pr[order[i]];
+        if (q.X != pr[0].X || q.M != pr[0].M || q.K != pr[0].K) return hipErrorInvalidValue;   // one activation matrix
+        if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
+        if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+        const size_t kb = int4 ? q.K / 2 : q.K;
+        const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
+        size_t l = fq_lds_bytes(int4, wt, 1, q.M, q.K) + 16;            // + the rows' 1 / rms
+        if (kind == 1) l += 2 * q.M * q.K;                              // + the summed rows (binary16)
+        l = (l + 15) & ~(size_t)15;
+        bt.wt[i] = wt;
+        bt.lds_floats[i] = (int)(l / sizeof(float));
+        lds_sub = std::max(lds_sub, l * (4 / wt));
+        const size_t ptiles = (q.N + SK_TN - 1) / SK_TN, per = 4 / wt;
+        blocks += (ptiles + per - 1) / per;
+        if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+        bt.tile_end[i] = (int)blocks;
+        bt.X[i] = q.X; bt.B[i] = q.B; bt.Bs[i] = q.Bs; bt.C[i] = q.C;
+        bt.M[i] = (int)q.M; bt.K[i] = (int)q.K; bt.N[i] = (int)q.N;
+    }
+    if (blocks == 0) return hipSuccess;
+    if (lds_sub > 64 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(256);
+#define FQP_CASE(KIND)                                                                                        \
+    case KIND:                                                                                                \
+        if (int4) skinny_batch_sub_kernel<true, SK_BATCH_P, KIND><<<grid, block, lds_sub, st>>>(bt);          \
+        else skinny_batch_sub_kernel<false, SK_BATCH_P, KIND><<<grid, block, lds_sub, st>>>(bt);              \
+        break;
+    switch (kind) { FQP_CASE(1) FQP_CASE(2) FQP_CASE(3) }
+#undef FQP_CASE
+    return hipGetLastError();
+}
+
+bool skinny_fq_pro_ok(bool int4, int kind, size_t M, size_t K) {
+    if (!skinny_fused_quant_ok(int4, M, K)) return false;
+    const size_t kb = int4 ? K / 2 : K;
+    const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
+    size_t l = fq_lds_bytes(int4, wt, 1, M, K) + 16 + (kind == 1 ? 2 * M * K : 0);
+    l = (l + 15) & ~(size_t)15;
+    return l * (4 / wt) <= 64 * 1024;
 }
 
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,

@@ -82,6 +82,12 @@ SIGNATURES = {
     "cactus_hip_gelu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_quantize_kv_pair_fp16_to_int8_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp]),
     "cactus_hip_sample_greedy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_norm_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_norm_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_silu_f16act_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_silu_f16act_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int8_gelu_f16act_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_matmul_int4_gelu_f16act_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_sample_f16_dev": (_i, [_vp, _vp, _sz, _sz, _f, _f, _sz, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cactus_hip_sample_max_survivors": (_sz, []),
     "cactus_hip_sample_uniform": (_f, [C.c_uint32]),
@@ -224,6 +230,36 @@ class MatmulShared:
         _dev(A, torch.int8); _dev(A_scales, torch.float32)
         M, K = A.shape
         _check(self._fn(_p(A), _p(A_scales), self._arr, len(self._keep), M, K, self._gs, _stream()))
+
+
+class MatmulProduced:
+    """Weights multiplied with FP16 rows that the same launch derives from the ops in front of them:
+    entries = [(B, B_scales, out)];
+      run_norm(x, addend, norm_weight, eps, out_sum)  rows = rms_norm(x [+ addend]) * norm_weight
+      run_act(gate, up, act="silu" | "gelu")          rows = act(gate) * up
+    One launch for M <= 4 (cactus_hip_matmul_int{8,4}_{norm,silu,gelu}_f16act_dev)."""
+
+    def __init__(self, entries, group_size=128, int4=False):
+        self._keep = entries
+        self._arr = (MatmulWeights * len(entries))()
+        for i, (B, Bs, out) in enumerate(entries):
+            _dev(Bs, torch.float16); _dev(out, torch.float16)
+            self._arr[i] = MatmulWeights(B.data_ptr(), Bs.data_ptr(), out.data_ptr(), B.shape[0])
+        self._tag = "int4" if int4 else "int8"
+        self._gs = group_size
+
+    def run_norm(self, x, addend, norm_weight, eps, out_sum=None):
+        _dev(x, torch.float16); _dev(norm_weight, torch.float16)
+        M, K = x.shape
+        fn = getattr(lib, "cactus_hip_matmul_%s_norm_f16act_dev" % self._tag)
+        _check(fn(_p(x), _p(addend), _p(norm_weight), _p(out_sum), float(eps), self._arr, len(self._keep), M, K,
+                  self._gs, _stream()))
+
+    def run_act(self, gate, up, act="silu"):
+        _dev(gate, torch.float16); _dev(up, torch.float16)
+        M, K = gate.shape
+        fn = getattr(lib, "cactus_hip_matmul_%s_%s_f16act_dev" % (self._tag, act))
+        _check(fn(_p(gate), _p(up), self._arr, len(self._keep), M, K, self._gs, _stream()))
 
 
 def matmul_group_sums(A, B, group_size=128, int4=False):

@@ -140,6 +140,39 @@ int cactus_hip_matmul_int4_shared_dev(const int8_t* A, const float* A_scales,
                                       const cactus_hip_matmul_weights* weights, size_t count, size_t M,
                                       size_t K, size_t group_size, void* stream);
 
+/* The matmuls of a decoder block together with the op that produces their FP16 input, one launch
+ * for M <= 4 (a decode step; otherwise a producer + quantization launch followed by the matmuls):
+ *   _norm_: rows = rms_norm(input [+ addend]) * norm_weight -- the residual add and norm in front
+ *           of q/k/v or gate/up (model_qwen.cpp:51-57, 109-113); input + addend is also written
+ *           to sum_output (required when addend is given; must not alias input or addend).
+ *   _silu_ / _gelu_: rows = act(gate) * up -- in front of the down projection (:114-116).
+ * Each row is then quantized as compute_matmul_node quantizes FP16 activations
+ * (graph_ops_nn.cpp:35-66, 163-165) and multiplied with every weight entry.  Results equal
+ * cactus_hip_add_rms_norm_f16_dev / cactus_hip_{silu,gelu}_multiply_f16_dev followed by
+ * cactus_hip_matmul_int{8,4}_f16act_dev per entry, bit for bit.  K <= 16384. */
+int cactus_hip_matmul_int8_norm_f16act_dev(const cactus_half_t* input, const cactus_half_t* addend,
+                                           const cactus_half_t* norm_weight, cactus_half_t* sum_output,
+                                           float eps, const cactus_hip_matmul_weights* weights,
+                                           size_t count, size_t M, size_t K, size_t group_size,
+                                           void* stream);
+int cactus_hip_matmul_int4_norm_f16act_dev(const cactus_half_t* input, const cactus_half_t* addend,
+                                           const cactus_half_t* norm_weight, cactus_half_t* sum_output,
+                                           float eps, const cactus_hip_matmul_weights* weights,
+                                           size_t count, size_t M, size_t K, size_t group_size,
+                                           void* stream);
+int cactus_hip_matmul_int8_silu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count,
+                                           size_t M, size_t K, size_t group_size, void* stream);
+int cactus_hip_matmul_int4_silu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count,
+                                           size_t M, size_t K, size_t group_size, void* stream);
+int cactus_hip_matmul_int8_gelu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count,
+                                           size_t M, size_t K, size_t group_size, void* stream);
+int cactus_hip_matmul_int4_gelu_f16act_dev(const cactus_half_t* gate, const cactus_half_t* up,
+                                           const cactus_hip_matmul_weights* weights, size_t count,
+                                           size_t M, size_t K, size_t group_size, void* stream);
+
 /* cactus_matmul_f16 (kernel.h:49-50; kernel_gemm.cpp:102-126): C = A * B^T,
  * a half[M,K], b_transposed half[N,K].  Accumulates in fp32 (the reference
  * accumulates in fp16 lanes), so it is compared by tolerance. */

@@ -479,3 +479,79 @@ def test_matmul_shared_activations_one_launch_bit_exact(H, M, K, Ns, int4):
     for (B, Bs), o in zip(ws, outs):
         want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
         assert np.array_equal(bits(o), want)
+
+
+# --------------------------------------------------------------------------- matmuls with produced activations
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,Ns,with_add", [
+    (1, 1024, (2048, 1024, 1024), True),      # Qwen3 q/k/v behind the input norm
+    (1, 1024, (3072, 3072), True),            # gate/up behind the post-attention norm
+    (1, 1024, (2048,), False),                # plain norm (first layer), one weight
+    (4, 1024, (1000, 40), True),              # four rows, ragged N
+    (2, 3072, (1024,), True),
+    (3, 256, (64, 24), False),
+    (1, 8192, (512,), True),
+    (5, 1024, (2048, 1024), True),            # M > 4: producer + quantization launch, then the matmuls
+    (16, 512, (256,), False),
+    (40, 1024, (1024, 512), True),
+])
+def test_matmul_norm_f16act_equals_norm_then_matmuls(H, M, K, Ns, with_add, int4):
+    """Residual add + RMS norm + activation quantization + the matmuls that read the normalized rows
+    (model_qwen.cpp:51-57, 109-113), one launch for M <= 4: sum and every output bit-exact against
+    the oracle's add, rms_norm, activation quantization and matmul."""
+    if int4 and K % 256:
+        pytest.skip("packed units hold two groups")
+    rng = np.random.default_rng(M + K + sum(Ns) + int4 + with_add)
+    a = (rng.standard_normal((M, K)) * 1.5).astype(np.float16)
+    b = (rng.standard_normal((M, K)) * 1.5).astype(np.float16)
+    w = (1.0 + 0.1 * rng.standard_normal(K)).astype(np.float16)
+    ws = [(rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K) for N in Ns]
+    outs = [torch.full((M, N), 7.0, dtype=torch.float16, device="cuda") for N in Ns]
+    mp = H.MatmulProduced([(dev(B), dev(Bs.view(np.float16)), o) for (B, Bs), o in zip(ws, outs)], 128, int4)
+    out_sum = torch.full((M, K), 3.0, dtype=torch.float16, device="cuda") if with_add else None
+    mp.run_norm(dev(a), dev(b) if with_add else None, dev(w), 1e-6, out_sum)
+    want_sum = O.binary("add", a, b) if with_add else a.view(np.uint16)
+    if with_add:
+        assert np.array_equal(bits(out_sum), want_sum)
+    q, s = O.quantize_activations(O.rms_norm(want_sum, w, 1e-6))
+    for (B, Bs), o in zip(ws, outs):
+        want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
+        assert np.array_equal(bits(o), want)
+
+
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("act", ["silu", "gelu"])
+@pytest.mark.parametrize("M,K,Ns", [(1, 3072, (1024,)), (4, 3072, (1024,)), (2, 2048, (640, 24)), (1, 256, (16,)),
+                                    (1, 12288, (256,)), (7, 3072, (1024,)), (33, 512, (128, 64))])
+def test_matmul_activation_f16act_equals_activation_then_matmul(H, M, K, Ns, act, int4):
+    """act(gate) * up + activation quantization + the down projection (model_qwen.cpp:114-117), one
+    launch for M <= 4."""
+    if int4 and K % 256:
+        pytest.skip("packed units hold two groups")
+    rng = np.random.default_rng(M + K + sum(Ns) + int4)
+    g = (rng.standard_normal((M, K)) * 3).astype(np.float16)
+    u = rng.standard_normal((M, K)).astype(np.float16)
+    ws = [(rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K) for N in Ns]
+    outs = [torch.full((M, N), 7.0, dtype=torch.float16, device="cuda") for N in Ns]
+    mp = H.MatmulProduced([(dev(B), dev(Bs.view(np.float16)), o) for (B, Bs), o in zip(ws, outs)], 128, int4)
+    mp.run_act(dev(g), dev(u), act)
+    rows = O.binary("multiply", getattr(O, act)(g.reshape(-1)).view(np.float16), u.reshape(-1)).reshape(M, K)
+    q, s = O.quantize_activations(rows)
+    for (B, Bs), o in zip(ws, outs):
+        want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
+        assert np.array_equal(bits(o), want)
+
+
+def test_matmul_produced_argument_errors(H):
+    import ctypes as C
+    x = dev(np.zeros((1, 128), np.float16))
+    B = dev(np.zeros((16, 128), np.int8)); Bs = dev(np.ones((16, 1), np.float16))
+    o = torch.empty((1, 16), dtype=torch.float16, device="cuda")
+    arr = (H.MatmulWeights * 1)(H.MatmulWeights(B.data_ptr(), Bs.data_ptr(), o.data_ptr(), 16))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    fn = H.lib.cactus_hip_matmul_int8_norm_f16act_dev
+    assert fn(p(x), p(x), p(x), None, 1e-6, arr, 1, 1, 128, 128, None) != 0          # addend without sum_output
+    assert fn(p(x), None, None, None, 1e-6, arr, 1, 1, 128, 128, None) != 0          # no norm weight
+    assert fn(None, None, p(x), None, 1e-6, arr, 1, 1, 128, 128, None) != 0
+    assert H.lib.cactus_hip_matmul_int8_silu_f16act_dev(p(x), None, arr, 1, 1, 128, 128, None) != 0
+    assert fn(None, None, None, None, 1e-6, None, 0, 0, 128, 128, None) == 0         # nothing to do
