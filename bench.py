@@ -370,18 +370,13 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                     res = hid
             else:
                 shared[li][0].run(xq, xs)      # quantized by the norm launch that produced it
-            H.qk_norm_rope(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), L["q_norm"], L["k_norm"], eps, theta,
-                           pos, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
+            # q/k norm + RoPE, and the new token's K and V join the cache (slot cache_len of every
+            # sequence; the attention of this step reads them as FP16), one launch
+            H.qk_norm_rope_kv_append(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D),
+                                     L["q_norm"], L["k_norm"], eps, theta, pos, kc[li], vc[li], ksc[li], vsc[li], lens,
+                                     128, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
             a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
                                            kr.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
-            # the new token's K and V join the cache (slot cache_len of every sequence)
-            if batch == 1:   # straight into the cache slot
-                H.quantize_kv_pair(kr.view(1, Hkv, D), vo.view(1, Hkv, D), kc[li, 0, cache_len:cache_len + 1],
-                                   vc[li, 0, cache_len:cache_len + 1], ksc[li, 0, cache_len:cache_len + 1],
-                                   vsc[li, 0, cache_len:cache_len + 1])
-            else:            # one launch: every sequence's slot
-                H.kv_append_batched(kr.view(batch, Hkv, D), vo.view(batch, Hkv, D), kc[li], vc[li], ksc[li], vsc[li],
-                                    lens)
             proj(a.view(batch, Hq * D), L["o"], oo)
             nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
             if batch <= 4:

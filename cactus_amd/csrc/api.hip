@@ -613,6 +613,35 @@ int cactus_hip_qk_norm_rope_f16_dev(const cactus_half_t* q, const cactus_half_t*
     return CACTUS_HIP_OK;
 }
 
+int cactus_hip_qk_norm_rope_kv_append_f16_dev(const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v,
+                                              const cactus_half_t* q_weight, const cactus_half_t* k_weight,
+                                              cactus_half_t* q_output, cactus_half_t* k_output, int8_t* k_cache,
+                                              int8_t* v_cache, float* k_scales, float* v_scales, const int32_t* slots,
+                                              size_t batch_size, size_t seq_len, size_t num_q_heads,
+                                              size_t num_kv_heads, size_t head_dim, float eps, size_t start_pos,
+                                              float theta, size_t group_size, size_t cache_batch_stride,
+                                              size_t scale_batch_stride, size_t max_slots, void* stream) {
+    if (batch_size * seq_len * head_dim == 0 || num_q_heads + num_kv_heads == 0) return CACTUS_HIP_OK;
+    if (!q || !k || !v || !q_weight || !k_weight || !q_output || !k_output || !k_cache || !v_cache || !k_scales ||
+        !v_scales)
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_kv_append: null operand");
+    if (group_size == 0 || group_size > (size_t(1) << 20))
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_kv_append: bad group_size");
+    if ((head_dim & 1) || head_dim > 2048)
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_kv_append: head_dim must be even and <= 2048");
+    if (seq_len > (size_t(1) << 30) || num_q_heads > (size_t(1) << 20) || num_kv_heads > (size_t(1) << 20))
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_kv_append: dimension too large");
+    const uint16_t *c, *s;
+    int rc = rope_rows(head_dim, theta, start_pos, seq_len, &c, &s);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_qk_norm_rope_append(q, k, v, q_weight, k_weight, q_output, k_output, c, s, k_cache, v_cache,
+                                              k_scales, v_scales, slots, batch_size, seq_len, num_q_heads, num_kv_heads,
+                                              head_dim, eps, group_size, cache_batch_stride, scale_batch_stride,
+                                              max_slots, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "qk_norm_rope_kv_append launch", e);
+    return CACTUS_HIP_OK;
+}
+
 namespace {
 int unary_dev(int op, const char* name, const cactus_half_t* in, cactus_half_t* out, size_t n, void* stream) {
     if (n == 0) return CACTUS_HIP_OK;

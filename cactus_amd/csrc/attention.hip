@@ -569,6 +569,9 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnParams p) {
     }
 }
 
+// (Merging inside the attention launch -- every split fences, takes a ticket, the last one merges --
+// was measured and dropped: the device-scope fences write back and invalidate the XCD's L2 under the
+// other workgroups' K/V streams, 2-3.5x slower at every split shape.)
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws,
                                                         uint16_t* __restrict__ out, int nsplit, int D) {
     // one workgroup per output row; the per-split factors exp(m_s - M) go through LDS once,

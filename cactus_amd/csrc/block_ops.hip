@@ -179,6 +179,44 @@ __global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ 
 // launch: a 16-lane group takes one (token, head) row of head_dim elements, normalizes it into
 // LDS with the arithmetic of rms_norm_kernel, then rotates it with the arithmetic of rope_kernel.
 // Rows [0, tokens*Hq) are q rows, the rest k rows; cos_t / sin_t as in rope_kernel.
+// With `ap.v` set the launch also appends the step's K and V to the INT8 cache
+// (engine_cache.cpp:234-267): the rotated k row and the v row (rows [tokens*(Hq+Hkv),
+// tokens*(Hq+2*Hkv)) of the launch) are quantized per group of `gs` dims with the arithmetic of
+// kv_quant_kernel and stored at slot slots[b] + s of sequence b (slots == nullptr: row for row).
+struct KvAppendArgs {
+    const uint16_t* v = nullptr;
+    int8_t* kc = nullptr;
+    int8_t* vc = nullptr;
+    float* ks = nullptr;
+    float* vs = nullptr;
+    const int32_t* slots = nullptr;
+    size_t cache_batch_stride = 0, scale_batch_stride = 0, max_slots = 0;
+    int gs = 128;
+};
+
+// one row of D halves in LDS -> int8 + one scale per group, by the 16 lanes of a group; lane l
+// owns elements 8l..8l+7 of each 128-wide slice of a group (kernel_quants.cpp:223-293)
+__device__ __forceinline__ void quant_row_groups(const uint16_t* row, int D, int gs, int8_t* dst, float* sc, int l) {
+    const int G = (D + gs - 1) / gs;
+    for (int g = 0; g < G; g++) {
+        const int start = g * gs, cnt = min(gs, D - start), cnt8 = cnt & ~7;
+        float m = 0.0f;
+        for (int k0 = l * 8; k0 < cnt; k0 += 128)
+            for (int k = k0; k < k0 + 8 && k < cnt; k++) m = fmaxf(m, fabsf(h2f(row[start + k])));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+        float scale = m / 127.0f;
+        if (scale < 1e-10f) scale = 1e-10f;
+        const float inv = 1.0f / scale;
+        if (l == 0) sc[g] = scale;
+        for (int k0 = l * 8; k0 < cnt; k0 += 128)
+            for (int k = k0; k < k0 + 8 && k < cnt; k++) {
+                const float v = h2f(row[start + k]) * inv;
+                dst[start + k] = (int8_t)((k < cnt8) ? clamp_i8(rne_i32(v)) : clamp_i8((int)roundf(v)));
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __restrict__ q,
                                                            const uint16_t* __restrict__ k,
                                                            const uint16_t* __restrict__ qw,
@@ -186,42 +224,75 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
                                                            uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_out,
                                                            const uint16_t* __restrict__ cos_t,
                                                            const uint16_t* __restrict__ sin_t, size_t tokens,
-                                                           int Hq, int Hkv, int D, int seq_len, float eps) {
+                                                           int Hq, int Hkv, int D, int seq_len, float eps,
+                                                           const KvAppendArgs ap) {
     extern __shared__ uint16_t qk_lds[];   // [16][D]
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const size_t nq = tokens * Hq, total = nq + tokens * Hkv;
+    const size_t nq = tokens * Hq, nqk = nq + tokens * Hkv, total = nqk + (ap.v ? tokens * Hkv : 0);
     const size_t row = (size_t)blockIdx.x * 16 + grp;
     const bool live = row < total;
     const size_t r = live ? row : total - 1;
-    const bool is_q = r < nq;
-    const size_t hr = is_q ? r : r - nq;                    // token * heads + head
+    const bool is_q = r < nq, is_v = r >= nqk;
+    const size_t hr = is_q ? r : (is_v ? r - nqk : r - nq);   // token * heads + head
     const size_t token = hr / (is_q ? Hq : Hkv);
-    const uint16_t* xr = (is_q ? q : k) + hr * D;
-    const uint16_t* w = is_q ? qw : kw;
-    uint16_t* orow = (is_q ? q_out : k_out) + hr * D;
-    const int base = (threadIdx.x & 63) & ~15;
-    const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, D, eps, l, base);
-    const h16 inv_h = (h16)inv;
     uint16_t* nrm = qk_lds + grp * D;
-    const int simd_end = D & ~7;
-    for (int i = l; i < D; i += 16) nrm[i] = rms_out(xr[i], w[i], inv, inv_h, i < simd_end);
-    __syncthreads();
+    // where a k / v row goes in the cache
+    size_t doff = hr * D, soff = hr * (size_t)((D + ap.gs - 1) / ap.gs);
+    bool place = live && ap.v != nullptr && !is_q;
+    if (place && ap.slots != nullptr) {
+        const size_t b = token / seq_len, sq = token % seq_len, h = hr - token * Hkv;
+        const long sl = (long)ap.slots[b] + (long)sq;
+        place = ap.slots[b] >= 0 && (size_t)sl < ap.max_slots;
+        const size_t slot = place ? (size_t)sl : 0;
+        doff = b * ap.cache_batch_stride + (slot * Hkv + h) * D;
+        soff = b * ap.scale_batch_stride + (slot * Hkv + h) * (size_t)((D + ap.gs - 1) / ap.gs);
+    }
+    uint16_t* orow = (is_q ? q_out : k_out) + hr * D;
+    if (is_v) {   // a v row goes straight to the quantizer
+        const uint16_t* vr = ap.v + hr * D;
+        for (int i = l; i < D; i += 16) nrm[i] = vr[i];
+    } else {
+        const uint16_t* xr = (is_q ? q : k) + hr * D;
+        const uint16_t* w = is_q ? qw : kw;
+        const int base = (threadIdx.x & 63) & ~15;
+        const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, D, eps, l, base);
+        const h16 inv_h = (h16)inv;
+        const int simd_end = D & ~7;
+        for (int i = l; i < D; i += 16) nrm[i] = rms_out(xr[i], w[i], inv, inv_h, i < simd_end);
+    }
+    __syncthreads();   // the one barrier of the kernel, reached by every thread
     if (!live) return;
+    if (is_v) {
+        if (place) quant_row_groups(nrm, D, ap.gs, ap.vc + doff, ap.vs + soff, l);
+        return;
+    }
     const int half_dim = D / 2, s = (int)(token % seq_len);
     for (int i = l; i < half_dim; i += 16) {
         const uint16_t cb = cos_t[(size_t)s * half_dim + i], sb = sin_t[(size_t)s * half_dim + i];
         const uint16_t x1b = nrm[i], x2b = nrm[half_dim + i];
+        uint16_t o1, o2;
         if (i < (half_dim & ~7)) {
             const h16 c = bits2h(cb), sn = bits2h(sb), x1 = bits2h(x1b), x2 = bits2h(x2b);
             const h16 p1 = x1 * c, p2 = x2 * c;
-            orow[i] = h2bits(__builtin_fmaf16(-x2, sn, p1));
-            orow[half_dim + i] = h2bits(__builtin_fmaf16(x1, sn, p2));
+            o1 = h2bits(__builtin_fmaf16(-x2, sn, p1));
+            o2 = h2bits(__builtin_fmaf16(x1, sn, p2));
         } else {
             const float c = h2f(cb), sn = h2f(sb), x1 = h2f(x1b), x2 = h2f(x2b);
             const float pa = x1 * c, pb = x2 * sn, pd = x2 * c, pe = x1 * sn;
-            orow[i] = f2h(pa - pb);
-            orow[half_dim + i] = f2h(pd + pe);
+            o1 = f2h(pa - pb);
+            o2 = f2h(pd + pe);
         }
+        orow[i] = o1;
+        orow[half_dim + i] = o2;
+        if (place) { nrm[i] = o1; nrm[half_dim + i] = o2; }   // the lane's own two elements: the rotated row
+    }
+    if (place) {
+        // the 16 lanes of the group sit in one wave; their LDS writes are ordered before the reads
+        // below by the wait on the LDS counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        quant_row_groups(nrm, D, ap.gs, ap.kc + doff, ap.ks + soff, l);
     }
 }
 
@@ -552,7 +623,23 @@ hipError_t launch_qk_norm_rope(const uint16_t* q, const uint16_t* k, const uint1
                                hipStream_t st) {
     const size_t total = tokens * (Hq + Hkv);
     qk_norm_rope_kernel<<<dim3((unsigned)((total + 15) / 16)), dim3(256), 16 * D * sizeof(uint16_t), st>>>(
-        q, k, qw, kw, q_out, k_out, cos_t, sin_t, tokens, (int)Hq, (int)Hkv, (int)D, (int)seq_len, eps);
+        q, k, qw, kw, q_out, k_out, cos_t, sin_t, tokens, (int)Hq, (int)Hkv, (int)D, (int)seq_len, eps, KvAppendArgs());
+    return hipGetLastError();
+}
+
+hipError_t launch_qk_norm_rope_append(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* qw,
+                                      const uint16_t* kw, uint16_t* q_out, uint16_t* k_out, const uint16_t* cos_t,
+                                      const uint16_t* sin_t, int8_t* kc, int8_t* vc, float* ks, float* vs,
+                                      const int32_t* slots, size_t batch, size_t seq_len, size_t Hq, size_t Hkv,
+                                      size_t D, float eps, size_t gs, size_t cache_batch_stride,
+                                      size_t scale_batch_stride, size_t max_slots, hipStream_t st) {
+    const size_t tokens = batch * seq_len, total = tokens * (Hq + 2 * Hkv);
+    KvAppendArgs ap;
+    ap.v = v; ap.kc = kc; ap.vc = vc; ap.ks = ks; ap.vs = vs; ap.slots = slots;
+    ap.cache_batch_stride = cache_batch_stride; ap.scale_batch_stride = scale_batch_stride; ap.max_slots = max_slots;
+    ap.gs = (int)gs;
+    qk_norm_rope_kernel<<<dim3((unsigned)((total + 15) / 16)), dim3(256), 16 * D * sizeof(uint16_t), st>>>(
+        q, k, qw, kw, q_out, k_out, cos_t, sin_t, tokens, (int)Hq, (int)Hkv, (int)D, (int)seq_len, eps, ap);
     return hipGetLastError();
 }
 

@@ -141,6 +141,13 @@ hipError_t launch_embedding_int8(const int8_t* emb, const uint16_t* scales, cons
                                  hipStream_t st);
 hipError_t launch_argmax(const uint16_t* logits, uint32_t* out, size_t rows, size_t vocab,
                          unsigned long long* scratch, hipStream_t st);
+// the same launch also quantizes the rotated k rows and the v rows into the INT8 cache
+hipError_t launch_qk_norm_rope_append(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* qw,
+                                      const uint16_t* kw, uint16_t* q_out, uint16_t* k_out, const uint16_t* cos_t,
+                                      const uint16_t* sin_t, int8_t* kc, int8_t* vc, float* ks, float* vs,
+                                      const int32_t* slots, size_t batch, size_t seq_len, size_t Hq, size_t Hkv,
+                                      size_t D, float eps, size_t gs, size_t cache_batch_stride,
+                                      size_t scale_batch_stride, size_t max_slots, hipStream_t st);
 hipError_t launch_row_quant(int mode, const uint16_t* a, const uint16_t* b, const uint16_t* w, uint16_t* sum_out,
                             uint16_t* y_out, int8_t* q_out, float* scales_out, size_t rows, size_t dims, float eps,
                             hipStream_t st);

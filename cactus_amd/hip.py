@@ -82,6 +82,7 @@ SIGNATURES = {
     "cactus_hip_gelu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "cactus_hip_quantize_kv_pair_fp16_to_int8_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp]),
     "cactus_hip_sample_greedy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "cactus_hip_qk_norm_rope_kv_append_f16_dev": (_i, [_vp] * 12 + [_sz] * 5 + [_f, _sz, _f] + [_sz] * 4 + [_vp]),
     "cactus_hip_matmul_int8_norm_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_norm_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_silu_f16act_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -380,6 +381,28 @@ def qk_norm_rope(q, k, q_weight, k_weight, eps, theta, start_pos=0, out_q=None, 
     ok = out_k if out_k is not None else torch.empty_like(k)
     _check(lib.cactus_hip_qk_norm_rope_f16_dev(_p(q), _p(k), _p(q_weight), _p(k_weight), _p(oq), _p(ok), B, S, Hq,
                                                Hkv, D, float(eps), start_pos, float(theta), _stream()))
+    return oq, ok
+
+
+def qk_norm_rope_kv_append(q, k, v, q_weight, k_weight, eps, theta, start_pos, k_cache, v_cache, k_scales, v_scales,
+                           slots=None, group_size=128, out_q=None, out_k=None):
+    """qk_norm_rope plus the INT8 cache append of the step's K (rotated) and V, one launch.
+    q [B, S, Hq, D], k / v [B, S, Hkv, D]; caches [B, max_slots, Hkv, D] with slots int32 [B]
+    (sequence b's tokens go to slots[b] .. slots[b] + S - 1), or slots None and caches [B * S, Hkv, D]."""
+    _dev(q, torch.float16); _dev(k, torch.float16); _dev(v, torch.float16)
+    B, S, Hq, D = q.shape
+    Hkv = k.shape[2]
+    oq = out_q if out_q is not None else torch.empty_like(q)
+    ok = out_k if out_k is not None else torch.empty_like(k)
+    if slots is not None:
+        _dev(slots, torch.int32)
+        cbs, sbs, ms = k_cache.stride(0), k_scales.stride(0), k_cache.shape[1]
+    else:
+        cbs = sbs = ms = 0
+    _check(lib.cactus_hip_qk_norm_rope_kv_append_f16_dev(
+        _p(q), _p(k), _p(v), _p(q_weight), _p(k_weight), _p(oq), _p(ok), _p(k_cache), _p(v_cache), _p(k_scales),
+        _p(v_scales), _p(slots), B, S, Hq, Hkv, D, float(eps), start_pos, float(theta), group_size, cbs, sbs, ms,
+        _stream()))
     return oq, ok
 
 

@@ -259,6 +259,23 @@ int cactus_hip_qk_norm_rope_f16_dev(const cactus_half_t* q, const cactus_half_t*
                                     size_t seq_len, size_t num_q_heads, size_t num_kv_heads,
                                     size_t head_dim, float eps, size_t start_pos, float theta,
                                     void* stream);
+/* cactus_hip_qk_norm_rope_f16_dev plus the cache append of the step (KVCache::update_from_graph,
+ * engine_cache.cpp:234-267), one launch: the rotated k rows and the v rows half[batch, seq, Hkv, D]
+ * are quantized as cactus_quantize_kv_fp16_to_int8 does and stored at slot slots[b] + s of sequence
+ * b (k_cache / v_cache: sequence b at b * cache_batch_stride elements, k_scales / v_scales at
+ * b * scale_batch_stride; a slot outside [0, max_slots) stores nothing); slots == NULL stores row
+ * for row into int8[batch * seq, Hkv, D] / float[batch * seq, Hkv, G].  k_output still receives the
+ * FP16 rows the attention of this step reads. */
+int cactus_hip_qk_norm_rope_kv_append_f16_dev(const cactus_half_t* q, const cactus_half_t* k,
+                                              const cactus_half_t* v, const cactus_half_t* q_weight,
+                                              const cactus_half_t* k_weight, cactus_half_t* q_output,
+                                              cactus_half_t* k_output, int8_t* k_cache, int8_t* v_cache,
+                                              float* k_scales, float* v_scales, const int32_t* slots,
+                                              size_t batch_size, size_t seq_len, size_t num_q_heads,
+                                              size_t num_kv_heads, size_t head_dim, float eps,
+                                              size_t start_pos, float theta, size_t group_size,
+                                              size_t cache_batch_stride, size_t scale_batch_stride,
+                                              size_t max_slots, void* stream);
 int cactus_hip_silu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
                                      cactus_half_t* output, size_t num_elements, void* stream);
 int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,

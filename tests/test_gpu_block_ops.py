@@ -363,3 +363,59 @@ def test_kv_append_batched_equals_per_sequence_quantization(H):
             assert np.array_equal(ks[b, where[b]], oks[b]) and np.array_equal(vs[b, where[b]], ovs[b])
             kc[b, where[b]] = 0; vc[b, where[b]] = 0; ks[b, where[b]] = 0; vs[b, where[b]] = 0
     assert not kc.any() and not vc.any() and not ks.any() and not vs.any()
+
+
+# --------------------------------------------------------------------------- q/k norm + RoPE + cache append
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,gs,start", [(1, 1, 16, 8, 128, 128, 512), (3, 1, 16, 8, 128, 128, 9),
+                                                   (2, 3, 4, 2, 64, 128, 0), (1, 1, 4, 1, 256, 128, 77),
+                                                   (2, 2, 2, 1, 20, 128, 5), (1, 5, 3, 3, 192, 64, 1),
+                                                   (256, 1, 16, 8, 128, 128, 512)])
+def test_qk_norm_rope_kv_append_equals_the_separate_launches(H, B, S, Hq, Hkv, D, gs, start):
+    """model_qwen.cpp:63-81 followed by the cache append of engine_cache.cpp:234-267: q / k outputs as
+    qk_norm_rope, cache slots as cactus_quantize_kv_fp16_to_int8 of the rotated k and of v."""
+    rng = np.random.default_rng(B * 31 + S + D + gs)
+    q, k = halves(rng, (B, S, Hq, D), 3.0), halves(rng, (B, S, Hkv, D), 3.0)
+    v = halves(rng, (B, S, Hkv, D), 2.0)
+    qw = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float16)
+    kw = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float16)
+    G = (D + gs - 1) // gs
+    max_slots = 12
+    slots = rng.integers(0, max_slots - S + 1, B).astype(np.int32)
+    if B > 2:
+        slots[1] = max_slots        # out of range: nothing is stored for that sequence
+        slots[2] = -1
+    kc = torch.full((B, max_slots, Hkv, D), 99, dtype=torch.int8, device="cuda"); vc = torch.full_like(kc, 99)
+    ks = torch.full((B, max_slots, Hkv, G), -1.0, dtype=torch.float32, device="cuda"); vs = torch.full_like(ks, -1.0)
+    oq, ok = H.qk_norm_rope_kv_append(dev(q), dev(k), dev(v), dev(qw), dev(kw), 1e-6, 1e6, start, kc, vc, ks, vs,
+                                      dev(slots), gs)
+    want_q = O.rope(O.rms_norm(q.reshape(-1, D), qw, 1e-6).reshape(q.shape), 1e6, start)
+    want_k = O.rope(O.rms_norm(k.reshape(-1, D), kw, 1e-6).reshape(k.shape), 1e6, start)
+    assert np.array_equal(bits(oq), want_q) and np.array_equal(bits(ok), want_k)
+    kc, vc, ks, vs = kc.cpu().numpy(), vc.cpu().numpy(), ks.cpu().numpy(), vs.cpu().numpy()
+    for b in range(B):
+        wkq, wks = O.quantize_kv(want_k[b].view(np.float16), gs)
+        wvq, wvs = O.quantize_kv(v[b], gs)
+        ok_slot = 0 <= slots[b] and slots[b] + S <= max_slots
+        for s in range(max_slots):
+            inside = ok_slot and slots[b] <= s < slots[b] + S
+            if inside:
+                j = s - slots[b]
+                assert np.array_equal(kc[b, s], wkq[j]) and np.array_equal(vc[b, s], wvq[j]), (b, s)
+                assert np.array_equal(ks[b, s], wks[j].reshape(Hkv, G)) and np.array_equal(vs[b, s], wvs[j].reshape(Hkv, G))
+            else:
+                assert (kc[b, s] == 99).all() and (vc[b, s] == 99).all() and (ks[b, s] == -1).all(), (b, s)
+
+
+def test_qk_norm_rope_kv_append_row_for_row(H):
+    """slots NULL: the quantized rows land row for row (the quantize_kv_pair layout)."""
+    rng = np.random.default_rng(12)
+    B, S, Hq, Hkv, D = 1, 4, 4, 2, 128
+    q, k, v = halves(rng, (B, S, Hq, D), 3.0), halves(rng, (B, S, Hkv, D), 3.0), halves(rng, (B, S, Hkv, D), 2.0)
+    qw = np.ones(D, np.float16); kw = np.ones(D, np.float16)
+    kc = torch.zeros((B * S, Hkv, D), dtype=torch.int8, device="cuda"); vc = torch.zeros_like(kc)
+    ks = torch.zeros((B * S, Hkv, 1), dtype=torch.float32, device="cuda"); vs = torch.zeros_like(ks)
+    _, ok = H.qk_norm_rope_kv_append(dev(q), dev(k), dev(v), dev(qw), dev(kw), 1e-6, 1e4, 3, kc, vc, ks, vs)
+    wkq, wks = O.quantize_kv(bits(ok).reshape(S, Hkv, D).view(np.float16))
+    wvq, wvs = O.quantize_kv(v.reshape(S, Hkv, D))
+    assert np.array_equal(kc.cpu().numpy(), wkq) and np.array_equal(vc.cpu().numpy(), wvq)
+    assert np.array_equal(ks.cpu().numpy().reshape(-1), wks.reshape(-1)) and np.array_equal(vs.cpu().numpy().reshape(-1), wvs.reshape(-1))
