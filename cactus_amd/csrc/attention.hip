@@ -650,12 +650,14 @@ void launch_t(const AttnParams& p, dim3 grid, hipStream_t st) {
 }  // namespace
 
 size_t attn_workspace_bytes(const AttnArgs& a) {
+    if (attn_prefill_ok(a)) return 0;
     const Plan pl = make_plan(a);
     if (pl.nsplit <= 1) return 0;
     return a.B * a.Hq * a.S * (size_t)pl.nsplit * (a.D + 2) * sizeof(float);
 }
 
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) {
+    if (attn_prefill_ok(a)) return launch_attention_prefill(a, st);
     const Plan pl = make_plan(a);
     AttnParams p;
     p.a = a;

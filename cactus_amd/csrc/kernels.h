@@ -117,6 +117,11 @@ struct AttnArgs {
 size_t attn_workspace_bytes(const AttnArgs& a);
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 
+// attention_prefill.hip: cactus_attention_f16 for many queries on the FP16 matrix cores (head_dim 64 /
+// 128, no window, no mask tensor); launch_attention routes eligible calls there
+bool attn_prefill_ok(const AttnArgs& a);
+hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st);
+
 // block_ops.hip: the ops between the hot kernels of a decoder block
 hipError_t launch_rms_norm(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t rows, size_t dims, float eps,
                            hipStream_t st);

@@ -408,6 +408,13 @@ F16ATT = [
     (1, 2, 2, 1, 1, 4, 0, 0, True, False),           # tests/test_graph.cpp:220-240 shape, any-shape kernel
     (1, 35, 35, 2, 2, 20, 0, 8, True, False),
     (1, 5, 70, 3, 1, 36, 65, 0, False, True),
+    # many queries, head_dim 64 / 128, no window, no mask: the matrix-core prefill kernel
+    (1, 300, 300, 4, 2, 128, 0, 0, True, False),     # ragged query tile and key block
+    (1, 130, 200, 4, 2, 64, 70, 0, True, False),     # chunk with an offset into a longer K/V
+    (2, 40, 75, 2, 1, 128, 0, 0, False, False),      # non-causal, 75 = 2 blocks + 11 (tail of 3 uses expf)
+    (1, 33, 131, 8, 8, 64, 98, 0, True, False),
+    (1, 1024, 1024, 2, 1, 128, 0, 0, True, False),
+    (3, 64, 64, 6, 3, 64, 0, 0, True, False),
 ]
 
 
