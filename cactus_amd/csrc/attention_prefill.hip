@@ -50,8 +50,12 @@ __device__ __forceinline__ float pf_weight(float s, float bmax, bool poly) {
     return y * __uint_as_float(e);
 }
 
+#ifndef PF_WAVES_PER_EU
+#define PF_WAVES_PER_EU 2
+#endif
 template <int D>
-__global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF_WAVES_PER_EU, PF_WAVES_PER_EU)))
+void attn_prefill_kernel(const AttnArgs a) {
     constexpr int KROW = D + 8;            // halves per K row in LDS (16-byte aligned, banks shifted)
     constexpr int VROW = PF_BLOCK + 4;     // halves per V^T row in LDS (8-byte aligned)
     constexpr int NDT = D / 32;            // 32-wide d tiles of the output
@@ -92,15 +96,22 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
     const uint16_t* Vb = a.v_new + (size_t)b * KV * Hkv * D + (size_t)kvh * D;
     const size_t kv_stride = (size_t)Hkv * D;   // halves between consecutive keys
 
-    // staging: piece p of a thread = 8 halves (key, d8) of the block
+    // staging: a piece = 8 halves (key, d8) of the block.  K pieces follow the rows (coalesced
+    // loads, 16-byte LDS stores).  V pieces are taken key-major -- lane = (key = lane % 32, two
+    // d8 columns per wave) -- so that the 2-byte stores of the transposition land on distinct
+    // banks: row d of V^T is 18 dwords, the 32 keys of a lane group fill 16 consecutive dwords,
+    // the wave's second d8 column sits 8 rows = 144 dwords (16 banks) further.
     v4i kst[PPT], vst[PPT];
+    const int vkey = lane & 31;
     auto fetch = [&](int blk) {
 #pragma unroll
         for (int p = 0; p < PPT; p++) {
             const int idx = p * 256 + tid, key = idx / (D / 8), d8 = idx % (D / 8);
             const int kp = min(blk * PF_BLOCK + key, KV - 1);
             kst[p] = *reinterpret_cast<const v4i*>(Kb + (size_t)kp * kv_stride + d8 * 8);
-            vst[p] = *reinterpret_cast<const v4i*>(Vb + (size_t)kp * kv_stride + d8 * 8);
+            const int vd8 = (p * 4 + w) * 2 + g;
+            const int vp = min(blk * PF_BLOCK + vkey, KV - 1);
+            vst[p] = *reinterpret_cast<const v4i*>(Vb + (size_t)vp * kv_stride + vd8 * 8);
         }
     };
     auto stash = [&]() {
@@ -108,9 +119,10 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
         for (int p = 0; p < PPT; p++) {
             const int idx = p * 256 + tid, key = idx / (D / 8), d8 = idx % (D / 8);
             *reinterpret_cast<v4i*>(sK + key * KROW + d8 * 8) = kst[p];
+            const int vd8 = (p * 4 + w) * 2 + g;
 #pragma unroll
             for (int e = 0; e < 8; e++)
-                sVt[(d8 * 8 + e) * VROW + key] = (uint16_t)(((uint32_t)vst[p][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                sVt[(vd8 * 8 + e) * VROW + vkey] = (uint16_t)(((uint32_t)vst[p][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
         }
     };
 
@@ -143,33 +155,63 @@ __global__ __launch_bounds__(256) void attn_prefill_kernel(const AttnArgs a) {
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
         }
 
-        // this lane's 16 keys: in-block index 8*(r/4) + 4*g + r%4
-        float sc[16];
-        float bm = -INFINITY;
+        // This lane's 16 keys: in-block index ib = 8*(r/4) + 4*g + r%4.  A key is visible when
+        // ib < lim (the block's keys below KV and, if causal, not after the query); most blocks
+        // are visible to the whole wave and whole (32 keys, all on the polynomial) -- that path
+        // has no per-element selects.
+        const int lim_blk = ke - kb;
+        const int lim = a.is_causal ? (int)max(-1LL, min((long long)lim_blk, qabs - kb + 1)) : lim_blk;
+        const bool full = lim_blk == PF_BLOCK && (!a.is_causal || off + q_first - kb + 1 >= PF_BLOCK) && q_first + 31 < S;
+        const int limg = lim - 4 * g;
+        float sc[16], wgt[16];
+        float bm = -INFINITY, bsum = 0.0f;
+        if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int ib = 8 * (r >> 2) + 4 * g + (r & 3);
-            const int kp = kb + ib;
-            const bool masked = kp >= ke || (a.is_causal && (long long)kp > qabs);
-            sc[r] = masked ? -INFINITY : sacc[r] * scale;
-            bm = fmaxf(bm, sc[r]);
+            for (int r = 0; r < 16; r++) {
+                sc[r] = sacc[r] * scale;
+                bm = fmaxf(bm, sc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[r] = (8 * (r >> 2) + (r & 3) < limg) ? sacc[r] * scale : -INFINITY;
+                bm = fmaxf(bm, sc[r]);
+            }
         }
         bm = fmaxf(bm, __shfl_xor(bm, 32));
         if (bm > -INFINITY) {            // :160-169, the running maximum is replaced
             const float corr = __expf(m_run - bm);
             l_run *= corr;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f c2 = {corr, corr};
 #pragma unroll
             for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) o[dt][r] *= corr;
+                for (int r = 0; r < 16; r += 2) {
+                    const v2f t = v2f{o[dt][r], o[dt][r + 1]} * c2;
+                    o[dt][r] = t[0];
+                    o[dt][r + 1] = t[1];
+                }
             m_run = bm;
         }
-        float wgt[16], bsum = 0.0f;
+        // weights: the polynomial of :178-191 evaluated without branches (a masked key's -inf gives
+        // garbage that the select discards); the expf tail of :197-204 only exists in a block that
+        // ends at KV with KV % 4 != 0
+        const int vecg = vec - 4 * g;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int ib = 8 * (r >> 2) + 4 * g + (r & 3);
-            wgt[r] = pf_weight(sc[r], bm, ib < vec);
-            bsum += wgt[r];
+            const float x = (sc[r] - bm) * 1.442695f;
+            const int xi = (int)x;
+            const float xf = x - (float)xi;
+            float y = fmaf(xf, 0.6931472f, 1.0f);
+            y = fmaf(xf * xf, 0.2402265f, y);
+            float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
+            if (!full) {
+                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(sc[r] - bm);
+                wv = (sc[r] == -INFINITY) ? 0.0f : wv;
+            }
+            wgt[r] = wv;
+            bsum += wv;
         }
         bsum += __shfl_xor(bsum, 32);
         l_run += bsum;
