@@ -494,6 +494,18 @@ def extra_table(H, gen, big):
     ex["block_ops_prefill"] = rows
     del xa, xb, o1, o2, q4, k4, oq, ok, ga, up, oa
     torch.cuda.empty_cache()
+    # FP16 causal prefill attention (Qwen3 heads), one layer: the matrix-core kernel
+    rows = {}
+    for S in (256, 1024, 4096):
+        q = (torch.rand((1, S, 16, 128), device="cuda", generator=gen) * 2 - 1).half()
+        k = (torch.rand((1, S, 8, 128), device="cuda", generator=gen) * 2 - 1).half()
+        v = (torch.rand((1, S, 8, 128), device="cuda", generator=gen) * 2 - 1).half()
+        o = torch.empty_like(q)
+        ms = time_graph(lambda i: H.attention_f16(q, k, v, 0.0, out=o), 4)
+        fl = 4.0 * S * S / 2 * 16 * 128        # causal: half of the S x S scores
+        rows[f"S{S}"] = {"us": round(ms * 1e3, 1), "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
+                         "frac_fp16_mfma_peak": round(fl / (ms * 1e-3) / 2.5e15, 4)}
+    ex["attn_prefill_f16_causal"] = rows
     # decode tail at the Qwen3 vocabulary: the stochastic sampler (engine defaults: temperature
     # 0.6, top-p 0.95, top-k 20) against the greedy one, and the entropy figure
     rows = {}

@@ -67,8 +67,17 @@ void attn_prefill_kernel(const AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jq = lane & 31, g = lane >> 5;
     const int S = (int)a.S, KV = (int)a.new_len, Hq = (int)a.Hq, Hkv = (int)a.Hkv;
-    const int qt = (int)(gridDim.x - 1 - blockIdx.x);   // long (late) query tiles first
-    const int h = blockIdx.y, b = blockIdx.z;
+    // Work items ranked by weight (a causal tile's work grows with its position): rank k -> tile
+    // nt-1 - k / (Hq*B).  The first half of the launch takes the heavy half in descending order, the
+    // second half the light half in ascending order, so the two workgroups that share a CU (ids i
+    // and i + total/2 when the chip holds the whole launch) add up to the same work everywhere
+    // (S = 4096, 16 heads: 341 -> 276 us).  Two LDS stages with one barrier per block measured
+    // slower (306 us) than this single stage with two.
+    const int nt = (S + PF_QTILE - 1) / PF_QTILE, hb = Hq * (int)a.B, total = nt * hb;
+    const int id = (int)blockIdx.x, half = (total + 1) / 2;
+    const int rank = id < half ? id : total - 1 - (id - half);
+    const int qt = nt - 1 - rank / hb;
+    const int h = (rank % hb) % Hq, b = (rank % hb) / Hq;
     const int kvh = h / (Hq / Hkv);
     const int q_first = qt * PF_QTILE + w * 32;         // first query of the wave
     const int qi = q_first + jq;                        // this lane's query
@@ -265,14 +274,16 @@ void attn_prefill_kernel(const AttnArgs a) {
 bool attn_prefill_ok(const AttnArgs& a) {
     return a.f16_mode && a.mask == nullptr && a.window_size == 0 && (a.D == 64 || a.D == 128) && a.S >= 32 &&
            a.new_len >= 1 && a.new_len < (size_t(1) << 30) && a.S < (size_t(1) << 30) && a.Hkv > 0 &&
-           a.Hq % a.Hkv == 0 && a.Hq <= 65535 && a.B <= 65535 &&
+           a.Hq % a.Hkv == 0 && a.Hq <= 65535 && a.B <= 65535 && a.Hq * a.B <= 1048576 &&
            ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k_new) |
              reinterpret_cast<uintptr_t>(a.v_new) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
 }
 
 hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st) {
     if (!attn_prefill_ok(a)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((a.S + PF_QTILE - 1) / PF_QTILE), (unsigned)a.Hq, (unsigned)a.B), block(256);
+    const size_t total = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B;
+    if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)total), block(256);
     if (a.D == 128) attn_prefill_kernel<128><<<grid, block, 0, st>>>(a);
     else attn_prefill_kernel<64><<<grid, block, 0, st>>>(a);
     return hipGetLastError();

@@ -565,11 +565,11 @@ def embedding(table, indices, scales=None, group_size=128, out=None, check=True)
     return o
 
 
-def attention_f16(q, k, v, scale, mask=None, position_offset=0, window_size=0, is_causal=True):
+def attention_f16(q, k, v, scale, mask=None, position_offset=0, window_size=0, is_causal=True, out=None):
     _dev(q, torch.float16); _dev(k, torch.float16); _dev(v, torch.float16)
     B, S, Hq, D = q.shape
     KV, Hkv = k.shape[1], k.shape[2]
-    out = torch.empty_like(q)
+    out = out if out is not None else torch.empty_like(q)
     _check(lib.cactus_hip_attention_f16_dev(_p(q), _p(k), _p(v), _p(out), B, S, KV, Hq, Hkv, D,
                                             float(scale), _p(mask), position_offset, window_size,
                                             int(bool(is_causal)), _stream()))
