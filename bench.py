@@ -506,6 +506,22 @@ def extra_table(H, gen, big):
         rows[f"S{S}"] = {"us": round(ms * 1e3, 1), "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1),
                          "frac_fp16_mfma_peak": round(fl / (ms * 1e-3) / 2.5e15, 4)}
     ex["attn_prefill_f16_causal"] = rows
+    # a 256-token prefill chunk against the INT8 cache (the chunks after the first)
+    rows = {}
+    for cache in (256, 2048, 3840):
+        S, Hq_, Hkv_, D_ = 256, 16, 8, 128
+        q = (torch.rand((1, S, Hq_, D_), device="cuda", generator=gen) * 2 - 1).half()
+        kn = (torch.rand((1, S, Hkv_, D_), device="cuda", generator=gen) * 2 - 1).half()
+        vn = (torch.rand((1, S, Hkv_, D_), device="cuda", generator=gen) * 2 - 1).half()
+        kc = torch.randint(-127, 128, (cache, Hkv_, D_), dtype=torch.int8, device="cuda", generator=gen)
+        vc = torch.randint(-127, 128, (cache, Hkv_, D_), dtype=torch.int8, device="cuda", generator=gen)
+        ks = torch.rand((cache, Hkv_, 1), device="cuda", generator=gen) * 0.02
+        vs = torch.rand((cache, Hkv_, 1), device="cuda", generator=gen) * 0.02
+        H.attention_hybrid(q, kc, vc, ks, vs, kn, vn, 0.0, position_offset=cache)      # sizes the workspace
+        ms = time_graph(lambda i: H.attention_hybrid(q, kc, vc, ks, vs, kn, vn, 0.0, position_offset=cache), 4)
+        fl = 4.0 * S * (cache + S / 2) * Hq_ * D_
+        rows[f"cache{cache}"] = {"us": round(ms * 1e3, 1), "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 1)}
+    ex["attn_prefill_chunk256_int8kv"] = rows
     # decode tail at the Qwen3 vocabulary: the stochastic sampler (engine defaults: temperature
     # 0.6, top-p 0.95, top-k 20) against the greedy one, and the entropy figure
     rows = {}

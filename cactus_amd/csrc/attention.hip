@@ -651,6 +651,10 @@ void launch_t(const AttnParams& p, dim3 grid, hipStream_t st) {
 
 size_t attn_workspace_bytes(const AttnArgs& a) {
     if (attn_prefill_ok(a)) return 0;
+    if (attn_prefill_hybrid_ok(a)) {
+        const int ns = attn_prefill_hybrid_splits(a);
+        return ns <= 1 ? 0 : a.B * a.Hq * a.S * (size_t)ns * (a.D + 2) * sizeof(float);
+    }
     const Plan pl = make_plan(a);
     if (pl.nsplit <= 1) return 0;
     return a.B * a.Hq * a.S * (size_t)pl.nsplit * (a.D + 2) * sizeof(float);
@@ -658,6 +662,16 @@ size_t attn_workspace_bytes(const AttnArgs& a) {
 
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) {
     if (attn_prefill_ok(a)) return launch_attention_prefill(a, st);
+    if (attn_prefill_hybrid_ok(a)) {
+        hipError_t e = launch_attention_prefill_hybrid(a, reinterpret_cast<float*>(workspace), st);
+        const int ns = attn_prefill_hybrid_splits(a);
+        if (e == hipSuccess && ns > 1) {
+            attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(
+                reinterpret_cast<const float*>(workspace), a.out, ns, (int)a.D);
+            e = hipGetLastError();
+        }
+        return e;
+    }
     const Plan pl = make_plan(a);
     AttnParams p;
     p.a = a;

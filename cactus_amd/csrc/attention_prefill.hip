@@ -269,7 +269,303 @@ void attn_prefill_kernel(const AttnArgs a) {
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// cactus_attention_hybrid_int8_fp16 (kernel_attention.cpp:257-482) for a chunk of many queries:
+// the same transposed MFMA scheme over the INT8 cache followed by the chunk's own FP16 keys.
+//  - A cached block is converted to binary16 on its way into LDS (an int8 is exact there); the
+//    per-key scales (one group per head: head_dim <= group size) multiply the score column and the
+//    weight of the key, as in attn_kernel: s = (q . k8) * k_scale * scale, O += (w * v_scale) * v8.
+//  - Standard online softmax with expf (:395-414), so partial results over disjoint key ranges
+//    combine exactly like the decode kernel's: the key blocks of a query tile are cut into
+//    `nsplit` ranges, each a workgroup of its own writing (max, sum, unnormalised O) records that
+//    attn_merge_kernel reduces.  A chunk has few query tiles and a long cache: without the split the
+//    launch is a handful of workgroups each walking the whole cache.
+// ---------------------------------------------------------------------------------------
+struct HybridPlan { int nsplit; };
+
+// 4 int8 -> 4 binary16 (exact): bytes ^ 0x80 are u = x + 128; 0x6400 | u is 1024 + u; minus 1152
+__device__ __forceinline__ uint2 i8x4_to_f16x4(uint32_t x) {
+    typedef _Float16 v2hf __attribute__((ext_vector_type(2)));
+    const uint32_t y = x ^ 0x80808080u;
+    const uint32_t lo = __builtin_amdgcn_perm(0x64646464u, y, 0x04010400u);
+    const uint32_t hi = __builtin_amdgcn_perm(0x64646464u, y, 0x04030402u);
+    const v2hf bias = {(_Float16)1152.0f, (_Float16)1152.0f};
+    const v2hf a = __builtin_bit_cast(v2hf, lo) - bias, b = __builtin_bit_cast(v2hf, hi) - bias;
+    return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+}
+
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF_WAVES_PER_EU, PF_WAVES_PER_EU)))
+void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int nsplit) {
+    constexpr int KROW = D + 8, VROW = PF_BLOCK + 4, NDT = D / 32, NST = D / 16;
+    constexpr int D16 = D / 16;            // 16-element pieces per row: a thread stages (key, d16)
+    __shared__ __attribute__((aligned(16))) uint16_t sK[PF_BLOCK * KROW];
+    __shared__ __attribute__((aligned(16))) uint16_t sVt[D * VROW];
+    __shared__ __attribute__((aligned(16))) float sKs[PF_BLOCK], sVs[PF_BLOCK];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jq = lane & 31, g = lane >> 5;
+    const int S = (int)a.S, Hq = (int)a.Hq, Hkv = (int)a.Hkv, new_len = (int)a.new_len;
+    const int nt = (S + PF_QTILE - 1) / PF_QTILE;
+    int item = (int)blockIdx.x;
+    const int split = item % nsplit; item /= nsplit;
+    const int qt = nt - 1 - item % nt; item /= nt;
+    const int h = item % Hq, b = item / Hq;
+    const int kvh = h / (Hq / Hkv);
+    const int q_first = qt * PF_QTILE + w * 32;
+    const int qi = q_first + jq;
+    const bool q_live = qi < S;
+    const int cl = a.cache_lens ? a.cache_lens[b] : (int)a.cache_len;
+    const int KV = cl + new_len;
+    const long long off = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset);
+    float scale = a.scale;
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);
+
+    // keys visible to a query: [0, kv_end); cached blocks cover [0, min(cl, kv_end)), the chunk's own
+    // FP16 keys [cl, kv_end) in blocks of their own (:331-334, :351-388)
+    auto kv_end_of = [&](int q) { return a.is_causal ? (int)max(0LL, min((long long)KV, off + q + 1)) : KV; };
+    const int kv_end_wg = kv_end_of(min(S, (qt + 1) * PF_QTILE) - 1);
+    const int kv_end_wave_hi = kv_end_of(min(S - 1, q_first + 31));   // the wave's last query sees the most
+    const int kv_end_wave_lo = kv_end_of(q_first);
+    const int kv_end = kv_end_of(qi);
+    const int nbc = (min(cl, kv_end_wg) + PF_BLOCK - 1) / PF_BLOCK;
+    const int nbn = kv_end_wg > cl ? (kv_end_wg - cl + PF_BLOCK - 1) / PF_BLOCK : 0;
+    const int nblk = nbc + nbn;
+    const int bps = (nblk + nsplit - 1) / nsplit;
+    const int blk_first = split * bps, blk_last = min(nblk, blk_first + bps);
+
+    v8hf qf[NST];
+    {
+        const uint16_t* qrow = a.q + (((size_t)b * S + min(qi, S - 1)) * Hq + h) * D;
+#pragma unroll
+        for (int st = 0; st < NST; st++) qf[st] = *reinterpret_cast<const v8hf*>(qrow + st * 16 + g * 8);
+    }
+    const int8_t* Kc = a.k_cached + (size_t)b * a.cache_batch_stride + (size_t)kvh * D;
+    const int8_t* Vc = a.v_cached + (size_t)b * a.cache_batch_stride + (size_t)kvh * D;
+    const float* Ks = a.k_scales + (size_t)b * a.scale_batch_stride + kvh;
+    const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride + kvh;
+    const uint16_t* Kn = a.k_new + (size_t)b * new_len * Hkv * D + (size_t)kvh * D;
+    const uint16_t* Vn = a.v_new + (size_t)b * new_len * Hkv * D + (size_t)kvh * D;
+    const size_t row_stride = (size_t)Hkv * D;   // elements between consecutive tokens
+
+    // staging: thread = (key = lane % 32, d16 = 2 * wave + lane / 32): 16 elements of K and of V
+    const int skey = lane & 31, sd16 = w * 2 + g;
+    const bool stager = sd16 < D16;
+    v4i kst[2], vst[2];          // cached: [0] holds 16 int8; FP16: two pieces of 8 halves
+    float ksv = 1.0f, vsv = 1.0f;
+    auto fetch = [&](int blk) {
+        if (blk < nbc) {
+            const int kp = min(blk * PF_BLOCK + skey, cl - 1);
+            if (stager) {
+                kst[0] = *reinterpret_cast<const v4i*>(Kc + (size_t)kp * row_stride + sd16 * 16);
+                vst[0] = *reinterpret_cast<const v4i*>(Vc + (size_t)kp * row_stride + sd16 * 16);
+            }
+            if (tid < 32) ksv = Ks[(size_t)kp * Hkv];
+            else if (tid < 64) vsv = Vs[(size_t)kp * Hkv];
+        } else {
+            const int kp = min((blk - nbc) * PF_BLOCK + skey, new_len - 1);
+            if (stager) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    kst[u] = *reinterpret_cast<const v4i*>(Kn + (size_t)kp * row_stride + sd16 * 16 + u * 8);
+                    vst[u] = *reinterpret_cast<const v4i*>(Vn + (size_t)kp * row_stride + sd16 * 16 + u * 8);
+                }
+            }
+            ksv = 1.0f;
+            vsv = 1.0f;
+        }
+    };
+    auto stash = [&](int blk) {
+        if (stager) {
+            v4i kh[2], vh[2];
+            if (blk < nbc) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint2 k0 = i8x4_to_f16x4((uint32_t)kst[0][2 * u]), k1 = i8x4_to_f16x4((uint32_t)kst[0][2 * u + 1]);
+                    const uint2 v0 = i8x4_to_f16x4((uint32_t)vst[0][2 * u]), v1 = i8x4_to_f16x4((uint32_t)vst[0][2 * u + 1]);
+                    kh[u] = v4i{(int)k0.x, (int)k0.y, (int)k1.x, (int)k1.y};
+                    vh[u] = v4i{(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                }
+            } else {
+                kh[0] = kst[0]; kh[1] = kst[1]; vh[0] = vst[0]; vh[1] = vst[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                *reinterpret_cast<v4i*>(sK + skey * KROW + sd16 * 16 + u * 8) = kh[u];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    sVt[(sd16 * 16 + u * 8 + e) * VROW + skey] = (uint16_t)(((uint32_t)vh[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+            }
+        }
+        if (tid < 32) sKs[tid] = ksv;
+        else if (tid < 64) sVs[tid - 32] = vsv;
+    };
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    v16f o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
+
+    if (blk_first < blk_last) fetch(blk_first);
+    for (int blk = blk_first; blk < blk_last; blk++) {
+        __syncthreads();
+        stash(blk);
+        __syncthreads();
+        if (blk + 1 < blk_last) fetch(blk + 1);
+
+        const bool cached = blk < nbc;
+        const int kb = cached ? blk * PF_BLOCK : cl + (blk - nbc) * PF_BLOCK;    // first key (absolute)
+        const int seg_end_hi = cached ? min(cl, kv_end_wave_hi) : kv_end_wave_hi;
+        if (kb >= seg_end_hi) continue;    // wave-uniform: nothing this wave's queries can see
+        const int lim = (cached ? min(cl, kv_end) : kv_end) - kb;               // this query: ib < lim visible
+        const bool full = (cached ? min(cl, kv_end_wave_lo) : kv_end_wave_lo) - kb >= PF_BLOCK && q_first + 31 < S;
+
+        v16f sacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < NST; st++) {
+            const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+        }
+        // per-key scales of this lane's 16 keys (in-block index 8*(r/4) + 4*g + r%4)
+        float ksc[16], vsc[16];
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const v4f kq = *reinterpret_cast<const v4f*>(sKs + 8 * r4 + 4 * g);
+            const v4f vq = *reinterpret_cast<const v4f*>(sVs + 8 * r4 + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ksc[4 * r4 + e] = kq[e]; vsc[4 * r4 + e] = vq[e]; }
+        }
+        const int limg = lim - 4 * g;
+        float sc[16], wgt[16];
+        float bm = -INFINITY, bsum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float sv = (sacc[r] * ksc[r]) * scale;
+            sc[r] = (full || 8 * (r >> 2) + (r & 3) < limg) ? sv : -INFINITY;
+            bm = fmaxf(bm, sc[r]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mn = fmaxf(m_run, bm);
+        if (mn > -INFINITY) {              // :395-414
+            const float corr = __expf(m_run - mn);
+            l_run *= corr;
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const v2f c2 = {corr, corr};
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const v2f t = v2f{o[dt][r], o[dt][r + 1]} * c2;
+                    o[dt][r] = t[0];
+                    o[dt][r + 1] = t[1];
+                }
+            m_run = mn;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            wgt[r] = (sc[r] == -INFINITY) ? 0.0f : __expf(sc[r] - mn);
+            bsum += wgt[r];
+        }
+        bsum += __shfl_xor(bsum, 32);
+        l_run += bsum;
+
+        v8hf phi[2], plo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float wv = wgt[8 * ks + e] * vsc[8 * ks + e];
+                const _Float16 hi = (_Float16)wv;
+                phi[ks][e] = hi;
+                plo[ks][e] = (_Float16)(wv - (float)hi);
+            }
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
+                const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                const v8hf vf = __builtin_bit_cast(v8hf, packed);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!q_live) return;
+    const size_t orow = ((size_t)b * S + qi) * Hq + h;
+    if (nsplit == 1) {
+        uint16_t* op = a.out + orow * D;
+        const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                uint32_t lo = 0, hi = 0;
+                if (l_run > 0.0f) {
+                    lo = (uint32_t)f2h_mul(o[dt][4 * r4], inv) | ((uint32_t)f2h_mul(o[dt][4 * r4 + 1], inv) << 16);
+                    hi = (uint32_t)f2h_mul(o[dt][4 * r4 + 2], inv) | ((uint32_t)f2h_mul(o[dt][4 * r4 + 3], inv) << 16);
+                }
+                *reinterpret_cast<uint2*>(op + dt * 32 + 8 * r4 + 4 * g) = make_uint2(lo, hi);
+            }
+    } else {      // (max, sum, unnormalised output) of this key range: attn_merge_kernel's record
+        float* rec = ws + (orow * nsplit + split) * (size_t)(D + 2);
+        if (g == 0) { rec[0] = m_run; rec[1] = l_run; }
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                float* dst = rec + 2 + dt * 32 + 8 * r4 + 4 * g;
+                *reinterpret_cast<float2*>(dst) = make_float2(o[dt][4 * r4], o[dt][4 * r4 + 1]);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(o[dt][4 * r4 + 2], o[dt][4 * r4 + 3]);
+            }
+    }
+}
+
 }  // namespace
+
+bool attn_prefill_hybrid_ok(const AttnArgs& a) {
+    return !a.f16_mode && a.S >= 32 && (a.D == 64 || a.D == 128) && a.qgs >= a.D && a.Hkv > 0 && a.Hq % a.Hkv == 0 &&
+           a.S < (size_t(1) << 30) && a.cache_len + a.new_len < (size_t(1) << 30) && a.cache_len + a.new_len >= 1 &&
+           a.Hq * a.B <= 1048576 &&
+           (a.cache_len == 0 || (a.k_cached && a.v_cached && a.k_scales && a.v_scales &&
+                                 ((reinterpret_cast<uintptr_t>(a.k_cached) | reinterpret_cast<uintptr_t>(a.v_cached)) & 15) == 0 &&
+                                 a.cache_batch_stride % 16 == 0)) &&
+           (a.new_len == 0 || (a.k_new && a.v_new &&
+                               ((reinterpret_cast<uintptr_t>(a.k_new) | reinterpret_cast<uintptr_t>(a.v_new)) & 15) == 0)) &&
+           ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+}
+
+// key splits: enough workgroups to fill the chip (about 1024), at least two blocks per split, at
+// most 256 (the merge kernel keeps one factor per split in LDS)
+int attn_prefill_hybrid_splits(const AttnArgs& a) {
+    const size_t tiles = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B;
+    const size_t blocks = (a.cache_len + PF_BLOCK - 1) / PF_BLOCK + (a.new_len + PF_BLOCK - 1) / PF_BLOCK;
+    size_t ns = tiles ? (1024 + tiles - 1) / tiles : 1;
+    const size_t cap = blocks / 2 ? blocks / 2 : 1;
+    if (ns > cap) ns = cap;
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+hipError_t launch_attention_prefill_hybrid(const AttnArgs& a, float* ws, hipStream_t st) {
+    if (!attn_prefill_hybrid_ok(a)) return hipErrorInvalidValue;
+    const int nsplit = attn_prefill_hybrid_splits(a);
+    if (nsplit > 1 && ws == nullptr) return hipErrorInvalidValue;
+    const size_t total = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B * (size_t)nsplit;
+    if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)total), block(256);
+    if (a.D == 128) attn_prefill_hybrid_kernel<128><<<grid, block, 0, st>>>(a, ws, nsplit);
+    else attn_prefill_hybrid_kernel<64><<<grid, block, 0, st>>>(a, ws, nsplit);
+    return hipGetLastError();
+}
 
 bool attn_prefill_ok(const AttnArgs& a) {
     return a.f16_mode && a.mask == nullptr && a.window_size == 0 && (a.D == 64 || a.D == 128) && a.S >= 32 &&

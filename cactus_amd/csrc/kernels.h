@@ -121,6 +121,12 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 // 128, no window, no mask tensor); launch_attention routes eligible calls there
 bool attn_prefill_ok(const AttnArgs& a);
 hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st);
+// the same for cactus_attention_hybrid_int8_fp16 with many queries (a prefill chunk against the INT8
+// cache): key ranges split over workgroups, records merged by attn_merge_kernel (ws as in
+// attn_workspace_bytes)
+bool attn_prefill_hybrid_ok(const AttnArgs& a);
+int attn_prefill_hybrid_splits(const AttnArgs& a);
+hipError_t launch_attention_prefill_hybrid(const AttnArgs& a, float* ws, hipStream_t st);
 
 // block_ops.hip: the ops between the hot kernels of a decoder block
 hipError_t launch_rms_norm(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t rows, size_t dims, float eps,

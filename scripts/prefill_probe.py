@@ -14,3 +14,16 @@ for S, Hq, Hkv, D in ((256, 16, 8, 128), (1024, 16, 8, 128), (4096, 16, 8, 128))
     ms = time_events(lambda i: H.attention_f16(q, k, v, 0.0), 5, warm=2)
     fl = 4.0 * S * S / 2 * Hq * D
     print(f"f16 causal prefill S={S}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.2f} TFLOP/s (causal half counted)")
+# a 256-token chunk against an INT8 cache (the engine's chunked prefill after chunk 0)
+for cache in (256, 2048, 3840):
+    S, Hq, Hkv, D = 256, 16, 8, 128
+    q = (torch.rand((1, S, Hq, D), device="cuda", generator=gen) * 2 - 1).half()
+    kn = (torch.rand((1, S, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+    vn = (torch.rand((1, S, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+    kc = torch.randint(-127, 128, (cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ks = torch.rand((cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+    vs = torch.rand((cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+    ms = time_events(lambda i: H.attention_hybrid(q, kc, vc, ks, vs, kn, vn, 0.0, position_offset=cache), 5, warm=2)
+    fl = 4.0 * S * (cache + S / 2) * Hq * D
+    print(f"hybrid chunk S=256 cache={cache}: {ms * 1e3:9.1f} us  {fl / ms / 1e9:7.2f} TFLOP/s")

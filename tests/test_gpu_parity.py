@@ -342,6 +342,14 @@ HYBRID = [
     (1, 4, 2, 1, 128, 50, 4, 10),         # offset < cache_len: causal cut inside the cache
     (1, 3, 4, 2, 20, 45, 3, None),        # head_dim not a multiple of 8: any-shape kernel
     (2, 2, 2, 1, 300, 37, 2, None),       # head_dim above 256, three scale groups
+    # many queries, head_dim 64 / 128: the matrix-core chunk kernel (key ranges split over workgroups)
+    (1, 256, 16, 8, 128, 512, 256, None),   # Qwen3 prefill chunk 2
+    (1, 256, 4, 2, 128, 1000, 256, None),   # cache not a multiple of 32
+    (1, 40, 4, 2, 64, 333, 40, None),
+    (2, 64, 6, 2, 128, 200, 64, None),      # two sequences (shared scales, as the reference indexes them)
+    (1, 130, 2, 1, 128, 0, 130, 0),         # empty cache: only the chunk's own keys
+    (1, 64, 2, 2, 64, 300, 64, 120),        # offset < cache_len: causal cut inside the cache
+    (1, 33, 4, 1, 128, 90, 33, 700),        # offset beyond the chunk: nothing masked
 ]
 
 
