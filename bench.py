@@ -419,6 +419,95 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
             "note": "a whole Qwen3-0.6B decode step: embedding lookup to greedy sampler, token ids stay on the device"}
 
 
+def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28):
+    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence, the way the engine walks a
+    long prompt (Model::prefill, engine_model.cpp:148-219: chunks of 256 tokens, the first against
+    nothing, the others against the INT8 cache): per layer norm + activation quantization, q/k/v GEMM,
+    q/k norm + RoPE + cache append, attention (FP16 for chunk 0, INT8-cache hybrid after), o GEMM,
+    add + norm, gate/up GEMM, SiLU x up, down GEMM, add; after the last chunk the final norm, the
+    lm_head on the last token and the greedy sampler.  One HIP graph per chunk, replayed in order."""
+    Hd, Hq, Hkv, D, F, V = 1024, 16, 8, 128, 3072, 151936
+    mk = lambda N, K: make_weights(K, N, False, gen)
+    Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), gate=mk(F, Hd),
+               up=mk(F, Hd), down=mk(Hd, F)) for _ in range(layers)]
+    head = mk(V, Hd)
+    nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
+    for L in Ls:
+        L.update(in_norm=nw(Hd), post_norm=nw(Hd), q_norm=nw(D), k_norm=nw(D))
+    final_norm = nw(Hd)
+    theta, eps = 1e6, 1e-6
+    H.rope_reserve(D, theta, tokens + 1)
+    half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
+    i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
+    M = chunk
+    nchunks = tokens // chunk
+    toks = torch.randint(0, V, (nchunks, M), dtype=torch.int32, device="cuda", generator=gen)
+    kc, vc = i8(layers, 1, tokens, Hkv, D), i8(layers, 1, tokens, Hkv, D)
+    ksc, vsc = f32(layers, 1, tokens, Hkv, 1), f32(layers, 1, tokens, Hkv, 1)
+    h0, hid, h2, x = half(M, Hd), half(M, Hd), half(M, Hd), half(M, Hd)
+    qo, ko, vo, qr, kr = half(M, Hq * D), half(M, Hkv * D), half(M, Hkv * D), half(M, Hq * D), half(M, Hkv * D)
+    ao, oo, go, uo, do = half(1, M, Hq, D), half(M, Hd), half(M, F), half(M, F), half(M, Hd)
+    logits, tok = half(1, V), torch.empty((1,), dtype=torch.int32, device="cuda")
+    xq, xs, xq2, xs2, aq, asc, oq, os_ = (i8(M, Hd), f32(M), i8(M, Hd), f32(M), i8(M, F), f32(M), i8(M, Hq * D),
+                                          f32(M))
+    shared = [(H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko), (L["v"][0], L["v"][1], vo)], 128),
+               H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128)) for L in Ls]
+    slots = [torch.full((1,), c * chunk, dtype=torch.int32, device="cuda") for c in range(nchunks)]
+
+    def run_chunk(c):
+        cache = c * chunk
+        H.embedding(head[0], toks[c], head[1], 128, out=h0, check=False)
+        H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
+        res = h0
+        for li, L in enumerate(Ls):
+            shared[li][0].run(xq, xs)
+            q4, k4, v4 = qo.view(1, M, Hq, D), ko.view(1, M, Hkv, D), vo.view(1, M, Hkv, D)
+            H.qk_norm_rope_kv_append(q4, k4, v4, L["q_norm"], L["k_norm"], eps, theta, cache, kc[li], vc[li], ksc[li],
+                                     vsc[li], slots[c], 128, out_q=qr.view(1, M, Hq, D), out_k=kr.view(1, M, Hkv, D))
+            if cache == 0:
+                a = H.attention_f16(qr.view(1, M, Hq, D), kr.view(1, M, Hkv, D), v4, 0.0, out=ao)
+            else:
+                a = H.attention_hybrid(qr.view(1, M, Hq, D), kc[li, 0, :cache], vc[li, 0, :cache], ksc[li, 0, :cache],
+                                       vsc[li, 0, :cache], kr.view(1, M, Hkv, D), v4, 0.0, position_offset=cache, out=ao)
+            H.quantize_activations(a.view(M, Hq * D), out_q=oq, out_scales=os_)
+            H.matmul_int8(oq, os_, L["o"][0], L["o"][1], 128, out=oo)
+            H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
+            shared[li][1].run(xq2, xs2)
+            H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
+            H.matmul_int8(aq, asc, L["down"][0], L["down"][1], 128, out=do)
+            nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
+            last = li + 1 == layers and c + 1 == nchunks
+            H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq, out_scales=xs)
+            res = hid
+        if c + 1 == nchunks:
+            H.matmul_f16act(x[M - 1:M], head[0], head[1], 128, out=logits)
+            H.sample_greedy(logits, out=tok)
+
+    graphs = []
+    for c in range(nchunks):
+        run_chunk(c)                      # sizes workspaces, builds RoPE rows
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run_chunk(c)
+        graphs.append(g)
+    for g in graphs:
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 2
+    e0.record()
+    for _ in range(reps):
+        for g in graphs:
+            g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    return {"ms": round(ms, 2), "tokens_per_s": round(tokens / (ms * 1e-3), 1), "tokens": tokens, "chunk": chunk,
+            "note": "chunked prefill of one sequence, Qwen3-0.6B op sequence, synthetic INT8 weights"}
+
+
 def extra_table(H, gen, big):
     """Secondary measurements: launches captured in a HIP graph and event timed, rotating weight
     buffers (> 256 MiB in total) so that weights come from HBM."""
@@ -538,6 +627,8 @@ def extra_table(H, gen, big):
                                      "entropy_us": round(ms_e * 1e3, 2)}
         del lg, smp
     ex["decode_tail"] = rows
+    ex["qwen3_0p6b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256)}
+    torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512)}
     return ex

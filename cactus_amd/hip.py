@@ -140,12 +140,12 @@ def init(device=0):
     _check(lib.cactus_hip_init(device))
 
 
-def quantize_activations(x):
+def quantize_activations(x, out_q=None, out_scales=None):
     """fp16 [M,K] -> (int8 [M,K], fp32 scales [M])."""
     _dev(x, torch.float16)
     M, K = x.shape
-    q = torch.empty((M, K), dtype=torch.int8, device=x.device)
-    s = torch.empty((M,), dtype=torch.float32, device=x.device)
+    q = out_q if out_q is not None else torch.empty((M, K), dtype=torch.int8, device=x.device)
+    s = out_scales if out_scales is not None else torch.empty((M,), dtype=torch.float32, device=x.device)
     _check(lib.cactus_hip_quantize_activations_dev(_p(x), _p(q), _p(s), M, K, _stream()))
     return q, s
 
@@ -577,13 +577,13 @@ def attention_f16(q, k, v, scale, mask=None, position_offset=0, window_size=0, i
 
 
 def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale, position_offset=0,
-                     is_causal=True, group_size=128, cache_len=None):
+                     is_causal=True, group_size=128, cache_len=None, out=None):
     _dev(q, torch.float16)
     B, S, Hq, D = q.shape
     new_len, Hkv = k_new.shape[1], k_new.shape[2]
     if cache_len is None:
         cache_len = k_cached.shape[-3]
-    out = torch.empty_like(q)
+    out = out if out is not None else torch.empty_like(q)
     _check(lib.cactus_hip_attention_hybrid_int8_fp16_dev(
         _p(q), _p(k_cached), _p(v_cached), _p(k_scales), _p(v_scales), _p(k_new), _p(v_new), _p(out),
         B, S, cache_len, new_len, Hq, Hkv, D, float(scale), position_offset, int(bool(is_causal)),
