@@ -542,13 +542,20 @@ bool attn_prefill_hybrid_ok(const AttnArgs& a) {
            ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
 }
 
-// key splits: enough workgroups to fill the chip (about 1024), at least two blocks per split, at
+// key splits: about 512 workgroups (1024 and 2048 measured slower: more records to write and merge;
+// 256 slower on the longest caches), at least two blocks per split, at
 // most 256 (the merge kernel keeps one factor per split in LDS)
 int attn_prefill_hybrid_splits(const AttnArgs& a) {
     const size_t tiles = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B;
     const size_t blocks = (a.cache_len + PF_BLOCK - 1) / PF_BLOCK + (a.new_len + PF_BLOCK - 1) / PF_BLOCK;
-    size_t ns = tiles ? (1024 + tiles - 1) / tiles : 1;
-    const size_t cap = blocks / 2 ? blocks / 2 : 1;
+#ifndef PF_SPLIT_TARGET
+#define PF_SPLIT_TARGET 512
+#endif
+#ifndef PF_SPLIT_MINBLK
+#define PF_SPLIT_MINBLK 2
+#endif
+    size_t ns = tiles ? (PF_SPLIT_TARGET + tiles - 1) / tiles : 1;
+    const size_t cap = blocks / PF_SPLIT_MINBLK ? blocks / PF_SPLIT_MINBLK : 1;
     if (ns > cap) ns = cap;
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
