@@ -257,7 +257,9 @@ struct GemmBatch {
     int N[G2_MAXB];
 };
 
-template <bool INT4>
+// NI: 16-row MFMA tiles per wave along m (4: 128-row workgroup tile, 2: 64-row tile for launches whose
+// 128-row tiles would leave most of the chip idle; INT8 only).
+template <bool INT4, int NI = 4>
 __global__ __launch_bounds__(512) void gemm2_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B_arg,
     const uint16_t* __restrict__ B_scales_arg, uint16_t* __restrict__ C_arg, int M, int K, int N_arg, int G, int nbm,
@@ -286,7 +288,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         bn -= pi ? bt.bn_end[pi - 1] : 0;
         B = bt.B[pi]; B_scales = bt.Bs[pi]; C = bt.C[pi]; N = bt.N[pi];
     }
-    const int m0 = bm * GM_BM, n0 = bn * GM_BN;
+    constexpr int BM = 32 * NI;          // rows of the workgroup tile
+    const int m0 = bm * BM, n0 = bn * GM_BN;
     const size_t brow_bytes = INT4 ? (size_t)K / 2 : (size_t)K;
 
     // Source of this thread's pieces (a piece = one wave instruction = 1 KB): a workgroup-uniform
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     for (int j = 0; j < 2; j++) {
         const int pi = w + 8 * j;
         const int row = pi * 8 + (lane >> 3), slot = lane & 7, ch = slot ^ ((row >> 1) & 7);
-        a_src[j] = (unsigned)min(row, M - 1 - m0) * (unsigned)K + ch * 16;
+        a_src[j] = (unsigned)min(min(row, BM - 1), M - 1 - m0) * (unsigned)K + ch * 16;   // piece j >= NI/2: unused
         a_dst[j] = pi * 1024;
         if constexpr (!INT4) {
             b_src[j] = (unsigned)min(row, N - 1 - n0) * (unsigned)brow_bytes + ch * 16;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         const int8_t* ak = scalar_ptr(a_base + (size_t)kt * 128);
         const uint8_t* bk = scalar_ptr(b_base + (size_t)kt * (INT4 ? 64 : 128));
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NI / 2; j++)
             __builtin_amdgcn_global_load_lds((gptr_t)(ak + a_src[j]), (lptr_t)(st + a_dst[j]), 16, 0, 0);
         if constexpr (INT4) {
             __builtin_amdgcn_global_load_lds((gptr_t)(bk + b_src[0]), (lptr_t)(st + b_dst[0]), 16, 0, 0);
@@ -331,19 +334,19 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     };
 
     typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f run[4][2][2];   // [..][e / 2] holds elements e, e + 1: folded with v_pk_fma_f32 (two exact fmas)
+    v2f run[NI][2][2];   // [..][e / 2] holds elements e, e + 1: folded with v_pk_fma_f32 (two exact fmas)
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int e = 0; e < 2; e++) run[i][j][e] = v2f{0.0f, 0.0f};
 
     // fragment read offsets inside a stage
-    int fa_off[4][2], fb_off[2][2];
+    int fa_off[NI][2], fb_off[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = wm * 64 + i * 16 + r;
+    for (int i = 0; i < NI; i++) {
+        const int row = wm * (16 * NI) + i * 16 + r;
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const int ch = INT4 ? 2 * q + s : 4 * s + q;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     //    half 1: end of LOAD(kt-1));
     //  - tile kt+3 reuses the stage of tile kt-1, whose last reader (half 1, LOAD(kt-1)) drained
     //    its reads before barrier 2kt, and is requested in MATH(kt), after barrier 2kt+1.
-    v4i fa[4][2], fb[2][2];
+    v4i fa[NI][2], fb[2][2];
     float sc[2];
     auto load_phase = [&](int kt) {
         const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < NI; i++) {
             const v4i c0 = *reinterpret_cast<const v4i*>(st + fa_off[i][0]);
             const v4i c1 = *reinterpret_cast<const v4i*>(st + fa_off[i][1]);
             if constexpr (INT4) {   // bytes 32q..32q+31 of the group: even bytes -> s = 0, odd -> s = 1
@@ -416,10 +419,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         }
     };
     auto math_phase = [&](int kt) {
-        v4i acc[4][2];
+        v4i acc[NI][2];
         __builtin_amdgcn_s_setprio(1);   // the wave feeding the MFMA pipe goes first on its SIMD
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[i][0], fb[j][0], v4i{0, 0, 0, 0}, 0, 0, 0);
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         __builtin_amdgcn_s_setprio(0);
         if (kt + 3 < G) issue_tile(kt + 3);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -443,12 +446,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
     auto wait_tile = [&](int j, int ahead = 2) {
         if (j >= G) return;
         const int later = min(ahead, G - 1 - j);
+        // requests per tile and wave: NI/2 for A, 2 (INT8) or 1 (INT4) for B
         if (later == 2) {
             if constexpr (INT4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else if (later == 1) {
             if constexpr (INT4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -492,19 +498,19 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         // per K step, between the slabs: before it every wave has waited for its own pieces of
         // tile kt+1 and has consumed every fragment of tile kt-1, so after it tile kt+1 is
         // readable and the stage of tile kt-1 can take the requests of tile kt+3.
-        v4i f0a[4], f0b[2], f1a[4], f1b[2];
-        auto read_slab = [&](int kt, int sl, v4i (&xa)[4], v4i (&xb)[2]) {
+        v4i f0a[NI], f0b[2], f1a[NI], f1b[2];
+        auto read_slab = [&](int kt, int sl, v4i (&xa)[NI], v4i (&xb)[2]) {
             const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
 #pragma unroll
             for (int j = 0; j < 2; j++) xb[j] = *reinterpret_cast<const v4i*>(st + fb_off[j][sl]);
 #pragma unroll
-            for (int i = 0; i < 4; i++) xa[i] = *reinterpret_cast<const v4i*>(st + fa_off[i][sl]);
+            for (int i = 0; i < NI; i++) xa[i] = *reinterpret_cast<const v4i*>(st + fa_off[i][sl]);
         };
         // plain v_fma_f32 on purpose: beside MFMAs a packed fp32 fma costs far more than the two
         // scalar ones it replaces (this file is built without SLP vectorization for the same reason)
-        auto rescale_half = [&](int half, v4i (&ap)[4][2], const float (&sp)[2]) {
+        auto rescale_half = [&](int half, v4i (&ap)[NI][2], const float (&sp)[2]) {
 #pragma unroll
-            for (int i = 2 * half; i < 2 * half + 2; i++)
+            for (int i = (NI / 2) * half; i < (NI / 2) * (half + 1); i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         auto shadow = [&]() {
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
 #pragma unroll
-            for (int x = 0; x < 7; x++) {
+            for (int x = 0; x < 2 * NI - 1; x++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         };
         // one K step: MFMAs into `ac`, rescale of `ap` (the previous group, raw fp16 scales `sp`);
         // `steady`: tiles kt+1..kt+3 exist, so the body is one branch-free block
-        auto step = [&](auto steady, int kt, v4i (&ac)[4][2], v4i (&ap)[4][2], const unsigned (&sp)[2], unsigned (&sn)[2]) {
+        auto step = [&](auto steady, int kt, v4i (&ac)[NI][2], v4i (&ap)[NI][2], const unsigned (&sp)[2], unsigned (&sn)[2]) {
             constexpr bool ST = decltype(steady)::value;
             fence();
             ac[0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f0a[0], f0b[0], v4i{0, 0, 0, 0}, 0, 0, 0);
@@ -538,14 +544,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
             fence();
             const float spf[2] = {h2f((uint16_t)sp[0]), h2f((uint16_t)sp[1])};
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < NI; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
                     if ((i | j) && !(G2_TIMING & 4)) ac[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f0a[i], f0b[j], v4i{0, 0, 0, 0}, 0, 0, 0);
             if (!(G2_TIMING & 2)) rescale_half(0, ap, spf);
             shadow();
             if constexpr (G2_TIMING & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr (ST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (ST && NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (ST) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else wait_tile(kt + 1, 1);
             if (!(G2_TIMING & 16)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -557,17 +564,17 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
             if (!(G2_TIMING & 8) && (ST || kt + 1 < G)) read_slab(kt + 1, 0, f0a, f0b);
             fence();
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < NI; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
                     if ((i | j) && !(G2_TIMING & 4)) ac[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f1a[i], f1b[j], ac[i][j], 0, 0, 0);
             if (!(G2_TIMING & 2)) rescale_half(1, ap, spf);
             shadow();
         };
-        v4i accx[4][2], accy[4][2];
+        v4i accx[NI][2], accy[NI][2];
         unsigned scx[2] = {0, 0}, scy[2] = {0, 0};   // raw fp16 scales, widened when used
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < 2; j++) accy[i][j] = v4i{0, 0, 0, 0};
         read_slab(0, 0, f0a, f0b);
@@ -632,10 +639,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         uint16_t* ct = reinterpret_cast<uint16_t*>(g2_lds);
         barrier();                      // every wave is done with the ring
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int lm = wm * 64 + i * 16 + q * 4 + e;
+                const int lm = wm * (16 * NI) + i * 16 + q * 4 + e;
                 const float as = A_scales[min(m0 + lm, M - 1)];
 #pragma unroll
                 for (int j = 0; j < 2; j++)
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
             }
         barrier();
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
+        for (int p = 0; p < NI; p++) {
             const int idx = p * 512 + t, lm = idx >> 4, c8 = (idx & 15) * 8;
             const int m = m0 + lm, n = n0 + c8;
             if (m < M && n < N)   // N % 8 == 0: a segment is inside or outside as a whole
@@ -651,10 +658,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int m = m0 + wm * 64 + i * 16 + q * 4 + e;
+                const int m = m0 + wm * (16 * NI) + i * 16 + q * 4 + e;
                 if (m >= M) continue;
                 const float as = A_scales[m];
 #pragma unroll
@@ -674,13 +681,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
 }
 
 // more than 64 KB of dynamic LDS has to be allowed once per device
-template <bool INT4>
+template <bool INT4, int NI>
 static hipError_t gemm2_allow_lds() {
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<INT4>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<INT4, NI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
@@ -688,18 +695,38 @@ static hipError_t gemm2_allow_lds() {
     return hipSuccess;
 }
 
+// 64-row tiles when 128-row tiles would not give every CU a workgroup (INT8 only: the packed-INT4 loop
+// is written for four m tiles per wave)
+static bool gemm2_small_tiles(bool int4, size_t M, size_t nbn) {
+#ifdef G2_NO_SMALL_TILES
+    return false;
+#endif
+    return !int4 && ((M + GM_BM - 1) / GM_BM) * nbn < 256 && M > 64;
+}
+
 template <bool INT4>
 static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const void* B, const uint16_t* B_scales,
                                uint16_t* C, size_t M, size_t K, size_t N, int G, hipStream_t st) {
     const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
-    hipError_t ea = gemm2_allow_lds<INT4>();
-    if (ea != hipSuccess) return ea;
-    const int nbm = (int)((M + GM_BM - 1) / GM_BM), nbn = (int)((N + GM_BN - 1) / GM_BN);
-    const int nwg = nbm * nbn;
+    const int nbn = (int)((N + GM_BN - 1) / GM_BN);
     GemmBatch none;
     none.count = 0;
-    gemm2_kernel<INT4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C,
-                                                                   (int)M, (int)K, (int)N, G, nbm, nwg, none);
+    if constexpr (!INT4) {
+        if (gemm2_small_tiles(false, M, (size_t)nbn)) {
+            hipError_t es = gemm2_allow_lds<false, 2>();
+            if (es != hipSuccess) return es;
+            const int nbm = (int)((M + 63) / 64), nwg = nbm * nbn;
+            gemm2_kernel<false, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales,
+                                                                              C, (int)M, (int)K, (int)N, G, nbm, nwg, none);
+            return hipGetLastError();
+        }
+    }
+    hipError_t ea = gemm2_allow_lds<INT4, 4>();
+    if (ea != hipSuccess) return ea;
+    const int nbm = (int)((M + GM_BM - 1) / GM_BM);
+    const int nwg = nbm * nbn;
+    gemm2_kernel<INT4, 4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales, C,
+                                                                      (int)M, (int)K, (int)N, G, nbm, nwg, none);
     return hipGetLastError();
 }
 
@@ -707,12 +734,15 @@ template <bool INT4>
 static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, const GemmProblem* pr, size_t count,
                                      size_t M, size_t K, int G, hipStream_t st) {
     const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
-    hipError_t e = gemm2_allow_lds<INT4>();
-    if (e != hipSuccess) return e;
     GemmBatch bt;
     memset(&bt, 0, sizeof bt);
     bt.count = (int)count;
-    const int nbm = (int)((M + GM_BM - 1) / GM_BM);
+    size_t nbn_all = 0;
+    for (size_t i = 0; i < count; i++) nbn_all += (pr[i].N + GM_BN - 1) / GM_BN;
+    const bool small = gemm2_small_tiles(INT4, M, nbn_all);
+    hipError_t e = small ? gemm2_allow_lds<false, 2>() : gemm2_allow_lds<INT4, 4>();
+    if (e != hipSuccess) return e;
+    const int nbm = small ? (int)((M + 63) / 64) : (int)((M + GM_BM - 1) / GM_BM);
     size_t nbn = 0;
     for (size_t i = 0; i < count; i++) {
         nbn += (pr[i].N + GM_BN - 1) / GM_BN;
@@ -725,8 +755,15 @@ static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, con
     }
     const int nwg = nbm * (int)nbn;
     if (nwg == 0) return hipSuccess;
-    gemm2_kernel<INT4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr, (int)M,
-                                                                   (int)K, 0, G, nbm, nwg, bt);
+    if constexpr (!INT4) {
+        if (small) {
+            gemm2_kernel<false, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr,
+                                                                              (int)M, (int)K, 0, G, nbm, nwg, bt);
+            return hipGetLastError();
+        }
+    }
+    gemm2_kernel<INT4, 4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr, (int)M,
+                                                                      (int)K, 0, G, nbm, nwg, bt);
     return hipGetLastError();
 }
 
