@@ -258,7 +258,7 @@ struct GemmBatch {
 };
 
 // NI: 16-row MFMA tiles per wave along m (4: 128-row workgroup tile, 2: 64-row tile for launches whose
-// 128-row tiles would leave most of the chip idle; INT8 only).
+// 128-row tiles would leave most of the chip idle).
 template <bool INT4, int NI = 4>
 __global__ __launch_bounds__(512) void gemm2_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B_arg,
@@ -448,11 +448,13 @@ __global__ __launch_bounds__(512) void gemm2_kernel(
         const int later = min(ahead, G - 1 - j);
         // requests per tile and wave: NI/2 for A, 2 (INT8) or 1 (INT4) for B
         if (later == 2) {
-            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if constexpr (INT4 && NI == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if constexpr (INT4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else if (later == 1) {
-            if constexpr (INT4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if constexpr (INT4 && NI == 4) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr (INT4) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if constexpr (NI == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else {
@@ -695,13 +697,12 @@ static hipError_t gemm2_allow_lds() {
     return hipSuccess;
 }
 
-// 64-row tiles when 128-row tiles would not give every CU a workgroup (INT8 only: the packed-INT4 loop
-// is written for four m tiles per wave)
-static bool gemm2_small_tiles(bool int4, size_t M, size_t nbn) {
+// 64-row tiles when 128-row tiles would not give every CU a workgroup
+static bool gemm2_small_tiles(size_t M, size_t nbn) {
 #ifdef G2_NO_SMALL_TILES
     return false;
 #endif
-    return !int4 && ((M + GM_BM - 1) / GM_BM) * nbn < 256 && M > 64;
+    return ((M + GM_BM - 1) / GM_BM) * nbn < 256 && M > 64;
 }
 
 template <bool INT4>
@@ -711,15 +712,13 @@ static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const voi
     const int nbn = (int)((N + GM_BN - 1) / GM_BN);
     GemmBatch none;
     none.count = 0;
-    if constexpr (!INT4) {
-        if (gemm2_small_tiles(false, M, (size_t)nbn)) {
-            hipError_t es = gemm2_allow_lds<false, 2>();
-            if (es != hipSuccess) return es;
-            const int nbm = (int)((M + 63) / 64), nwg = nbm * nbn;
-            gemm2_kernel<false, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales,
-                                                                              C, (int)M, (int)K, (int)N, G, nbm, nwg, none);
-            return hipGetLastError();
-        }
+    if (gemm2_small_tiles(M, (size_t)nbn)) {
+        hipError_t es = gemm2_allow_lds<INT4, 2>();
+        if (es != hipSuccess) return es;
+        const int nbm = (int)((M + 63) / 64), nwg = nbm * nbn;
+        gemm2_kernel<INT4, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales,
+                                                                          C, (int)M, (int)K, (int)N, G, nbm, nwg, none);
+        return hipGetLastError();
     }
     hipError_t ea = gemm2_allow_lds<INT4, 4>();
     if (ea != hipSuccess) return ea;
@@ -739,8 +738,8 @@ static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, con
     bt.count = (int)count;
     size_t nbn_all = 0;
     for (size_t i = 0; i < count; i++) nbn_all += (pr[i].N + GM_BN - 1) / GM_BN;
-    const bool small = gemm2_small_tiles(INT4, M, nbn_all);
-    hipError_t e = small ? gemm2_allow_lds<false, 2>() : gemm2_allow_lds<INT4, 4>();
+    const bool small = gemm2_small_tiles(M, nbn_all);
+    hipError_t e = small ? gemm2_allow_lds<INT4, 2>() : gemm2_allow_lds<INT4, 4>();
     if (e != hipSuccess) return e;
     const int nbm = small ? (int)((M + 63) / 64) : (int)((M + GM_BM - 1) / GM_BM);
     size_t nbn = 0;
@@ -755,12 +754,10 @@ static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, con
     }
     const int nwg = nbm * (int)nbn;
     if (nwg == 0) return hipSuccess;
-    if constexpr (!INT4) {
-        if (small) {
-            gemm2_kernel<false, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr,
-                                                                              (int)M, (int)K, 0, G, nbm, nwg, bt);
-            return hipGetLastError();
-        }
+    if (small) {
+        gemm2_kernel<INT4, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr,
+                                                                          (int)M, (int)K, 0, G, nbm, nwg, bt);
+        return hipGetLastError();
     }
     gemm2_kernel<INT4, 4><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr, (int)M,
                                                                       (int)K, 0, G, nbm, nwg, bt);
