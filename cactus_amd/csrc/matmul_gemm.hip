@@ -702,7 +702,7 @@ static bool gemm2_small_tiles(size_t M, size_t nbn) {
 #ifdef G2_NO_SMALL_TILES
     return false;
 #endif
-    return ((M + GM_BM - 1) / GM_BM) * nbn < 256 && M > 64;
+    return ((M + GM_BM - 1) / GM_BM) * nbn < 256;
 }
 
 template <bool INT4>
