@@ -9,8 +9,9 @@
 //   1. scaled = half(logit * half(1/temperature))                     (:482-496; the bias written
 //      at :473-480 is overwritten by both branches and never has an effect)
 //   2. repetition penalty 1.1 for every occurrence of a token in the history (:502-513)
-//   3. top-k: values below the k-th largest become -inf (:515-535) -- the k-th largest of 16-bit
-//      values comes from two 256-bin histograms of an order-preserving key (exact, no sort)
+//   3. top-k: values below the k-th largest drop out (:515-535) -- the k-th largest of 16-bit
+//      values comes from two 256-bin histograms of an order-preserving key (exact, no sort; the
+//      first histogram is filled by the pass that applies the temperature)
 //   4. the survivors are gathered in index order (at most SAMPLE_CAP of them)
 //   5. top-p over the survivors in descending order (:537-588): fp32 exp / sum / cumulative sum in
 //      that order; entries from the first position > 0 whose cumulative mass exceeds top_p are cut.
@@ -55,11 +56,51 @@ __global__ __launch_bounds__(1024) void sample_kernel(
     uint32_t* H = history ? history + row * SAMPLE_HISTORY : nullptr;
     const int hc = H ? min((int)hist_counts[row], SAMPLE_HISTORY) : 0;
 
-    // 1. temperature
-    for (int i = t; i < vocab; i += 1024) F[i] = use_temp ? hmul(L[i], inv_temp) : L[i];
+    // The row is walked in chunks of 8 elements (one 16-byte access when the row allows it).
+    const bool vec = (vocab & 7) == 0 && ((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(F)) & 15) == 0;
+    const int nchunk = (vocab + 7) / 8;
+    auto load8 = [&](const uint16_t* src, int c, uint16_t (&v)[8]) {   // elements past the row read as -inf
+        if (vec) {
+            const v4i x = *reinterpret_cast<const v4i*>(src + (size_t)c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (uint16_t)(((uint32_t)x[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = (c * 8 + e < vocab) ? src[(size_t)c * 8 + e] : H_NEG_INF;
+        }
+    };
+    const bool use_topk = top_k > 0 && top_k < vocab;
+
+    // 1. temperature, and the histogram of the high key byte for the top-k selection
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    for (int c = t; c < nchunk; c += 1024) {
+        uint16_t v[8];
+        load8(L, c, v);
+        if (use_temp) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = hmul(v[e], inv_temp);
+        }
+        if (vec) {
+            v4i x;
+#pragma unroll
+            for (int e = 0; e < 4; e++) x[e] = (int)((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16));
+            *reinterpret_cast<v4i*>(F + (size_t)c * 8) = x;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (c * 8 + e < vocab) F[(size_t)c * 8 + e] = v[e];
+        }
+        if (use_topk) {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (c * 8 + e < vocab) atomicAdd(&hist[order_key(v[e]) >> 8], 1u);
+        }
+    }
     __syncthreads();
 
-    // 2. repetition penalty: the first occurrence of a token applies it once per occurrence
+    // 2. repetition penalty: the first occurrence of a token applies it once per occurrence (and
+    // moves the token between histogram bins)
     if (t < hc) {
         const uint32_t tok = H[t];
         bool first = true;
@@ -71,19 +112,21 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         }
         if (first && tok < (uint32_t)vocab) {
             const uint16_t pinv = f2h(1.0f / 1.1f), pen = f2h(1.1f);
-            uint16_t v = F[tok];
+            const uint16_t v0 = F[tok];
+            uint16_t v = v0;
             for (int c = 0; c < cnt; c++) v = (h2f(v) > 0.0f) ? hmul(v, pinv) : hmul(v, pen);
             F[tok] = v;
+            if (use_topk) {
+                atomicSub(&hist[order_key(v0) >> 8], 1u);
+                atomicAdd(&hist[order_key(v) >> 8], 1u);
+            }
         }
     }
     __syncthreads();
 
-    // 3. top-k threshold
-    if (top_k > 0 && top_k < vocab) {
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        for (int i = t; i < vocab; i += 1024) atomicAdd(&hist[order_key(F[i]) >> 8], 1u);
-        __syncthreads();
+    // 3. top-k threshold: the key of the k-th largest value (0: everything passes)
+    uint32_t kth = 0;
+    if (use_topk) {
         if (t == 0) {
             uint32_t cum = 0;
             int b = 255;
@@ -98,9 +141,14 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         const int hb = s_hb;
         if (t < 256) hist[t] = 0;
         __syncthreads();
-        for (int i = t; i < vocab; i += 1024) {
-            const uint32_t k = order_key(F[i]);
-            if ((int)(k >> 8) == hb) atomicAdd(&hist[k & 255], 1u);
+        for (int c = t; c < nchunk; c += 1024) {
+            uint16_t v[8];
+            load8(F, c, v);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t k = order_key(v[e]);
+                if (c * 8 + e < vocab && (int)(k >> 8) == hb) atomicAdd(&hist[k & 255], 1u);
+            }
         }
         __syncthreads();
         if (t == 0) {
@@ -113,22 +161,27 @@ __global__ __launch_bounds__(1024) void sample_kernel(
             s_kth = (hb << 8) | b;
         }
         __syncthreads();
-        const uint32_t kth = (uint32_t)s_kth;
-        for (int i = t; i < vocab; i += 1024)
-            if (order_key(F[i]) < kth) F[i] = H_NEG_INF;
-        __syncthreads();
+        kth = (uint32_t)s_kth;
     }
 
-    // 4. survivors in index order: wave w owns one contiguous range
-    const int per = (((vocab + 15) / 16) + 63) & ~63;
-    const int lo = w * per, hi = min(vocab, lo + per);
+    // 4. survivors (not below the k-th value, not -inf) in index order: wave w owns one contiguous
+    // range of chunks, a lane 8 consecutive elements of each 512-element step
+    auto alive_mask = [&](int c) -> uint32_t {
+        if (c >= nchunk) return 0u;
+        uint16_t v[8];
+        load8(F, c, v);
+        uint32_t m = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            m |= (uint32_t)(c * 8 + e < vocab && v[e] != H_NEG_INF && order_key(v[e]) >= kth) << e;
+        return m;
+    };
+    const int cper = (((nchunk + 15) / 16) + 63) & ~63;
+    const int clo = w * cper, chi = min(nchunk, clo + cper);
     {
         uint32_t c = 0;
-        for (int i0 = lo; i0 < hi; i0 += 64) {
-            const int i = i0 + lane;
-            const bool alive = i < hi && F[i] != H_NEG_INF;
-            c += (uint32_t)__popcll(__ballot(alive));
-        }
+        for (int c0 = clo; c0 < chi; c0 += 64) c += (uint32_t)__popc(alive_mask(c0 + lane < chi ? c0 + lane : nchunk));
+        c = (uint32_t)wave_sum((float)c);      // < 2^24: exact
         if (lane == 0) wcount[w] = c;
     }
     __syncthreads();
@@ -142,17 +195,31 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         return;
     }
     const int n = (int)n_all;
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int i = i0 + lane;
-        const uint16_t v = i < hi ? F[i] : H_NEG_INF;
-        const bool alive = i < hi && v != H_NEG_INF;
-        const unsigned long long m = __ballot(alive);
-        if (alive) {
-            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            sv_bits[pos] = v;
-            sv_idx[pos] = (uint32_t)i;
+    for (int c0 = clo; c0 < chi; c0 += 64) {
+        const int c = c0 + lane < chi ? c0 + lane : nchunk;
+        const uint32_t m = alive_mask(c);
+        const uint32_t cnt = (uint32_t)__popc(m);
+        // exclusive prefix of cnt over the lanes of the wave
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
         }
-        base += (uint32_t)__popcll(m);
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (m) {
+            uint16_t v[8];
+            load8(F, c, v);
+            uint32_t pos = base + incl - cnt;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (m & (1u << e)) {
+                    sv_bits[pos] = v[e];
+                    sv_idx[pos] = (uint32_t)(c * 8 + e);
+                    pos++;
+                }
+        }
+        base += total;
     }
     __syncthreads();
 
