@@ -256,7 +256,7 @@ def main():
               "frac_hbm": round(kbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": kbytes}
 
     extra = {}
-    if not args.no_extra and rank == 0:
+    if not args.no_extra and rank == 0 and world == 1:   # the secondary table is a single-GPU measurement
         extra = extra_table(H, gen, big)
     if rank == 0:
         extra = dict(extra, single_launch_8192=single)
