@@ -353,11 +353,39 @@ __global__ __launch_bounds__(256) void row_quant_kernel(const uint16_t* __restri
     const int t = threadIdx.x;
     const size_t row = blockIdx.x, off = row * (size_t)dims;
     float m = 0.0f;
+    // 8 elements per access when the row allows it
+    bool vec = (dims & 7) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) |
+                                    reinterpret_cast<uintptr_t>(sum_out) | reinterpret_cast<uintptr_t>(y_out)) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(q_out) & 7) == 0;
+    if (MODE == 0) vec = vec && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+    const int nch = dims / 8;
+    auto half_of = [](const v4i& x, int e) -> uint16_t { return (uint16_t)(((uint32_t)x[e >> 1] >> (16 * (e & 1))) & 0xFFFFu); };
+    auto pack8 = [](const uint16_t (&v)[8]) -> v4i {
+        v4i x;
+#pragma unroll
+        for (int e = 0; e < 4; e++) x[e] = (int)((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16));
+        return x;
+    };
     if (MODE == 0) {
-        for (int i = t; i < dims; i += 256) {
-            const uint16_t v = b ? h2bits(bits2h(a[off + i]) + bits2h(b[off + i])) : a[off + i];
-            xin[i] = v;
-            if (sum_out) sum_out[off + i] = v;
+        if (vec) {
+            for (int c = t; c < nch; c += 256) {
+                v4i xv = *reinterpret_cast<const v4i*>(a + off + c * 8);
+                if (b) {
+                    const v4i bv = *reinterpret_cast<const v4i*>(b + off + c * 8);
+                    uint16_t v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = h2bits(bits2h(half_of(xv, e)) + bits2h(half_of(bv, e)));
+                    xv = pack8(v);
+                }
+                *reinterpret_cast<v4i*>(xin + c * 8) = xv;
+                if (sum_out) *reinterpret_cast<v4i*>(sum_out + off + c * 8) = xv;
+            }
+        } else {
+            for (int i = t; i < dims; i += 256) {
+                const uint16_t v = b ? h2bits(bits2h(a[off + i]) + bits2h(b[off + i])) : a[off + i];
+                xin[i] = v;
+                if (sum_out) sum_out[off + i] = v;
+            }
         }
         __syncthreads();
         if (t < 16) {
@@ -368,10 +396,37 @@ __global__ __launch_bounds__(256) void row_quant_kernel(const uint16_t* __restri
         const float inv = s_inv;
         const h16 inv_h = (h16)inv;
         const int simd_end = dims & ~7;
-        for (int i = t; i < dims; i += 256) {
-            const uint16_t y = rms_out(xin[i], w[i], inv, inv_h, i < simd_end);
-            yb[i] = y;
-            m = fmaxf(m, fabsf(h2f(y)));
+        if (vec) {
+            for (int c = t; c < nch; c += 256) {
+                const v4i xv = *reinterpret_cast<const v4i*>(xin + c * 8);
+                const v4i wv = *reinterpret_cast<const v4i*>(w + c * 8);
+                uint16_t y[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    y[e] = rms_out(half_of(xv, e), half_of(wv, e), inv, inv_h, true);
+                    m = fmaxf(m, fabsf(h2f(y[e])));
+                }
+                *reinterpret_cast<v4i*>(yb + c * 8) = pack8(y);
+            }
+        } else {
+            for (int i = t; i < dims; i += 256) {
+                const uint16_t y = rms_out(xin[i], w[i], inv, inv_h, i < simd_end);
+                yb[i] = y;
+                m = fmaxf(m, fabsf(h2f(y)));
+            }
+        }
+    } else if (vec) {
+        for (int c = t; c < nch; c += 256) {
+            const v4i av = *reinterpret_cast<const v4i*>(a + off + c * 8);
+            const v4i bv = *reinterpret_cast<const v4i*>(b + off + c * 8);
+            uint16_t y[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint16_t act = unary_one<MODE == 1 ? OP_SILU : OP_GELU>(half_of(av, e), off + c * 8 + e < total_vend);
+                y[e] = h2bits(bits2h(act) * bits2h(half_of(bv, e)));
+                m = fmaxf(m, fabsf(h2f(y[e])));
+            }
+            *reinterpret_cast<v4i*>(yb + c * 8) = pack8(y);
         }
     } else {
         for (int i = t; i < dims; i += 256) {
@@ -390,12 +445,20 @@ __global__ __launch_bounds__(256) void row_quant_kernel(const uint16_t* __restri
     if (t == 0) scales_out[row] = scale;
     const float iq = 1.0f / scale;
     const int q8 = dims & ~7;
-    for (int i = t; i < dims; i += 256) {     // each thread re-reads the elements it produced
-        const uint16_t y = yb[i];
-        float q = h2f(y) * iq;
-        q = fmaxf(fminf(q, 127.0f), -128.0f);
-        q_out[off + i] = (int8_t)((i < q8) ? clamp_i8(rne_i32(q)) : (int)roundf(q));
-        if (y_out) y_out[off + i] = y;
+    if (vec) {      // each thread re-reads the chunks it produced
+        for (int c = t; c < nch; c += 256) {
+            const v4i yv = *reinterpret_cast<const v4i*>(yb + c * 8);
+            *reinterpret_cast<uint2*>(q_out + off + c * 8) = quant8_bits(yv, iq);
+            if (y_out) *reinterpret_cast<v4i*>(y_out + off + c * 8) = yv;
+        }
+    } else {
+        for (int i = t; i < dims; i += 256) {
+            const uint16_t y = yb[i];
+            float q = h2f(y) * iq;
+            q = fmaxf(fminf(q, 127.0f), -128.0f);
+            q_out[off + i] = (int8_t)((i < q8) ? clamp_i8(rne_i32(q)) : (int)roundf(q));
+            if (y_out) y_out[off + i] = y;
+        }
     }
 }
 
