@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ sin_t, size_t tokens,
                                                            int Hq, int Hkv, int D, int seq_len, float eps,
                                                            const KvAppendArgs ap) {
-    extern __shared__ uint16_t qk_lds[];   // [16][D]
+    extern __shared__ __attribute__((aligned(16))) uint16_t qk_lds[];   // [16][D]
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const size_t nq = tokens * Hq, nqk = nq + tokens * Hkv, total = nqk + (ap.v ? tokens * Hkv : 0);
     const size_t row = (size_t)blockIdx.x * 16 + grp;
@@ -248,17 +248,39 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
         soff = b * ap.scale_batch_stride + (slot * Hkv + h) * (size_t)((D + ap.gs - 1) / ap.gs);
     }
     uint16_t* orow = (is_q ? q_out : k_out) + hr * D;
+    // rows move 8 elements per access when head_dim and the pointers allow it: the row is copied to
+    // LDS first and the 16-lane chain reads it from there
+    const bool vecD = (D & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(ap.v) |
+                        reinterpret_cast<uintptr_t>(q_out) | reinterpret_cast<uintptr_t>(k_out)) & 15) == 0;
+    auto wave_sync = [] {   // the 16 lanes of a row sit in one wave: orders their LDS writes before the reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     if (is_v) {   // a v row goes straight to the quantizer
         const uint16_t* vr = ap.v + hr * D;
-        for (int i = l; i < D; i += 16) nrm[i] = vr[i];
+        if (vecD) {
+            for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(nrm + c * 8) = *reinterpret_cast<const v4i*>(vr + c * 8);
+        } else {
+            for (int i = l; i < D; i += 16) nrm[i] = vr[i];
+        }
     } else {
         const uint16_t* xr = (is_q ? q : k) + hr * D;
         const uint16_t* w = is_q ? qw : kw;
         const int base = (threadIdx.x & 63) & ~15;
-        const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, D, eps, l, base);
-        const h16 inv_h = (h16)inv;
         const int simd_end = D & ~7;
-        for (int i = l; i < D; i += 16) nrm[i] = rms_out(xr[i], w[i], inv, inv_h, i < simd_end);
+        if (vecD) {
+            for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(nrm + c * 8) = *reinterpret_cast<const v4i*>(xr + c * 8);
+            wave_sync();
+            const float inv = row_inv_rms([&](int i) -> uint16_t { return nrm[i]; }, D, eps, l, base);
+            const h16 inv_h = (h16)inv;
+            for (int i = l; i < D; i += 16) nrm[i] = rms_out(nrm[i], w[i], inv, inv_h, true);   // in place: own elements
+        } else {
+            const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, D, eps, l, base);
+            const h16 inv_h = (h16)inv;
+            for (int i = l; i < D; i += 16) nrm[i] = rms_out(xr[i], w[i], inv, inv_h, i < simd_end);
+        }
     }
     __syncthreads();   // the one barrier of the kernel, reached by every thread
     if (!live) return;
@@ -282,18 +304,17 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
             o1 = f2h(pa - pb);
             o2 = f2h(pd + pe);
         }
-        orow[i] = o1;
-        orow[half_dim + i] = o2;
-        if (place) { nrm[i] = o1; nrm[half_dim + i] = o2; }   // the lane's own two elements: the rotated row
+        if (!vecD) {
+            orow[i] = o1;
+            orow[half_dim + i] = o2;
+        }
+        if (place || vecD) { nrm[i] = o1; nrm[half_dim + i] = o2; }   // the lane's own two elements: the rotated row
     }
-    if (place) {
-        // the 16 lanes of the group sit in one wave; their LDS writes are ordered before the reads
-        // below by the wait on the LDS counter
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        quant_row_groups(nrm, D, ap.gs, ap.kc + doff, ap.ks + soff, l);
+    if (place || vecD) wave_sync();
+    if (vecD) {
+        for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(orow + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
     }
+    if (place) quant_row_groups(nrm, D, ap.gs, ap.kc + doff, ap.ks + soff, l);
 }
 
 // The call is treated as one contiguous piece: whole groups of 8 from the start take the vector
