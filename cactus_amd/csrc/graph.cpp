@@ -863,9 +863,16 @@ void KVCache::set_window_size(size_t window, size_t sink) {
     }
 }
 
+void KVCache::set_ring(bool on) {
+    if (current_seq_len != 0) throw std::runtime_error("KVCache: ring mode can only change while the cache is empty");
+    ring = on;
+    ring_head = 0;
+}
+
 void KVCache::reset() {
     current_seq_len = 0;
     total_seq_len = 0;
+    ring_head = 0;
 }
 
 const int8_t* KVCache::get_keys_int8(size_t layer) const {
@@ -929,6 +936,7 @@ void KVCache::update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_no
     total_seq_len += seq_len;
     bool any = false;
     void* scratch = nullptr;
+    size_t next_ring_head = ring_head;
     for (size_t l = 0; l < layers; l++) {
         if (!mode[l]) continue;
         any = true;
@@ -953,7 +961,28 @@ void KVCache::update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_no
                 quant(ksrc, sink_size + skip_tokens, c, true, sink_size, remaining_window);
                 quant(vsrc, sink_size + skip_tokens, c, false, sink_size, remaining_window);
                 c.size_tokens = window_size;
+                next_ring_head = 0;   // rewritten in temporal order
             }
+            continue;
+        }
+        if (sliding && ring) {
+            // Overwrite the oldest recent slots in place.  The write position is the end of the held
+            // tokens while the window is still filling, the ring head afterwards; it wraps from the
+            // end of the window back to the first slot after the sink.
+            ensure_capacity(c, window_size);
+            c.size_tokens = window_size;
+            const size_t recent = window_size - sink_size;
+            size_t pos = old_seq_len < window_size ? old_seq_len : sink_size + ring_head;
+            size_t done = 0;
+            while (done < seq_len) {
+                const size_t n = std::min(seq_len - done, window_size - pos);
+                quant(ksrc, done, c, true, pos, n);
+                quant(vsrc, done, c, false, pos, n);
+                done += n;
+                pos += n;
+                if (pos == window_size) pos = sink_size;
+            }
+            next_ring_head = (pos - sink_size) % recent;
             continue;
         }
         size_t dst_token;
@@ -992,7 +1021,10 @@ void KVCache::update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_no
         (void)hipStreamSynchronize(nullptr);
         (void)hipFree(scratch);
     }
-    if (any) current_seq_len = sliding ? window_size : new_total_len;
+    if (any) {
+        current_seq_len = sliding ? window_size : new_total_len;
+        ring_head = next_ring_head;
+    }
 }
 
 }  // namespace cactus_hip
@@ -1175,6 +1207,10 @@ void cactus_hip_kvcache_destroy(void* c) { delete K_(c); }
 int cactus_hip_kvcache_set_window(void* c, size_t window, size_t sink) {
     return guarded<int>(-1, [&] { K_(c)->set_window_size(window, sink); return 0; });
 }
+int cactus_hip_kvcache_set_ring(void* c, int on) {
+    return guarded<int>(-1, [&] { K_(c)->set_ring(on != 0); return 0; });
+}
+size_t cactus_hip_kvcache_ring_head(void* c) { return K_(c)->ring_head; }
 void cactus_hip_kvcache_reset(void* c) { K_(c)->reset(); }
 int cactus_hip_kvcache_update(void* c, void* g, const size_t* k_nodes, const size_t* v_nodes, size_t seq_len) {
     return guarded<int>(-1, [&] {

@@ -245,11 +245,19 @@ struct KVCache {
     size_t window_size = 0, sink_size = 4;
     size_t current_seq_len = 0;   // tokens held (<= window)
     size_t total_seq_len = 0;     // tokens seen (RoPE / position offset)
+    // Ring mode: once the window is full, appended tokens overwrite the oldest slots of the recent
+    // region [sink, window) in place instead of sliding that region down (the reference's memmove,
+    // engine_cache.cpp:276-303).  The slots then hold the same tokens as without the ring, rotated:
+    // slot sink + (ring_head + i) % (window - sink) is the i-th oldest recent token.  Every cached key
+    // is visible to every query of the hybrid attention, so the rotation only permutes its sums.
+    bool ring = false;
+    size_t ring_head = 0;
     std::vector<LayerCache> layer_caches;
 
     ~KVCache();
     void init(size_t layers, size_t max_seq, size_t kv_heads, size_t dim);
     void set_window_size(size_t window, size_t sink);
+    void set_ring(bool on);       // only while the cache is empty
     void reset();
     bool is_empty() const { return current_seq_len == 0; }
     size_t get_effective_seq_len() const { return current_seq_len; }

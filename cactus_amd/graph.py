@@ -46,6 +46,8 @@ GRAPH_SIGNATURES = {
     "cactus_hip_kvcache_create": (_vp, [_sz, _sz, _sz, _sz]),
     "cactus_hip_kvcache_destroy": (None, [_vp]),
     "cactus_hip_kvcache_set_window": (_i, [_vp, _sz, _sz]),
+    "cactus_hip_kvcache_set_ring": (_i, [_vp, _i]),
+    "cactus_hip_kvcache_ring_head": (_sz, [_vp]),
     "cactus_hip_kvcache_reset": (None, [_vp]),
     "cactus_hip_kvcache_update": (_i, [_vp, _vp, _szp, _szp, _sz]),
     "cactus_hip_kvcache_len": (_sz, [_vp]),
@@ -278,6 +280,12 @@ class KVCache:
 
     def set_window_size(self, window, sink=4):
         _ok(lib.cactus_hip_kvcache_set_window(self._c, window, sink))
+
+    def set_ring(self, on=True):
+        _ok(lib.cactus_hip_kvcache_set_ring(self._c, int(on)))
+
+    def ring_head(self):
+        return lib.cactus_hip_kvcache_ring_head(self._c)
 
     def reset(self):
         lib.cactus_hip_kvcache_reset(self._c)

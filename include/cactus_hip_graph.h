@@ -98,6 +98,13 @@ size_t cactus_hip_graph_node_count(void* graph);
 void*  cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim);
 void   cactus_hip_kvcache_destroy(void* cache);
 int    cactus_hip_kvcache_set_window(void* cache, size_t window, size_t sink);
+/* Ring mode (no counterpart in the reference, which memmoves the window once per layer and token,
+ * engine_cache.cpp:276-303): with on != 0, tokens appended to a full window overwrite the oldest
+ * slots of [sink, window) in place.  Slot sink + (ring_head + i) % (window - sink) then holds the
+ * i-th oldest recent token; attention over the cache sees the same keys in rotated order.  Only
+ * while the cache is empty. */
+int    cactus_hip_kvcache_set_ring(void* cache, int on);
+size_t cactus_hip_kvcache_ring_head(void* cache);
 void   cactus_hip_kvcache_reset(void* cache);
 /* k_nodes / v_nodes: one node id per layer holding the new FP16 K/V [seq_len, Hkv, D]. */
 int    cactus_hip_kvcache_update(void* cache, void* graph, const size_t* k_nodes, const size_t* v_nodes,

@@ -364,6 +364,63 @@ def test_sliding_window_matches_host_model(G):
     cache.close()
 
 
+def test_ring_window_matches_sliding_window(G):
+    """Ring mode holds the same tokens as the sliding cache, rotated by ring_head, with no move
+    per append (the reference memmoves the window per layer and token, engine_cache.cpp:276-303);
+    hybrid attention over the rotated cache agrees with attention over the ordered one."""
+    rng = np.random.default_rng(5)
+    Hq, Hkv, D, W, sink = 4, 2, 128, 40, 3
+    R = W - sink
+    slide = G.KVCache(1, 2048, Hkv, D)
+    ring = G.KVCache(1, 2048, Hkv, D)
+    slide.set_window_size(W, sink)
+    ring.set_window_size(W, sink)
+    ring.set_ring(True)
+    g = G.CactusGraph()
+    for step, n in enumerate([30, 1, 7, 5, 1, 1, 36, 1, 1, 37, 20, 1]):
+        k = rng.normal(0, 1, (n, Hkv, D)).astype(np.float16)
+        v = rng.normal(0, 1, (n, Hkv, D)).astype(np.float16)
+        _fill_cache(G, g, slide, [k], [v])
+        g.soft_reset()
+        _fill_cache(G, g, ring, [k], [v])
+        g.soft_reset()
+        L = slide.get_effective_seq_len()
+        assert ring.get_effective_seq_len() == L and ring.get_total_seq_len() == slide.get_total_seq_len()
+        h = ring.ring_head()
+        assert (h == 0) if L < W else (0 <= h < R)
+        order = np.arange(L)
+        if L == W:
+            order = np.concatenate([np.arange(sink), sink + (h + np.arange(R)) % R])
+        for a, b in zip(slide.download(0), ring.download(0)):
+            assert (a == b[order]).all(), f"step {step}"
+
+        qd = rng.normal(0, 1, (1, 1, Hq, D)).astype(np.float16)
+        knew = rng.normal(0, 1, (1, 1, Hkv, D)).astype(np.float16)
+        vnew = rng.normal(0, 1, (1, 1, Hkv, D)).astype(np.float16)
+        outs = []
+        for cache in (slide, ring):
+            qn = g.input(qd.shape, G.FP16)
+            kn = g.input(knew.shape, G.FP16)
+            vn = g.input(vnew.shape, G.FP16)
+            o = g.attention_int8_hybrid(qn, kn, vn, 0.0, cache.get_total_seq_len(), cache.get_keys_int8(0),
+                                        cache.get_values_int8(0), cache.get_key_scales(0),
+                                        cache.get_value_scales(0), L, Hkv, D)
+            g.set_input(qn, qd)
+            g.set_input(kn, knew)
+            g.set_input(vn, vnew)
+            g.execute()
+            outs.append(g.get_output(o).astype(np.float64))
+            g.soft_reset()
+        assert np.abs(outs[0] - outs[1]).max() <= 2e-3 + 4e-3 * np.abs(outs[0]).max(), f"step {step}"
+    ring.reset()
+    assert ring.ring_head() == 0 and ring.is_empty()
+    with pytest.raises(Exception):
+        slide.set_ring(True)        # not while tokens are held
+    g.close()
+    slide.close()
+    ring.close()
+
+
 def test_incremental_updates(G):
     """tests/test_kv_cache.cpp:132-178."""
     Hkv, D, W = 4, 32, 8
