@@ -9,7 +9,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libcactus_hip.so")
 
 SOURCES = ["quant_kernels.hip", "matmul_skinny.hip", "matmul_gemm.hip", "matmul_generic.hip",
-           "matmul_f16.hip", "attention.hip", "attention_prefill.hip", "block_ops.hip", "sampler.hip", "api.hip", "graph.cpp"]
+           "matmul_f16.hip", "attention.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "api.hip", "graph.cpp"]
 HEADERS = ["common.hip.h", "block_math.hip.h", "kernels.h", "graph.h", os.path.join("..", "..", "include", "cactus_hip.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), so the

@@ -682,6 +682,27 @@ int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_hal
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "gelu_multiply launch", e);
     return CACTUS_HIP_OK;
 }
+int cactus_hip_conv1d_causal_depthwise_f16_dev(const cactus_half_t* input, const cactus_half_t* weight,
+                                               cactus_half_t* output, size_t N, size_t L, size_t C, size_t K,
+                                               size_t dilation, void* stream) {
+    if (N == 0 || L == 0 || C == 0) return CACTUS_HIP_OK;
+    if (!input || !weight || !output) return fail(CACTUS_HIP_EINVAL, "conv1d_causal: null operand");
+    if (K == 0 || dilation == 0) return fail(CACTUS_HIP_EINVAL, "conv1d_causal: kernel size and dilation must be >= 1");
+    hipError_t e = launch_conv1d_causal_depthwise(input, weight, output, N, L, C, K, dilation, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "conv1d_causal launch", e);
+    return CACTUS_HIP_OK;
+}
+int cactus_hip_lfm2_conv_gate_f16_dev(const cactus_half_t* in_proj, const cactus_half_t* weight, cactus_half_t* state,
+                                      cactus_half_t* gated, size_t num_seqs, size_t L, size_t C, size_t K, size_t W,
+                                      void* stream) {
+    if (num_seqs == 0 || L == 0 || C == 0) return CACTUS_HIP_OK;
+    if (!in_proj || !weight || !gated || (W > 0 && !state)) return fail(CACTUS_HIP_EINVAL, "lfm2_conv_gate: null operand");
+    if (K == 0) return fail(CACTUS_HIP_EINVAL, "lfm2_conv_gate: kernel size must be >= 1");
+    if (num_seqs > 65535) return fail(CACTUS_HIP_EINVAL, "lfm2_conv_gate: more than 65535 sequences per call");
+    hipError_t e = launch_lfm2_conv_gate(in_proj, weight, state, gated, num_seqs, L, C, K, W, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "lfm2_conv_gate launch", e);
+    return CACTUS_HIP_OK;
+}
 int cactus_hip_add_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n, void* stream) {
     return binary_dev(0, "add: null operand or launch failure", a, b, out, n, stream);
 }

@@ -1,0 +1,214 @@
+// Causal depthwise convolution over [N, L, C] rows and the LFM2 short-convolution block built on it.
+//
+//   cactus_conv1d_causal_depthwise_f16   cactus/kernel/kernel_conv.cpp:15-110
+//   LFM2Model::build_conv1d              cactus/models/model_lfm2.cpp:123-207
+//   ConvCache                            cactus/engine/engine_cache.cpp:494-597
+//
+// Roofline: HBM.  Algorithmic bytes per element of the plain convolution 2 in + 2 out (the K taps
+// of a row are re-read from cache); per token and channel of the LFM2 block 6 in (B, C gate, X of
+// the in-projection) + 2 out, plus 4 * W bytes of state per sequence and channel and call.
+//
+// Evaluation order kept from the reference: taps k = 0 .. K-1 read x[t - k * dilation] against
+// w[c][K-1-k]; whole groups of 8 taps go through four fp32 lanes (lane j takes taps k = j mod 4,
+// fused multiply-add, in k order) that are summed (l0+l1)+(l2+l3); the remaining K % 8 taps are
+// fused into that sum one by one, taps before the start of the sequence skipped; one rounding to
+// binary16 at the end.  The reference computes two rows per pass; each row's arithmetic is
+// independent of the other's.
+#include "common.hip.h"
+#include "kernels.h"
+#include "block_math.hip.h"
+
+namespace cactus_hip {
+
+namespace {
+
+// `xat(k, &x)` gives tap k's input (returns false when it lies before the sequence),
+// `wrev(k)` the weight it meets.
+template <typename XAt, typename WRev>
+__device__ __forceinline__ uint16_t conv_taps(size_t K, XAt xat, WRev wrev) {
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+    size_t k = 0;
+    for (; k + 8 <= K; k += 8) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+            const size_t kb = k + 4 * h;
+            xat(kb + 0, x0); xat(kb + 1, x1); xat(kb + 2, x2); xat(kb + 3, x3);
+            l0 = fmaf(x0, wrev(kb + 0), l0);
+            l1 = fmaf(x1, wrev(kb + 1), l1);
+            l2 = fmaf(x2, wrev(kb + 2), l2);
+            l3 = fmaf(x3, wrev(kb + 3), l3);
+        }
+    }
+    float acc = (l0 + l1) + (l2 + l3);
+    for (; k < K; k++) {
+        float x;
+        if (xat(k, x)) acc = fmaf(wrev(k), x, acc);
+    }
+    return f2h(acc);
+}
+
+// One thread per output element, channel fastest.
+__global__ __launch_bounds__(256) void conv1d_causal_dw_kernel(const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ w,
+                                                               uint16_t* __restrict__ y, size_t total, size_t L,
+                                                               size_t C, size_t K, size_t dil) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const size_t c = idx % C, t = (idx / C) % L, n = idx / (C * L);
+    const uint16_t* xb = x + n * L * C + c;
+    const uint16_t* wc = w + c * K;
+    y[idx] = conv_taps(
+        K,
+        [&](size_t k, float& out) {
+            const size_t back = k * dil;
+            if (back > t) return false;
+            out = h2f(xb[(t - back) * C]);
+            return true;
+        },
+        [&](size_t k) { return h2f(wc[K - 1 - k]); });
+}
+
+// LFM2 short convolution, one launch from the in-projection's rows to the gated rows that enter the
+// out-projection:  Bx = B * X (fp16 product), y = causal depthwise convolution (dilation 1) over the
+// sequence's last W rows of Bx from earlier calls followed by this call's rows, gated = Cg * y (fp16
+// product).  in_proj is [nseq, L, 3, C] with B, Cg, X in that order (model_lfm2.cpp:136-146).
+// `state` [nseq, W, C] holds a sequence's last W rows of Bx in temporal order and starts as zeros.
+// The reference keeps them in a circular buffer with a row count and convolves over only the rows
+// it holds; a zero row adds nothing to the fp32 sums, so rows of zeros in place of rows not yet
+// held give the same bits.
+// mode 0: gated rows only; 1: gated rows, then the state update by the same thread (the launch has
+// one chunk of rows per sequence, so the thread that read a channel's state is the one writing it);
+// 2: state update only.
+template <int VEC>
+__global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __restrict__ in_proj,
+                                                             const uint16_t* __restrict__ w,
+                                                             uint16_t* __restrict__ state,
+                                                             uint16_t* __restrict__ gated, size_t L, size_t C,
+                                                             size_t K, size_t W, size_t rows_per_chunk, int mode) {
+    const size_t cv = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (cv * VEC >= C) return;
+    const size_t c0 = cv * VEC, n = blockIdx.z;
+    const uint16_t* ip = in_proj + n * L * 3 * C + c0;
+    uint16_t* st = state + n * W * C + c0;
+
+    // row i of (state rows ++ Bx rows) for the thread's channels
+    auto xrow = [&](size_t i, uint16_t (&out)[VEC]) {
+        if (i < W) {
+            if (VEC == 8) {
+                *reinterpret_cast<v4i*>(out) = *reinterpret_cast<const v4i*>(st + i * C);
+            } else {
+                out[0] = st[i * C];
+            }
+        } else {
+            const uint16_t* r = ip + (i - W) * 3 * C;
+            alignas(16) uint16_t b[VEC], xx[VEC];
+            if (VEC == 8) {
+                *reinterpret_cast<v4i*>(b) = *reinterpret_cast<const v4i*>(r);
+                *reinterpret_cast<v4i*>(xx) = *reinterpret_cast<const v4i*>(r + 2 * C);
+            } else {
+                b[0] = r[0];
+                xx[0] = r[2 * C];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; e++) out[e] = h2bits(bits2h(b[e]) * bits2h(xx[e]));
+        }
+    };
+
+    if (mode != 2) {
+        const size_t t_begin = (size_t)blockIdx.y * rows_per_chunk;
+        const size_t t_end = t_begin + rows_per_chunk < L ? t_begin + rows_per_chunk : L;
+        for (size_t t = t_begin; t < t_end; t++) {
+            const size_t pos = t + W;   // row of the concatenation this output belongs to
+            alignas(16) uint16_t cg[VEC], o[VEC];
+            if (VEC == 8) *reinterpret_cast<v4i*>(cg) = *reinterpret_cast<const v4i*>(ip + t * 3 * C + C);
+            else cg[0] = ip[t * 3 * C + C];
+            if (K < 8) {
+                // no whole group of 8 taps: the sum is the plain chain over the taps
+                float acc[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; e++) acc[e] = 0.f;
+                for (size_t k = 0; k < K && k <= pos; k++) {
+                    alignas(16) uint16_t xr[VEC];
+                    xrow(pos - k, xr);
+#pragma unroll
+                    for (int e = 0; e < VEC; e++)
+                        acc[e] = fmaf(h2f(w[(c0 + e) * K + K - 1 - k]), h2f(xr[e]), acc[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; e++) o[e] = h2bits(bits2h(cg[e]) * bits2h(f2h(acc[e])));
+            } else {
+#pragma unroll 1
+                for (int e = 0; e < VEC; e++) {
+                    const uint16_t* wc = w + (c0 + e) * K;
+                    const uint16_t yv = conv_taps(
+                        K,
+                        [&](size_t k, float& out) {
+                            if (k > pos) return false;
+                            const size_t i = pos - k;
+                            if (i < W) out = h2f(st[i * C + e]);
+                            else {
+                                const uint16_t* r = ip + (i - W) * 3 * C + e;
+                                out = h2f(h2bits(bits2h(r[0]) * bits2h(r[2 * C])));
+                            }
+                            return true;
+                        },
+                        [&](size_t k) { return h2f(wc[K - 1 - k]); });
+                    o[e] = h2bits(bits2h(cg[e]) * bits2h(yv));
+                }
+            }
+            uint16_t* g = gated + (n * L + t) * C + c0;
+            if (VEC == 8) *reinterpret_cast<v4i*>(g) = *reinterpret_cast<const v4i*>(o);
+            else g[0] = o[0];
+        }
+    }
+    if (mode != 0) {
+        // new state row j = row L + j of the concatenation; ascending j reads a state row before the
+        // iteration that overwrites it
+        for (size_t j = 0; j < W; j++) {
+            alignas(16) uint16_t r[VEC];
+            xrow(L + j, r);
+            if (VEC == 8) *reinterpret_cast<v4i*>(st + j * C) = *reinterpret_cast<const v4i*>(r);
+            else st[j * C] = r[0];
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_conv1d_causal_depthwise(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t N, size_t L,
+                                          size_t C, size_t K, size_t dilation, hipStream_t st) {
+    const size_t total = N * L * C;
+    if (total == 0) return hipSuccess;
+    const size_t blocks = (total + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    conv1d_causal_dw_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(x, w, y, total, L, C, K, dilation);
+    return hipGetLastError();
+}
+
+hipError_t launch_lfm2_conv_gate(const uint16_t* in_proj, const uint16_t* w, uint16_t* state, uint16_t* gated,
+                                 size_t nseq, size_t L, size_t C, size_t K, size_t W, hipStream_t st) {
+    if (nseq == 0 || L == 0 || C == 0) return hipSuccess;
+    if (nseq > 65535) return hipErrorInvalidValue;
+    const bool vec = (C % 8 == 0) && (((reinterpret_cast<uintptr_t>(in_proj) | reinterpret_cast<uintptr_t>(state) |
+                                        reinterpret_cast<uintptr_t>(gated)) & 15) == 0);
+    const size_t threads = vec ? C / 8 : C;
+    const unsigned gx = (unsigned)((threads + 255) / 256);
+    // rows per thread: one chunk while the launch still has a few thousand threads, else chunks of 16 rows
+    size_t rpc = L;
+    if (L > 16 && nseq * threads < 65536) rpc = 16;
+    const size_t chunks = (L + rpc - 1) / rpc;
+    if (chunks > 65535) return hipErrorInvalidValue;
+    auto go = [&](unsigned gy, int mode) {
+        const dim3 grid(gx, gy, (unsigned)nseq), block(256);
+        if (vec) lfm2_conv_gate_kernel<8><<<grid, block, 0, st>>>(in_proj, w, state, gated, L, C, K, W, rpc, mode);
+        else lfm2_conv_gate_kernel<1><<<grid, block, 0, st>>>(in_proj, w, state, gated, L, C, K, W, rpc, mode);
+        return hipGetLastError();
+    };
+    if (chunks == 1) return go(1, W > 0 ? 1 : 0);
+    hipError_t e = go((unsigned)chunks, 0);
+    if (e != hipSuccess || W == 0) return e;
+    return go(1, 2);
+}
+
+}  // namespace cactus_hip

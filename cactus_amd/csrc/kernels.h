@@ -172,4 +172,11 @@ hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, siz
 hipError_t launch_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out, size_t num_indices,
                                 size_t vocab, size_t hidden, int* bad, hipStream_t st);
 
+// conv_ops.hip: causal depthwise convolution [N, L, C] and the LFM2 short-convolution block
+// (B * X, convolution over the carried state rows and the new rows, C-gate product, state update)
+hipError_t launch_conv1d_causal_depthwise(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t N, size_t L,
+                                          size_t C, size_t K, size_t dilation, hipStream_t st);
+hipError_t launch_lfm2_conv_gate(const uint16_t* in_proj, const uint16_t* w, uint16_t* state, uint16_t* gated,
+                                 size_t nseq, size_t L, size_t C, size_t K, size_t W, hipStream_t st);
+
 }  // namespace cactus_hip

@@ -76,6 +76,8 @@ SIGNATURES = {
     "cactus_hip_add_rms_norm_f16_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _f, _vp]),
     "cactus_hip_qk_norm_rope_f16_dev": (_i, [_vp] * 6 + [_sz] * 5 + [_f, _sz, _f, _vp]),
     "cactus_hip_silu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_conv1d_causal_depthwise_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_lfm2_conv_gate_f16_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_add_rms_norm_quant_f16_dev": (_i, [_vp] * 7 + [_sz, _sz, _f, _vp]),
     "cactus_hip_silu_multiply_quant_f16_dev": (_i, [_vp] * 5 + [_sz, _sz, _vp]),
     "cactus_hip_gelu_multiply_quant_f16_dev": (_i, [_vp] * 5 + [_sz, _sz, _vp]),
@@ -404,6 +406,32 @@ def qk_norm_rope_kv_append(q, k, v, q_weight, k_weight, eps, theta, start_pos, k
         _p(v_scales), _p(slots), B, S, Hq, Hkv, D, float(eps), start_pos, float(theta), group_size, cbs, sbs, ms,
         _stream()))
     return oq, ok
+
+
+def conv1d_causal_depthwise(x, weight, dilation=1, out=None):
+    """x fp16 [N, L, C], weight fp16 [C, K] (or [C, 1, K]) -> fp16 [N, L, C]."""
+    _dev(x, torch.float16); _dev(weight, torch.float16)
+    N, L, Cc = x.shape
+    K = weight.shape[-1]
+    o = out if out is not None else torch.empty_like(x)
+    _check(lib.cactus_hip_conv1d_causal_depthwise_f16_dev(_p(x), _p(weight), _p(o), N, L, Cc, K, dilation, _stream()))
+    return o
+
+
+def lfm2_conv_gate(in_proj, weight, state, out=None):
+    """in_proj fp16 [num_seqs, L, 3 * C] (B, C-gate, X), weight fp16 [C, K], state fp16 [num_seqs, W, C]
+    (updated in place; None for no state) -> gated fp16 [num_seqs, L, C]."""
+    _dev(in_proj, torch.float16); _dev(weight, torch.float16)
+    nseq, L, C3 = in_proj.shape
+    Cc = C3 // 3
+    K = weight.shape[-1]
+    W = 0 if state is None else state.shape[1]
+    if state is not None:
+        _dev(state, torch.float16)
+    o = out if out is not None else torch.empty((nseq, L, Cc), dtype=torch.float16, device=in_proj.device)
+    _check(lib.cactus_hip_lfm2_conv_gate_f16_dev(_p(in_proj), _p(weight), _p(state), _p(o), nseq, L, Cc, K, W,
+                                                 _stream()))
+    return o
 
 
 def silu_multiply(gate, up, out=None):

@@ -281,6 +281,25 @@ int cactus_hip_silu_multiply_f16_dev(const cactus_half_t* gate, const cactus_hal
 int cactus_hip_gelu_multiply_f16_dev(const cactus_half_t* gate, const cactus_half_t* up,
                                      cactus_half_t* output, size_t num_elements, void* stream);
 
+/* cactus_conv1d_causal_depthwise_f16 (kernel.h:106-111; kernel_conv.cpp:15-110): input
+ * half[N, L, C], weight half[C, K], output[n, t, c] = sum_k weight[c, K-1-k] * input[n, t - k*dilation, c]
+ * over the taps that lie inside the sequence, fp32 sums in the reference's order, one rounding. */
+int cactus_hip_conv1d_causal_depthwise_f16_dev(const cactus_half_t* input, const cactus_half_t* weight,
+                                               cactus_half_t* output, size_t N, size_t L, size_t C,
+                                               size_t K, size_t dilation, void* stream);
+/* The LFM2 short-convolution block between its two projections (LFM2Model::build_conv1d,
+ * model_lfm2.cpp:136-204, with ConvCache, engine_cache.cpp:494-597), one launch:
+ * in_proj half[num_seqs, L, 3, C] holds B, C-gate, X of each row; Bx = B * X;
+ * y = causal depthwise convolution (dilation 1) over the sequence's last W rows of Bx from earlier
+ * calls followed by this call's L rows; gated[num_seqs, L, C] = C-gate * y.  state
+ * half[num_seqs, W, C] carries those last W rows in temporal order between calls (W = conv_L_cache - 1
+ * in the reference) and must start as zeros, which stands for "no rows held yet": results equal the
+ * reference's, whose circular buffer convolves over only the rows it holds.  The call leaves the new
+ * last W rows in state.  W == 0: no state (state may be NULL). */
+int cactus_hip_lfm2_conv_gate_f16_dev(const cactus_half_t* in_proj, const cactus_half_t* weight,
+                                      cactus_half_t* state, cactus_half_t* gated, size_t num_seqs, size_t L,
+                                      size_t C, size_t K, size_t W, void* stream);
+
 /* A row producer followed by the activation quantization of the matmul that consumes it
  * (quantize_activations_fp16_to_int8, graph_ops_nn.cpp:35-66), one launch, one workgroup per row:
  * results equal cactus_hip_add_rms_norm_f16_dev / cactus_hip_silu_multiply_f16_dev /

@@ -63,6 +63,8 @@ def _load():
     lib.oracle_sample_uniform.argtypes = [C.c_uint32]
     lib.oracle_logits_entropy_f16.restype = C.c_float
     lib.oracle_logits_entropy_f16.argtypes = [vp, sz]
+    lib.oracle_conv1d_causal_depthwise_f16.argtypes = [vp, vp, vp, sz, sz, sz, sz, sz]
+    lib.oracle_lfm2_conv_gate_f16.argtypes = [vp, vp, vp, vp, vp, vp, sz, sz, sz, sz]
     return lib
 
 
@@ -285,3 +287,33 @@ def sample_uniform(seed):
 def logits_entropy(logits):
     logits = _c(logits, np.uint16).reshape(-1)
     return float(lib.oracle_logits_entropy_f16(_p(logits), logits.size))
+
+
+def conv1d_causal_depthwise(x, weight, dilation=1):
+    x = _c(x, np.uint16); w = _c(weight, np.uint16)
+    N, L, Cc = x.shape
+    K = w.shape[-1]
+    out = np.zeros(x.shape, np.uint16)
+    lib.oracle_conv1d_causal_depthwise_f16(_p(x), _p(w), _p(out), N, L, Cc, K, dilation)
+    return out
+
+
+class Lfm2ConvState:
+    """One sequence's ConvCache layer: circular rows [W, C], head, count."""
+
+    def __init__(self, W, Cc):
+        self.rows = np.zeros((max(W, 1), Cc), np.uint16)
+        self.W = W
+        self.head = C.c_size_t(0)
+        self.count = C.c_size_t(0)
+
+
+def lfm2_conv_gate(in_proj, weight, state):
+    """in_proj [L, 3*C] of one sequence, weight [C, K]; state: Lfm2ConvState (updated)."""
+    ip = _c(in_proj, np.uint16); w = _c(weight, np.uint16)
+    L, C3 = ip.shape
+    Cc = C3 // 3
+    out = np.zeros((L, Cc), np.uint16)
+    lib.oracle_lfm2_conv_gate_f16(_p(ip), _p(w), _p(state.rows), C.byref(state.head), C.byref(state.count),
+                                  _p(out), L, Cc, w.shape[-1], state.W)
+    return out

@@ -967,3 +967,99 @@ float oracle_logits_entropy_f16(const uint16_t* logits, size_t vocab_size) {
     }
     return (float)(entropy / log((double)vocab_size));
 }
+
+/* ------------------------------------------------------------------------ */
+/* cactus_conv1d_causal_depthwise_f16: cactus/kernel/kernel_conv.cpp:15-110  */
+/*   wrev[k] = float(W[c][K-1-k]) (:28-30).  Whole groups of 8 taps: four    */
+/*   fp32 lanes, lane j takes taps k+j then k+4+j with vfmaq_f32, a tap      */
+/*   before the sequence enters as 0 (:39-94); lanes summed by vaddvq_f32 =  */
+/*   (l0+l1)+(l2+l3) (:96-97); the last K % 8 taps are `acc += w * x`        */
+/*   statements, skipped when before the sequence (:99-104); one rounding to */
+/*   fp16 (:106-107).  The two rows of a pass (t0, t1) are independent.      */
+/* ------------------------------------------------------------------------ */
+void oracle_conv1d_causal_depthwise_f16(const uint16_t* input, const uint16_t* weight, uint16_t* output,
+                                        size_t N, size_t L, size_t C, size_t K, size_t dilation) {
+    float* wrev = (float*)malloc((K ? K : 1) * sizeof(float));
+    for (size_t n = 0; n < N; n++) {
+        const uint16_t* Xb = input + n * L * C;
+        uint16_t* Yb = output + n * L * C;
+        for (size_t c = 0; c < C; c++) {
+            for (size_t k = 0; k < K; k++) wrev[k] = oracle_h2f(weight[c * K + (K - 1 - k)]);
+            for (size_t t = 0; t < L; t++) {
+                float lane[4] = {0.f, 0.f, 0.f, 0.f};
+                size_t k = 0;
+                for (; k + 8 <= K; k += 8) {
+                    for (size_t half = 0; half < 2; half++) {
+                        for (size_t j = 0; j < 4; j++) {
+                            const size_t kk = k + 4 * half + j, back = kk * dilation;
+                            const float x = back <= t ? oracle_h2f(Xb[(t - back) * C + c]) : 0.f;
+                            lane[j] = fmaf(x, wrev[kk], lane[j]);
+                        }
+                    }
+                }
+                float acc = (lane[0] + lane[1]) + (lane[2] + lane[3]);
+                for (; k < K; k++) {
+                    const size_t back = k * dilation;
+                    if (back <= t) acc = mad_stmt(wrev[k], oracle_h2f(Xb[(t - back) * C + c]), acc);
+                }
+                Yb[t * C + c] = oracle_f2h(acc);
+            }
+        }
+    }
+    free(wrev);
+}
+
+/* ------------------------------------------------------------------------ */
+/* LFM2Model::build_conv1d between its two matmuls                           */
+/* (cactus/models/model_lfm2.cpp:136-204) with ConvCache                     */
+/* (cactus/engine/engine_cache.cpp:494-597), one sequence:                   */
+/*   in_proj [L, 3, C] -> B, Cg, X (:136-145); Bx = B * X (:146);            */
+/*   the cache's rows, oldest first -- the segment from head to the end,     */
+/*   then the one from 0 to head once the buffer is full, rows 0..count-1    */
+/*   before that (get_window, engine_cache.cpp:511-549; :167-190) -- are     */
+/*   concatenated in front of Bx; causal depthwise conv with dilation 1      */
+/*   over the concatenation (:196-199); the last L rows (:200-203);          */
+/*   gated = Cg * y (:204).  Then ConvCache::update copies the last          */
+/*   min(L, W) rows of Bx into the circular buffer (:585-596).               */
+/*   state [W, C], *head, *count are the buffer (zeros, 0, 0 at the start).  */
+/* ------------------------------------------------------------------------ */
+void oracle_lfm2_conv_gate_f16(const uint16_t* in_proj, const uint16_t* weight, uint16_t* state,
+                               size_t* head, size_t* count, uint16_t* gated,
+                               size_t L, size_t C, size_t K, size_t W) {
+    size_t held = 0;
+    if (W > 0 && *count > 0) held = *count < W ? *count : W;
+    const size_t total = held + L;
+    uint16_t* cat = (uint16_t*)malloc((total ? total : 1) * C * sizeof(uint16_t));
+    uint16_t* y = (uint16_t*)malloc((total ? total : 1) * C * sizeof(uint16_t));
+    size_t row = 0;
+    if (held > 0) {
+        if (*count < W) {
+            memcpy(cat, state, held * C * sizeof(uint16_t));
+            row = held;
+        } else {
+            const size_t len2 = W - *head;
+            memcpy(cat, state + *head * C, len2 * C * sizeof(uint16_t));
+            memcpy(cat + len2 * C, state, *head * C * sizeof(uint16_t));
+            row = W;
+        }
+    }
+    uint16_t* bx = cat + row * C;
+    for (size_t t = 0; t < L; t++)
+        for (size_t c = 0; c < C; c++)
+            bx[t * C + c] = h_mul(in_proj[(t * 3 + 0) * C + c], in_proj[(t * 3 + 2) * C + c]);
+    oracle_conv1d_causal_depthwise_f16(cat, weight, y, 1, total, C, K, 1);
+    const size_t start = total > L ? total - L : 0;
+    for (size_t t = 0; t < L; t++)
+        for (size_t c = 0; c < C; c++)
+            gated[t * C + c] = h_mul(in_proj[(t * 3 + 1) * C + c], y[(start + t) * C + c]);
+    if (W > 0) {
+        const size_t copy_rows = L < W ? L : W, start_row = L > W ? L - W : 0;
+        for (size_t i = 0; i < copy_rows; i++) {
+            memcpy(state + *head * C, bx + (start_row + i) * C, C * sizeof(uint16_t));
+            *head = (*head + 1) % W;
+            if (*count < W) ++*count;
+        }
+    }
+    free(cat);
+    free(y);
+}

@@ -113,6 +113,14 @@ float oracle_logits_entropy_f16(const uint16_t* logits, size_t vocab_size);
 int  oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out,
                           size_t num_indices, size_t vocab_size, size_t hidden_dim);
 
+/* LFM2's short convolution (PARITY UNPINNED: the reference's tests hold nothing
+ * for the causal convolution or the conv cache; checked against float64 sums). */
+void oracle_conv1d_causal_depthwise_f16(const uint16_t* input, const uint16_t* weight, uint16_t* output,
+                                        size_t N, size_t L, size_t C, size_t K, size_t dilation);
+void oracle_lfm2_conv_gate_f16(const uint16_t* in_proj, const uint16_t* weight, uint16_t* state,
+                               size_t* head, size_t* count, uint16_t* gated,
+                               size_t L, size_t C, size_t K, size_t W);
+
 #ifdef __cplusplus
 }
 #endif
