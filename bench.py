@@ -582,6 +582,21 @@ def extra_table(H, gen, big):
         rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
     ex["block_ops_prefill"] = rows
     del xa, xb, o1, o2, q4, k4, oq, ok, ga, up, oa
+    # LFM2-1.2B short-convolution block (hidden 2048, 3 taps, 2 carried rows): bytes = the
+    # in-projection's B, C-gate, X rows in + gated rows out + the state read and written
+    rows = {}
+    Cc, Kc, Wc = 2048, 3, 2
+    wconv = half(Cc, Kc)
+    for name, nseq, Lc in (("decode_b1024", 1024, 1), ("decode_b128", 128, 1), ("prefill_1x4096", 1, 4096),
+                           ("prefill_16x256", 16, 256)):
+        ipj, stt = half(nseq, Lc, 3 * Cc), torch.zeros((nseq, Wc, Cc), dtype=torch.float16, device="cuda")
+        og = torch.empty((nseq, Lc, Cc), dtype=torch.float16, device="cuda")
+        ms = time_graph(lambda i: H.lfm2_conv_gate(ipj, wconv, stt, out=og), 8)
+        nbytes = nseq * Cc * (8 * Lc + 4 * Wc)
+        gb = nbytes / (ms * 1e-3) / 1e9
+        rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
+    ex["lfm2_conv_block"] = rows
+    del ipj, stt, og
     torch.cuda.empty_cache()
     # FP16 causal prefill attention (Qwen3 heads), one layer: the matrix-core kernel
     rows = {}

@@ -22,6 +22,14 @@ namespace cactus_hip {
 
 namespace {
 
+// half(acc) of an fp32 sum that ends in a fused multiply-add.  Without the empty asm hipcc folds the
+// last fma and the conversion into v_fma_mixlo_f16, which rounds the exact sum once and flips
+// fp32 -> fp16 ties.
+__device__ __forceinline__ uint16_t f2h_sum(float acc) {
+    asm volatile("" : "+v"(acc));
+    return f2h(acc);
+}
+
 // `xat(k, &x)` gives tap k's input (returns false when it lies before the sequence),
 // `wrev(k)` the weight it meets.
 template <typename XAt, typename WRev>
@@ -45,7 +53,7 @@ __device__ __forceinline__ uint16_t conv_taps(size_t K, XAt xat, WRev wrev) {
         float x;
         if (xat(k, x)) acc = fmaf(wrev(k), x, acc);
     }
-    return f2h(acc);
+    return f2h_sum(acc);
 }
 
 // One thread per output element, channel fastest.
@@ -77,10 +85,12 @@ __global__ __launch_bounds__(256) void conv1d_causal_dw_kernel(const uint16_t* _
 // The reference keeps them in a circular buffer with a row count and convolves over only the rows
 // it holds; a zero row adds nothing to the fp32 sums, so rows of zeros in place of rows not yet
 // held give the same bits.
-// mode 0: gated rows only; 1: gated rows, then the state update by the same thread (the launch has
-// one chunk of rows per sequence, so the thread that read a channel's state is the one writing it);
-// 2: state update only.
-template <int VEC>
+// mode 0: gated rows only; 1: gated rows, and the thread of the sequence's first row chunk then
+// writes the channel's new state (it is the only one that read the old rows: the launcher gives every
+// chunk at least K - 1 rows, so later chunks reach back only into this call's rows); 2: state only.
+// KT: the tap count when it is 2, 3 or 4 (weights and the last KT - 1 rows stay in registers, a row
+// of the in-projection is read once per chunk), 0 for any other K.
+template <int VEC, int KT>
 __global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __restrict__ in_proj,
                                                              const uint16_t* __restrict__ w,
                                                              uint16_t* __restrict__ state,
@@ -115,7 +125,52 @@ __global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __r
         }
     };
 
-    if (mode != 2) {
+    if (mode != 2 && KT > 0) {
+        const size_t t_begin = (size_t)blockIdx.y * rows_per_chunk;
+        const size_t t_end = t_begin + rows_per_chunk < L ? t_begin + rows_per_chunk : L;
+        float wr[KT > 0 ? KT : 1][VEC];
+#pragma unroll
+        for (int k = 0; k < KT; k++)
+#pragma unroll
+            for (int e = 0; e < VEC; e++) wr[k][e] = h2f(w[(c0 + e) * KT + KT - 1 - k]);
+        // hist[j]: row pos - (KT - 1) + j of the concatenation; rows before it count as zeros, which
+        // leave the sums as the skipped taps of the reference do
+        alignas(16) uint16_t hist[KT > 1 ? KT - 1 : 1][VEC];
+#pragma unroll
+        for (int j = 0; j < KT - 1; j++) {
+            const size_t need = (size_t)(KT - 1 - j);
+            if (t_begin + W >= need) xrow(t_begin + W - need, hist[j]);
+            else {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) hist[j][e] = 0;
+            }
+        }
+        for (size_t t = t_begin; t < t_end; t++) {
+            alignas(16) uint16_t cg[VEC], o[VEC], cur[VEC];
+            if (VEC == 8) *reinterpret_cast<v4i*>(cg) = *reinterpret_cast<const v4i*>(ip + t * 3 * C + C);
+            else cg[0] = ip[t * 3 * C + C];
+            xrow(t + W, cur);
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                float acc = fmaf(wr[0][e], h2f(cur[e]), 0.f);
+#pragma unroll
+                for (int k = 1; k < KT; k++) acc = fmaf(wr[k][e], h2f(hist[KT - 1 - k][e]), acc);
+                o[e] = h2bits(bits2h(cg[e]) * bits2h(f2h_sum(acc)));
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < KT - 1; j++)
+#pragma unroll
+                for (int e = 0; e < VEC; e++) hist[j][e] = hist[j + 1][e];
+            if (KT > 1) {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) hist[KT - 2][e] = cur[e];
+            }
+            uint16_t* g = gated + (n * L + t) * C + c0;
+            if (VEC == 8) *reinterpret_cast<v4i*>(g) = *reinterpret_cast<const v4i*>(o);
+            else g[0] = o[0];
+        }
+    }
+    if (mode != 2 && KT == 0) {
         const size_t t_begin = (size_t)blockIdx.y * rows_per_chunk;
         const size_t t_end = t_begin + rows_per_chunk < L ? t_begin + rows_per_chunk : L;
         for (size_t t = t_begin; t < t_end; t++) {
@@ -136,7 +191,7 @@ __global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __r
                         acc[e] = fmaf(h2f(w[(c0 + e) * K + K - 1 - k]), h2f(xr[e]), acc[e]);
                 }
 #pragma unroll
-                for (int e = 0; e < VEC; e++) o[e] = h2bits(bits2h(cg[e]) * bits2h(f2h(acc[e])));
+                for (int e = 0; e < VEC; e++) o[e] = h2bits(bits2h(cg[e]) * bits2h(f2h_sum(acc[e])));
             } else {
 #pragma unroll 1
                 for (int e = 0; e < VEC; e++) {
@@ -162,7 +217,7 @@ __global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __r
             else g[0] = o[0];
         }
     }
-    if (mode != 0) {
+    if (mode == 2 || (mode == 1 && blockIdx.y == 0)) {
         // new state row j = row L + j of the concatenation; ascending j reads a state row before the
         // iteration that overwrites it
         for (size_t j = 0; j < W; j++) {
@@ -194,18 +249,32 @@ hipError_t launch_lfm2_conv_gate(const uint16_t* in_proj, const uint16_t* w, uin
                                         reinterpret_cast<uintptr_t>(gated)) & 15) == 0);
     const size_t threads = vec ? C / 8 : C;
     const unsigned gx = (unsigned)((threads + 255) / 256);
-    // rows per thread: one chunk while the launch still has a few thousand threads, else chunks of 16 rows
+    // Rows per thread: enough chunks for a few waves per SIMD, at least 4 rows (and K - 1, see the
+    // kernel) so the rows re-read at the start of a chunk stay a small share.
     size_t rpc = L;
-    if (L > 16 && nseq * threads < 65536) rpc = 16;
+    while (rpc > 4 && nseq * threads * ((L + rpc - 1) / rpc) < 131072) rpc = (rpc + 1) / 2;
+    if (rpc + 1 < K) rpc = K - 1 < L ? K - 1 : L;
     const size_t chunks = (L + rpc - 1) / rpc;
     if (chunks > 65535) return hipErrorInvalidValue;
+    const bool one_launch = chunks == 1 || rpc + 1 >= K;
     auto go = [&](unsigned gy, int mode) {
         const dim3 grid(gx, gy, (unsigned)nseq), block(256);
-        if (vec) lfm2_conv_gate_kernel<8><<<grid, block, 0, st>>>(in_proj, w, state, gated, L, C, K, W, rpc, mode);
-        else lfm2_conv_gate_kernel<1><<<grid, block, 0, st>>>(in_proj, w, state, gated, L, C, K, W, rpc, mode);
+#define CACTUS_CONV_GO(V, T) lfm2_conv_gate_kernel<V, T><<<grid, block, 0, st>>>(in_proj, w, state, gated, L, C, K, W, rpc, mode)
+        if (vec) {
+            if (K == 2) CACTUS_CONV_GO(8, 2);
+            else if (K == 3) CACTUS_CONV_GO(8, 3);
+            else if (K == 4) CACTUS_CONV_GO(8, 4);
+            else CACTUS_CONV_GO(8, 0);
+        } else {
+            if (K == 2) CACTUS_CONV_GO(1, 2);
+            else if (K == 3) CACTUS_CONV_GO(1, 3);
+            else if (K == 4) CACTUS_CONV_GO(1, 4);
+            else CACTUS_CONV_GO(1, 0);
+        }
+#undef CACTUS_CONV_GO
         return hipGetLastError();
     };
-    if (chunks == 1) return go(1, W > 0 ? 1 : 0);
+    if (one_launch) return go((unsigned)chunks, W > 0 ? 1 : 0);
     hipError_t e = go((unsigned)chunks, 0);
     if (e != hipSuccess || W == 0) return e;
     return go(1, 2);

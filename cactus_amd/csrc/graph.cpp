@@ -189,6 +189,12 @@ size_t CactusGraph::rope(size_t input, float theta, size_t position_offset, Comp
     return add_node(OpType::ROPE, {input}, {}, p);
 }
 
+size_t CactusGraph::conv1d_causal(size_t input, size_t weight, size_t, size_t dilation) {   // graph_builder.cpp:318-321
+    OpParams p;
+    p.dilation = dilation;
+    return add_node(OpType::CONV1D_CAUSAL, {input, weight}, {}, p);
+}
+
 void CactusGraph::ensure_device(BufferDesc& b) {
     if (b.device_data == nullptr) {
         b.device_data = dev_alloc(b.byte_size);
@@ -605,6 +611,26 @@ void CactusGraph::compute_rms_norm_node(GraphNode& n) {
                                           in.shape[1], n.params.epsilon, nullptr));
 }
 
+// graph_ops_nn.cpp:459-530 (the FP16-weight branch)
+void CactusGraph::compute_conv1d_causal_node(GraphNode& n) {
+    if (n.params.backend == ComputeBackend::NPU)
+        throw std::runtime_error("NPU causal convolution operation not yet implemented");
+    const BufferDesc& x = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& w = node(n.input_ids[1]).output_buffer;
+    if (x.shape.size() != 3) throw std::runtime_error("Causal conv requires 3D input [batch, seq_len, in_channels]");
+    if (w.shape.size() != 3) throw std::runtime_error("Weight must be 3D");
+    if (n.params.dilation < 1) throw std::runtime_error("dilation must be >= 1");
+    if (w.shape[1] != 1 || w.shape[0] != x.shape[2])
+        throw std::runtime_error("Only depthwise causal convolution is supported currently");
+    if (w.precision != Precision::FP16 || x.precision != Precision::FP16)
+        throw std::runtime_error("Depthwise causal conv supports FP16 weights and inputs on the device");
+    abi_check(cactus_hip_conv1d_causal_depthwise_f16_dev(static_cast<const cactus_half_t*>(x.device_data),
+                                                         static_cast<const cactus_half_t*>(w.device_data),
+                                                         static_cast<cactus_half_t*>(n.output_buffer.device_data),
+                                                         x.shape[0], x.shape[1], x.shape[2], w.shape[2],
+                                                         n.params.dilation, nullptr));
+}
+
 // graph_ops_nn.cpp:253-277
 void CactusGraph::compute_rope_node(GraphNode& n) {
     if (n.params.backend == ComputeBackend::NPU) throw std::runtime_error("NPU RoPE operation not yet implemented");
@@ -737,6 +763,7 @@ void CactusGraph::execute() {
             case OpType::RMS_NORM: compute_rms_norm_node(n); break;
             case OpType::ROPE: compute_rope_node(n); break;
             case OpType::EMBEDDING: compute_embedding_node(n); break;
+            case OpType::CONV1D_CAUSAL: compute_conv1d_causal_node(n); break;
             case OpType::MATMUL: compute_matmul_node(n); break;
             case OpType::ATTENTION: compute_attention_node(n); break;
             case OpType::ATTENTION_INT8_HYBRID: compute_attention_int8_hybrid_node(n); break;
@@ -1101,6 +1128,9 @@ long cactus_hip_graph_reshape(void* g, size_t input, const size_t* shape, size_t
 }
 long cactus_hip_graph_embedding(void* g, size_t table, size_t indices) {
     return guarded<long>(-1, [&] { return (long)G_(g)->embedding(table, indices); });
+}
+long cactus_hip_graph_conv1d_causal(void* g, size_t input, size_t weight, size_t kernel_size, size_t dilation) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->conv1d_causal(input, weight, kernel_size, dilation); });
 }
 long cactus_hip_graph_rms_norm(void* g, size_t input, size_t weight, float epsilon) {
     return guarded<long>(-1, [&] { return (long)G_(g)->rms_norm(input, weight, epsilon); });

@@ -32,7 +32,8 @@ enum class ComputeBackend { CPU = 0, NPU = 1, HIP = 2 };           // HIP is the
 enum class OpType {
     INPUT, MATMUL, ATTENTION, ATTENTION_INT8_HYBRID, QUANTIZE_ACTIVATIONS,
     // the ops between the hot kernels of a decoder block
-    ADD, ADD_CLIPPED, SUBTRACT, MULTIPLY, DIVIDE, SILU, GELU, RMS_NORM, ROPE, RESHAPE, EMBEDDING
+    ADD, ADD_CLIPPED, SUBTRACT, MULTIPLY, DIVIDE, SILU, GELU, RMS_NORM, ROPE, RESHAPE, EMBEDDING,
+    CONV1D_CAUSAL   // LFM2's short convolution
 };
 
 size_t precision_size(Precision p);   // bytes per element (INT4 counted as 1, graph.h:128-136)
@@ -73,6 +74,7 @@ struct OpParams {
     size_t position_offset = 0;
     float epsilon = 1e-5f;   // RMS_NORM
     float theta = 0.0f;      // ROPE
+    size_t dilation = 1;     // CONV1D_CAUSAL
     size_t window_size = 0;
     bool is_causal = true;
     Precision output_precision = Precision::INT8;
@@ -132,6 +134,9 @@ public:
     size_t rms_norm(size_t input, size_t weight, float epsilon = 1e-5f);
     size_t rope(size_t input, float theta, size_t position_offset = 0,
                 ComputeBackend backend = ComputeBackend::HIP);
+    // graph.h:460; graph_builder.cpp:318-321.  input [N, L, C], weight [C, 1, K], FP16 both (the
+    // reference also takes INT8 weights, which it dequantizes on the host per call).
+    size_t conv1d_causal(size_t input, size_t weight, size_t kernel_size, size_t dilation = 1);
 
     // Host data: copied to HBM now (set_input) or once per distinct pointer and kept resident
     // (set_external_input: weights that outlive the graph's steps).
@@ -178,6 +183,7 @@ private:
     void compute_rms_norm_node(GraphNode& n);
     void compute_rope_node(GraphNode& n);
     void compute_embedding_node(GraphNode& n);
+    void compute_conv1d_causal_node(GraphNode& n);
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;

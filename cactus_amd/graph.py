@@ -29,6 +29,7 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_embedding": (_l, [_vp, _sz, _sz]),
     "cactus_hip_graph_rms_norm": (_l, [_vp, _sz, _sz, _f]),
     "cactus_hip_graph_rope": (_l, [_vp, _sz, _f, _sz]),
+    "cactus_hip_graph_conv1d_causal": (_l, [_vp, _sz, _sz, _sz, _sz]),
     "cactus_hip_graph_mmap_weights": (_l, [_vp, C.c_char_p]),
     "cactus_hip_graph_node_info": (_i, [_vp, _sz, _szp, _szp, C.POINTER(C.c_int), _szp, _szp, C.POINTER(C.c_int)]),
     "cactus_hip_cact_parse_header": (_i, [_vp, _sz, C.POINTER(C.c_uint64)]),
@@ -154,6 +155,9 @@ class CactusGraph:
 
     def rms_norm(self, x, weight, epsilon=1e-5):
         return self._same(_node(lib.cactus_hip_graph_rms_norm(self._g, x, weight, epsilon)), x)
+
+    def conv1d_causal(self, x, weight, kernel_size, dilation=1):
+        return self._same(_node(lib.cactus_hip_graph_conv1d_causal(self._g, x, weight, kernel_size, dilation)), x)
 
     def rope(self, x, theta, position_offset=0):
         return self._same(_node(lib.cactus_hip_graph_rope(self._g, x, theta, position_offset)), x)

@@ -52,6 +52,8 @@ long   cactus_hip_graph_reshape(void* graph, size_t input, const size_t* shape, 
 long   cactus_hip_graph_embedding(void* graph, size_t table, size_t indices);
 long   cactus_hip_graph_rms_norm(void* graph, size_t input, size_t weight, float epsilon);
 long   cactus_hip_graph_rope(void* graph, size_t input, float theta, size_t position_offset);
+/* CactusGraph::conv1d_causal (graph.h:460): input [N, L, C], weight [C, 1, K], FP16. */
+long   cactus_hip_graph_conv1d_causal(void* graph, size_t input, size_t weight, size_t kernel_size, size_t dilation);
 /* CactusGraph::mmap_weights (graph.h:435; graph_io.cpp:48-72): a CACT tensor file becomes a weight
  * node (payload and group scales copied to HBM once, INT4 kept packed); the same file name gives
  * the same node.  node_info reports what was loaded (shape4: room for 4 dims). */

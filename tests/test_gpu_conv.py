@@ -102,3 +102,35 @@ def test_lfm2_conv_gate_decode_batch_full_size(H):
         c.count.value = W
         assert np.array_equal(got[s], O.lfm2_conv_gate(ip[s], w, c))
         assert np.array_equal(bits(state[s]), np.concatenate([c.rows[c.head.value:], c.rows[:c.head.value]]))
+
+
+def test_graph_conv1d_causal_node(H):
+    """CactusGraph::conv1d_causal (graph_builder.cpp:318-321, graph_ops_nn.cpp:459-530) inside the
+    node sequence of LFM2Model::build_conv1d without a cache (model_lfm2.cpp:146-204): multiply,
+    conv1d_causal, multiply -- against the oracle and against the one-launch block op."""
+    import cactus_amd.graph as G
+    rng = np.random.default_rng(21)
+    L, C, K = 37, 48, 3
+    b, cg, x = halves(rng, (L, C)), halves(rng, (L, C)), halves(rng, (L, C))
+    w = halves(rng, (C, 1, K), 0.5)
+    g = G.CactusGraph()
+    nb, ncg, nx = (g.input((L, C), G.FP16) for _ in range(3))
+    nw = g.input((C, 1, K), G.FP16)
+    bx = g.multiply(nb, nx)
+    y = g.conv1d_causal(g.reshape(bx, (1, L, C)), nw, K, 1)
+    gated = g.multiply(ncg, g.reshape(y, (L, C)))
+    for node, arr in ((nb, b), (ncg, cg), (nx, x), (nw, w)):
+        g.set_input(node, arr)
+    g.execute()
+    got = g.get_output(gated).view(np.uint16)
+    ip = np.concatenate([b, cg, x], axis=1)
+    want = O.lfm2_conv_gate(ip, w.reshape(C, K), O.Lfm2ConvState(0, C))
+    assert np.array_equal(got, want)
+    fused = bits(H.lfm2_conv_gate(dev(ip[None]), dev(w.reshape(C, K)), None))[0]
+    assert np.array_equal(fused, want)
+    bad = g.input((L, C), G.FP16)
+    g.conv1d_causal(bad, nw, K, 1)
+    g.set_input(bad, b)
+    with pytest.raises(Exception, match="3D input"):
+        g.execute()
+    g.close()
