@@ -419,6 +419,101 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
             "note": "a whole Qwen3-0.6B decode step: embedding lookup to greedy sampler, token ids stay on the device"}
 
 
+def lfm2_decode_step(H, gen, batch, cache_len):
+    """One decode step of the LFM2-1.2B op sequence (model_lfm2.cpp:123-331) for `batch` independent
+    sequences on one GPU: 16 blocks, 10 with the short convolution (in-projection to 3 x hidden,
+    B*X / 3-tap causal conv over the carried rows / C-gate in one launch, out-projection) and 6 with
+    attention (q/k/v, per-head q/k norms, RoPE, INT8 cache append, attention over the cache, o), each
+    followed by residual add, norm, gate/up, SiLU x up, down, residual add; final norm, lm_head,
+    greedy sampler; embedding lookup of the previous token in front.  Dimensions are the public model
+    card's (hidden 2048, ffn 8192, 32 q / 8 kv heads of 64, vocab 65536, conv_L_cache 3, attention in
+    blocks 2, 5, 8, 10, 12, 14): the reference reads them from config.txt.  Synthetic INT8 weights, one
+    HIP graph per step."""
+    Hd, Hq, Hkv, D, F, V, layers, Kc, Wc = 2048, 32, 8, 64, 8192, 65536, 16, 3, 2
+    attn_at = (2, 5, 8, 10, 12, 14)
+    mk = lambda N, K: make_weights(K, N, False, gen)
+    nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
+    half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
+    Ls = []
+    for li in range(layers):
+        L = dict(gate=mk(F, Hd), up=mk(F, Hd), down=mk(Hd, F), in_norm=nw(Hd), post_norm=nw(Hd), attn=li in attn_at)
+        if L["attn"]:
+            L.update(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), q_norm=nw(D), k_norm=nw(D))
+        else:
+            L.update(in_proj=mk(3 * Hd, Hd), out_proj=mk(Hd, Hd),
+                     conv_w=((torch.rand((Hd, Kc), device="cuda", generator=gen) - 0.5)).half(),
+                     state=((torch.rand((batch, Wc, Hd), device="cuda", generator=gen) - 0.5)).half())
+        Ls.append(L)
+    head, final_norm = mk(V, Hd), nw(Hd)
+    theta, eps, pos = 1e6, 1e-5, cache_len
+    H.rope_reserve(D, theta, pos + 1)
+    na = len(attn_at)
+    kc = torch.randint(-127, 128, (na, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (na, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ksc = torch.rand((na, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
+    vsc = torch.rand((na, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
+    lens = torch.full((batch,), cache_len, dtype=torch.int32, device="cuda")
+    tok = torch.randint(0, V, (batch,), dtype=torch.int32, device="cuda", generator=gen)
+    h0, hid, x, h2 = half(batch, Hd), half(batch, Hd), half(batch, Hd), half(batch, Hd)
+    qo, ko, vo, qr, kr = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hkv * D), half(batch, Hq * D), half(batch, Hkv * D)
+    ipj, gated, oo, go, uo, do, logits = half(batch, 3 * Hd), half(batch, Hd), half(batch, Hd), half(batch, F), half(batch, F), half(batch, Hd), half(batch, V)
+    i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
+    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
+    xq, xs, xq2, xs2, aq, asc = i8(batch, Hd), f32(batch), i8(batch, Hd), f32(batch), i8(batch, F), f32(batch)
+    for L in Ls:
+        if L["attn"]:
+            L["qkv"] = H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko), (L["v"][0], L["v"][1], vo)], 128)
+        L["gu"] = H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128)
+
+    def step():
+        H.embedding(head[0], tok, head[1], 128, out=h0, check=False)
+        H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
+        res, ai = h0, 0
+        for li, L in enumerate(Ls):
+            if L["attn"]:
+                L["qkv"].run(xq, xs)
+                H.qk_norm_rope_kv_append(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D),
+                                         L["q_norm"], L["k_norm"], eps, theta, pos, kc[ai], vc[ai], ksc[ai], vsc[ai], lens,
+                                         128, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
+                a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[ai], vc[ai], ksc[ai], vsc[ai],
+                                               kr.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
+                H.matmul_f16act(a.view(batch, Hq * D), L["o"][0], L["o"][1], 128, out=oo)
+                ai += 1
+            else:
+                H.matmul_int8(xq, xs, L["in_proj"][0], L["in_proj"][1], 128, out=ipj)
+                H.lfm2_conv_gate(ipj.view(batch, 1, 3 * Hd), L["conv_w"], L["state"], out=gated.view(batch, 1, Hd))
+                H.matmul_f16act(gated, L["out_proj"][0], L["out_proj"][1], 128, out=oo)
+            H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
+            L["gu"].run(xq2, xs2)
+            H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
+            H.matmul_int8(aq, asc, L["down"][0], L["down"][1], 128, out=do)
+            last = li + 1 == layers
+            nxt = final_norm if last else Ls[li + 1]["in_norm"]
+            H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq, out_scales=xs)
+            res = hid
+        H.matmul_f16act(x, head[0], head[1], 128, out=logits)
+        H.sample_greedy(logits, out=tok)
+
+    step()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
+            "cache_len": cache_len,
+            "note": "a whole LFM2-1.2B-shape decode step (10 conv + 6 attention blocks): embedding lookup to greedy "
+                    "sampler, token ids stay on the device; dimensions from the public model card"}
+
+
 def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28):
     """A chunked prefill of one sequence through the Qwen3-0.6B op sequence, the way the engine walks a
     long prompt (Model::prefill, engine_model.cpp:148-219: chunks of 256 tokens, the first against
@@ -646,6 +741,11 @@ def extra_table(H, gen, big):
     torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512)}
+    torch.cuda.empty_cache()
+    # config 4 (1024 independent LFM2-1.2B sequences sharded over the GPUs of a node): what one GPU
+    # runs at 8 GPUs (128 sequences) and at 1 GPU (1024)
+    ex["lfm2_1p2b_decode_step"] = {"b128_c512": lfm2_decode_step(H, gen, 128, 512),
+                                      "b1024_c512": lfm2_decode_step(H, gen, 1024, 512)}
     return ex
 
 
