@@ -134,3 +134,55 @@ def test_graph_conv1d_causal_node(H):
     with pytest.raises(Exception, match="3D input"):
         g.execute()
     g.close()
+
+
+def test_lfm2_conv_decoder_block_bit_exact(H):
+    """A whole LFM2 convolution block (model_lfm2.cpp:123-207, 267-299): input norm, in-projection
+    (INT8 weights, row-quantized activations), short convolution with its carried rows,
+    out-projection, residual add, norm, gate / up, SiLU x up, down, residual add -- a 9-token
+    prefill followed by three single-token steps, on the device and in the oracle.  No attention in
+    this block, so every intermediate is compared bit for bit."""
+    from tests.helpers import rand_weights_int8
+    rng = np.random.default_rng(31)
+    Hd, F, K, W, eps = 256, 512, 3, 2, 1e-5
+    scale_down = lambda Bs: (Bs.astype(np.float32) * 0.2).astype(np.float16)
+    wt = {}
+    for name, (n, k) in {"in_proj": (3 * Hd, Hd), "out_proj": (Hd, Hd), "gate": (F, Hd), "up": (F, Hd),
+                         "down": (Hd, F)}.items():
+        B, Bs = rand_weights_int8(rng, n, k)
+        wt[name] = (B, scale_down(Bs))
+    in_norm = (1.0 + 0.1 * rng.standard_normal(Hd)).astype(np.float16)
+    post_norm = (1.0 + 0.1 * rng.standard_normal(Hd)).astype(np.float16)
+    conv_w = halves(rng, (Hd, K), 0.5)
+    dw = {k: (dev(v[0]), dev(v[1])) for k, v in wt.items()}
+    d_in_norm, d_post_norm, d_conv_w = dev(in_norm), dev(post_norm), dev(conv_w)
+    state = torch.zeros((1, W, Hd), dtype=torch.float16, device="cuda")
+    cache = O.Lfm2ConvState(W, Hd)
+
+    def omm(x_bits, w):
+        q, s = O.quantize_activations(x_bits)
+        return O.matmul_int8(q, s, w[0], w[1].view(np.uint16), 128)
+
+    for L in (9, 1, 1, 1):
+        hidden = halves(rng, (L, Hd))
+        # oracle
+        normed = O.rms_norm(hidden, in_norm, eps)
+        ipj = omm(normed, wt["in_proj"])
+        gated = O.lfm2_conv_gate(ipj, conv_w, cache)
+        proj = omm(gated, wt["out_proj"])
+        after = O.binary("add", hidden, proj)
+        normed2 = O.rms_norm(after, post_norm, eps)
+        act = O.binary("multiply", O.silu(omm(normed2, wt["gate"])), omm(normed2, wt["up"]))
+        want = O.binary("add", after, omm(act, wt["down"]))
+        # device
+        dh = dev(hidden)
+        g_ipj = H.matmul_f16act(H.rms_norm(dh, d_in_norm, eps), *dw["in_proj"], 128)
+        assert np.array_equal(bits(g_ipj), ipj), L
+        g_gated = H.lfm2_conv_gate(g_ipj.view(1, L, 3 * Hd), d_conv_w, state).view(L, Hd)
+        assert np.array_equal(bits(g_gated), gated), L
+        g_after = H.add(dh, H.matmul_f16act(g_gated, *dw["out_proj"], 128))
+        assert np.array_equal(bits(g_after), after), L
+        g_n2 = H.rms_norm(g_after, d_post_norm, eps)
+        g_act = H.silu_multiply(H.matmul_f16act(g_n2, *dw["gate"], 128), H.matmul_f16act(g_n2, *dw["up"], 128))
+        got = H.add(g_after, H.matmul_f16act(g_act, *dw["down"], 128))
+        assert np.array_equal(bits(got), want), L
