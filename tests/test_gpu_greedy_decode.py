@@ -1,0 +1,165 @@
+"""Greedy decoding of a Qwen3-style model (models/model_qwen.cpp:51-129, 143-172; Model::decode,
+engine_model.cpp:221-253) on the device against the CPU oracle: the same prompt, then token after
+token with the INT8 KV cache, and the two token streams must be identical.
+
+Dimensions are Qwen3-0.6B's (hidden 1024, 16 q / 8 kv heads of 128, ffn 3072, eps 1e-6, theta 1e6,
+tied INT8 embedding / lm_head; engine.h:44-59): two cut-down cases (4 layers, 8192 entries) and the
+whole shape (28 layers, vocabulary 151936).  The weights are synthetic (no model files exist offline).  Logits are held to an fp16 tolerance -- attention sums in another order on
+the device -- and the argmax must agree at every step."""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import rand_weights_int8
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+HID, HQ, HKV, D, FF = 1024, 16, 8, 128, 3072
+EPS, THETA = 1e-6, 1e6
+
+
+@pytest.fixture(scope="module")
+def G():
+    import cactus_amd.hip as hip
+    hip.init(0)
+    import cactus_amd.graph as graph
+    return graph
+
+
+def make_model(rng, LAYERS, VOCAB, gain):
+    # weight = int8 ~ U{-127..127} times a group scale of (0.01 + |U(-1,1)| * 0.05) * gain: standard
+    # deviation about 2.6 * gain
+    def mat(n, k, gain):
+        B, Bs = rand_weights_int8(rng, n, k)
+        return B, (Bs.astype(np.float32) * gain).astype(np.float16)
+    layers = []
+    for _ in range(LAYERS):
+        L = {name: mat(n, k, gain) for name, (n, k) in {"q": (HQ * D, HID), "k": (HKV * D, HID), "v": (HKV * D, HID),
+                                                         "o": (HID, HQ * D), "gate": (FF, HID), "up": (FF, HID),
+                                                         "down": (HID, FF)}.items()}
+        for name, n in {"in_norm": HID, "post_norm": HID, "q_norm": D, "k_norm": D}.items():
+            L[name] = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float16)
+        layers.append(L)
+    emb = mat(VOCAB, HID, 1.0)
+    return {"layers": layers, "emb": emb, "final_norm": (1.0 + 0.1 * rng.standard_normal(HID)).astype(np.float16)}
+
+
+def omm(x_bits, wt):
+    q, s = O.quantize_activations(x_bits)
+    return O.matmul_int8(q, s, wt[0], wt[1].view(np.uint16), 128)
+
+
+def oracle_forward(m, tokens, pos, caches):
+    """Logits (uint16 bits) of the last of `tokens`; caches: per layer [kq, ks, vq, vs] or None, extended."""
+    S = len(tokens)
+    h = O.embedding(m["emb"][0], np.asarray(tokens, np.int32), m["emb"][1].view(np.uint16), 128)
+    for li, L in enumerate(m["layers"]):
+        n1 = O.rms_norm(h, L["in_norm"], EPS)
+        q = O.rms_norm(omm(n1, L["q"]).reshape(S * HQ, D), L["q_norm"], EPS).reshape(1, S, HQ, D)
+        k = O.rms_norm(omm(n1, L["k"]).reshape(S * HKV, D), L["k_norm"], EPS).reshape(1, S, HKV, D)
+        v = omm(n1, L["v"]).reshape(1, S, HKV, D)
+        q, k = O.rope(q, THETA, pos), O.rope(k, THETA, pos)
+        scale = 1.0 / np.sqrt(D)
+        if caches[li] is None:
+            attn = O.attention_f16(q, k, v, scale, position_offset=pos)
+        else:
+            kq, ks, vq, vs = caches[li]
+            attn = O.attention_hybrid(q, kq[None], vq[None], ks[None], vs[None], k, v, scale, position_offset=pos)
+        nkq, nks = O.quantize_kv(k.reshape(S, HKV, D))
+        nvq, nvs = O.quantize_kv(v.reshape(S, HKV, D))
+        if caches[li] is None:
+            caches[li] = [nkq, nks, nvq, nvs]
+        else:
+            caches[li] = [np.concatenate([a, b]) for a, b in zip(caches[li], (nkq, nks, nvq, nvs))]
+        h = O.binary("add", h, omm(attn.reshape(S, HQ * D), L["o"]))
+        n2 = O.rms_norm(h, L["post_norm"], EPS)
+        act = O.binary("multiply", O.silu(omm(n2, L["gate"])), omm(n2, L["up"]))
+        h = O.binary("add", h, omm(act, L["down"]))
+    last = O.rms_norm(h[S - 1:S], m["final_norm"], EPS)
+    return omm(last, m["emb"])[0]
+
+
+def bind(G, g, m):
+    def weight(pair):
+        n = g.input(pair[0].shape, G.INT8)
+        g.set_external_input(n, pair[0])
+        g.set_grouped_scales(n, 128, pair[0].shape[1] // 128, pair[1])
+        return n
+
+    def vec(a):
+        n = g.input(a.shape, G.FP16)
+        g.set_external_input(n, a)
+        return n
+    wn = {"layers": [], "emb": weight(m["emb"]), "final_norm": vec(m["final_norm"])}
+    for L in m["layers"]:
+        wn["layers"].append({k: (weight(v) if isinstance(v, tuple) else vec(v)) for k, v in L.items()})
+    return wn
+
+
+def graph_forward(G, g, wn, tokens, pos, cache):
+    S = len(tokens)
+    idx = g.input((S,), G.FP32)
+    g.set_input(idx, np.asarray(tokens, np.float32))
+    h = g.embedding(wn["emb"], idx)
+    k_nodes, v_nodes = [], []
+    for li, L in enumerate(wn["layers"]):
+        n1 = g.rms_norm(h, L["in_norm"], EPS)
+        q, k, v = (g.matmul(n1, L[name], True) for name in ("q", "k", "v"))
+        q = g.reshape(g.rms_norm(g.reshape(q, (S * HQ, D)), L["q_norm"], EPS), (1, S, HQ, D))
+        k = g.reshape(g.rms_norm(g.reshape(k, (S * HKV, D)), L["k_norm"], EPS), (1, S, HKV, D))
+        v = g.reshape(v, (1, S, HKV, D))
+        q, k = g.rope(q, THETA, pos), g.rope(k, THETA, pos)
+        k_nodes.append(k)
+        v_nodes.append(v)
+        scale = 1.0 / np.sqrt(D)
+        if cache.is_empty():
+            attn = g.attention(q, k, v, scale, pos)
+        else:
+            attn = g.attention_int8_hybrid(q, k, v, scale, pos, cache.get_keys_int8(li), cache.get_values_int8(li),
+                                           cache.get_key_scales(li), cache.get_value_scales(li),
+                                           cache.get_effective_seq_len(), HKV, D)
+        h = g.add(h, g.matmul(g.reshape(attn, (S, HQ * D)), L["o"], True))
+        n2 = g.rms_norm(h, L["post_norm"], EPS)
+        act = g.multiply(g.silu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
+        h = g.add(h, g.matmul(act, L["down"], True))
+    logits = g.matmul(g.rms_norm(h, wn["final_norm"], EPS), wn["emb"], True)     # every row; the last one is used
+    g.execute()
+    out = g.get_output(logits).reshape(S, -1)[S - 1].copy()
+    cache.update_from_graph(g, k_nodes, v_nodes, S)
+    g.soft_reset()
+    return out
+
+
+@pytest.mark.parametrize("seed,prompt_len,steps,LAYERS,VOCAB,gain", [(3, 11, 14, 4, 8192, 0.05), (8, 1, 10, 4, 8192, 0.05),
+                                                                      (5, 9, 8, 28, 151936, 0.02)])
+def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain):
+    import cactus_amd.hip as H
+    rng = np.random.default_rng(seed)
+    m = make_model(rng, LAYERS, VOCAB, gain)
+    prompt = rng.integers(0, VOCAB, prompt_len).tolist()
+    g = G.CactusGraph()
+    wn = bind(G, g, m)
+    cache = G.KVCache(LAYERS, 2048, HKV, D)
+    ocaches = [None] * LAYERS
+
+    dev_tokens, ora_tokens = [], []
+    feed_d, feed_o, pos = prompt, prompt, 0
+    for step in range(steps):
+        lg_d = graph_forward(G, g, wn, feed_d, pos, cache)
+        lg_o = oracle_forward(m, feed_o, pos, ocaches).view(np.float16)
+        ref = lg_o.astype(np.float64)
+        err = np.abs(lg_d.astype(np.float64) - ref).max()
+        assert err <= 2e-2 + 2e-2 * np.abs(ref).max(), (step, err)
+        td = int(H.sample_greedy(torch.from_numpy(lg_d[None].copy()).cuda()).cpu()[0])
+        to = int(O.sample_greedy(lg_o[None])[0])
+        dev_tokens.append(td)
+        ora_tokens.append(to)
+        assert td == to, (step, dev_tokens, ora_tokens, np.sort(ref)[-2:])
+        pos += len(feed_d)
+        feed_d, feed_o = [td], [to]
+    assert dev_tokens == ora_tokens and cache.get_total_seq_len() == prompt_len + steps - 1
+    assert len(set(dev_tokens)) > 1          # not a degenerate stream
+    g.close()
+    cache.close()
