@@ -260,6 +260,10 @@ def main():
         extra = extra_table(H, gen, big)
     if rank == 0:
         extra = dict(extra, single_launch_8192=single)
+    if world > 1 and not args.no_extra:
+        sd = sharded_decode(H, gen, world)
+        if rank == 0:
+            extra = dict(extra, sharded_decode=sd)
 
     if rank == 0:
         cpu = None
@@ -287,6 +291,38 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def sharded_decode(H, gen, world):
+    """Independent sequences sharded over the ranks, no collective in the data path: every rank runs
+    whole decode steps on its own sequences (full weight replica, its own KV cache); the job's rate is
+    the sequences of all ranks over the slowest rank's step time.  Qwen3-0.6B: 256 sequences per GPU
+    (the single-GPU configuration repeated per rank); LFM2-1.2B shape: 1024 sequences divided over the
+    ranks.  Every rank reaches the one all-reduce whatever happened before it."""
+    import torch.distributed as dist
+    ms = [1e30, 1e30]
+    try:
+        ms[0] = qwen3_decode_step(H, gen, 256, 512)["ms_per_step"]
+        torch.cuda.empty_cache()
+    except Exception as e:     # reported as a missing row, never as a hang
+        print(f"sharded_decode: qwen3 step failed on a rank: {e}", file=sys.stderr)
+    per_rank = max(1024 // world, 1)
+    try:
+        ms[1] = lfm2_decode_step(H, gen, per_rank, 512)["ms_per_step"]
+        torch.cuda.empty_cache()
+    except Exception as e:
+        print(f"sharded_decode: lfm2 step failed on a rank: {e}", file=sys.stderr)
+    tt = torch.tensor(ms, dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    q_ms, l_ms = (float(v) for v in tt.tolist())
+    out = {"scaling_note": "max step time over ranks; qwen3 weak (256 sequences per GPU), lfm2 strong (1024 sequences in all)"}
+    if q_ms < 1e29:
+        out["qwen3_0p6b_b256_per_gpu_c512"] = {"ms_per_step": round(q_ms, 4), "sequences": 256 * world,
+                                                "tokens_per_s": round(256 * world / (q_ms * 1e-3), 1)}
+    if l_ms < 1e29:
+        out["lfm2_1p2b_1024_sequences_c512"] = {"ms_per_step": round(l_ms, 4), "sequences_per_gpu": per_rank,
+                                                 "tokens_per_s": round(per_rank * world / (l_ms * 1e-3), 1)}
+    return out
 
 
 def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
