@@ -703,6 +703,16 @@ int cactus_hip_lfm2_conv_gate_f16_dev(const cactus_half_t* in_proj, const cactus
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "lfm2_conv_gate launch", e);
     return CACTUS_HIP_OK;
 }
+int cactus_hip_scalar_op_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t num_elements,
+                                 float scalar_value, int op_type, void* stream) {
+    if (op_type < 0 || op_type > 3)
+        return fail(CACTUS_HIP_EINVAL, "scalar_op: only ADD, SUBTRACT, MULTIPLY, DIVIDE (0..3) run on the device");
+    if (num_elements == 0) return CACTUS_HIP_OK;
+    if (!input || !output) return fail(CACTUS_HIP_EINVAL, "scalar_op: null operand");
+    hipError_t e = launch_scalar_op(op_type, input, scalar_value, output, num_elements, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "scalar_op launch", e);
+    return CACTUS_HIP_OK;
+}
 int cactus_hip_add_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* out, size_t n, void* stream) {
     return binary_dev(0, "add: null operand or launch failure", a, b, out, n, stream);
 }

@@ -520,6 +520,29 @@ __global__ __launch_bounds__(256) void binary_kernel(const uint16_t* __restrict_
     }
 }
 
+// cactus_scalar_op_f16 (kernel_scalar.cpp:7-154): the scalar is rounded to binary16 once, then one
+// fp16 operation per element, vector body and tail alike.
+template <int OP>
+__global__ __launch_bounds__(256) void scalar_kernel(const uint16_t* __restrict__ a, uint16_t scalar_bits,
+                                                     uint16_t* __restrict__ out, size_t n) {
+    const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (c * 8 >= n) return;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (c * 8 + 8 <= n && vec_ok) {
+        const v4i av = *reinterpret_cast<const v4i*>(a + c * 8);
+        v4i o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t lo = binary_one<OP>((uint16_t)((uint32_t)av[e] & 0xFFFFu), scalar_bits);
+            const uint32_t hi = binary_one<OP>((uint16_t)((uint32_t)av[e] >> 16), scalar_bits);
+            o[e] = (int)(lo | (hi << 16));
+        }
+        *reinterpret_cast<v4i*>(out + c * 8) = o;
+    } else {
+        for (size_t i = c * 8; i < c * 8 + 8 && i < n; i++) out[i] = binary_one<OP>(a[i], scalar_bits);
+    }
+}
+
 // Embedding rows.  INT8 with per-group fp16 scales: half(float(q) * float(scale)); FP16: copy.
 // An index outside [0, vocab) writes nothing and raises *bad (checked by the caller).
 __global__ __launch_bounds__(256) void embedding_int8_kernel(const int8_t* __restrict__ emb,
@@ -765,6 +788,19 @@ hipError_t launch_row_quant(int mode, const uint16_t* a, const uint16_t* b, cons
     else if (mode == 1) row_quant_kernel<1><<<grid, block, lds, st>>>(a, b, w, sum_out, y_out, q_out, scales_out, (int)dims, eps, vend);
     else if (mode == 2) row_quant_kernel<2><<<grid, block, lds, st>>>(a, b, w, sum_out, y_out, q_out, scales_out, (int)dims, eps, vend);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_scalar_op(int op, const uint16_t* a, float scalar, uint16_t* out, size_t n, hipStream_t st) {
+    const dim3 grid((unsigned)(((n + 7) / 8 + 255) / 256)), block(256);
+    const uint16_t sb = __builtin_bit_cast(uint16_t, (_Float16)scalar);   // static_cast<__fp16>(scalar_value)
+    switch (op) {
+        case BIN_ADD: scalar_kernel<BIN_ADD><<<grid, block, 0, st>>>(a, sb, out, n); break;
+        case BIN_SUB: scalar_kernel<BIN_SUB><<<grid, block, 0, st>>>(a, sb, out, n); break;
+        case BIN_MUL: scalar_kernel<BIN_MUL><<<grid, block, 0, st>>>(a, sb, out, n); break;
+        case BIN_DIV: scalar_kernel<BIN_DIV><<<grid, block, 0, st>>>(a, sb, out, n); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

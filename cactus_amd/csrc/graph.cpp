@@ -189,6 +189,17 @@ size_t CactusGraph::rope(size_t input, float theta, size_t position_offset, Comp
     return add_node(OpType::ROPE, {input}, {}, p);
 }
 
+size_t CactusGraph::scalar_node(OpType op, size_t input, float value) {   // graph_builder.cpp:424-450
+    OpParams p;
+    p.scalar = value;
+    p.output_precision = get_output_buffer(input).precision;
+    return add_node(op, {input}, {}, p);
+}
+size_t CactusGraph::scalar_add(size_t input, float value) { return scalar_node(OpType::SCALAR_ADD, input, value); }
+size_t CactusGraph::scalar_subtract(size_t input, float value) { return scalar_node(OpType::SCALAR_SUBTRACT, input, value); }
+size_t CactusGraph::scalar_multiply(size_t input, float value) { return scalar_node(OpType::SCALAR_MULTIPLY, input, value); }
+size_t CactusGraph::scalar_divide(size_t input, float value) { return scalar_node(OpType::SCALAR_DIVIDE, input, value); }
+
 size_t CactusGraph::conv1d_causal(size_t input, size_t weight, size_t, size_t dilation) {   // graph_builder.cpp:318-321
     OpParams p;
     p.dilation = dilation;
@@ -586,6 +597,17 @@ void CactusGraph::compute_binary_node(GraphNode& n) {
     }
 }
 
+// graph_ops_math.cpp:66-93 (the FP16 branch)
+void CactusGraph::compute_scalar_node(GraphNode& n) {
+    const BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    if (in.precision != Precision::FP16) throw std::runtime_error("Scalar operations only support FP16 precision");
+    const int op = n.op_type == OpType::SCALAR_ADD ? 0 : n.op_type == OpType::SCALAR_SUBTRACT ? 1
+                 : n.op_type == OpType::SCALAR_MULTIPLY ? 2 : 3;
+    abi_check(cactus_hip_scalar_op_f16_dev(static_cast<const cactus_half_t*>(in.device_data),
+                                           static_cast<cactus_half_t*>(n.output_buffer.device_data),
+                                           n.output_buffer.total_size, n.params.scalar, op, nullptr));
+}
+
 // graph_ops_math.cpp:158-180
 void CactusGraph::compute_activation_node(GraphNode& n) {
     const BufferDesc& in = node(n.input_ids[0]).output_buffer;
@@ -764,6 +786,8 @@ void CactusGraph::execute() {
             case OpType::ROPE: compute_rope_node(n); break;
             case OpType::EMBEDDING: compute_embedding_node(n); break;
             case OpType::CONV1D_CAUSAL: compute_conv1d_causal_node(n); break;
+            case OpType::SCALAR_ADD: case OpType::SCALAR_SUBTRACT: case OpType::SCALAR_MULTIPLY:
+            case OpType::SCALAR_DIVIDE: compute_scalar_node(n); break;
             case OpType::MATMUL: compute_matmul_node(n); break;
             case OpType::ATTENTION: compute_attention_node(n); break;
             case OpType::ATTENTION_INT8_HYBRID: compute_attention_int8_hybrid_node(n); break;
@@ -1118,6 +1142,17 @@ long cactus_hip_graph_binary(void* g, int op, size_t a, size_t b) {
             case 3: return (long)G_(g)->divide(a, b);
             case 4: return (long)G_(g)->add_clipped(a, b);
             default: throw std::invalid_argument("binary op must be 0..4");
+        }
+    });
+}
+long cactus_hip_graph_scalar_op(void* g, int op, size_t input, float value) {
+    return guarded<long>(-1, [&] {
+        switch (op) {
+            case 0: return (long)G_(g)->scalar_add(input, value);
+            case 1: return (long)G_(g)->scalar_subtract(input, value);
+            case 2: return (long)G_(g)->scalar_multiply(input, value);
+            case 3: return (long)G_(g)->scalar_divide(input, value);
+            default: throw std::invalid_argument("scalar op must be 0..3");
         }
     });
 }

@@ -33,7 +33,8 @@ enum class OpType {
     INPUT, MATMUL, ATTENTION, ATTENTION_INT8_HYBRID, QUANTIZE_ACTIVATIONS,
     // the ops between the hot kernels of a decoder block
     ADD, ADD_CLIPPED, SUBTRACT, MULTIPLY, DIVIDE, SILU, GELU, RMS_NORM, ROPE, RESHAPE, EMBEDDING,
-    CONV1D_CAUSAL   // LFM2's short convolution
+    CONV1D_CAUSAL,   // LFM2's short convolution
+    SCALAR_ADD, SCALAR_SUBTRACT, SCALAR_MULTIPLY, SCALAR_DIVIDE
 };
 
 size_t precision_size(Precision p);   // bytes per element (INT4 counted as 1, graph.h:128-136)
@@ -75,6 +76,7 @@ struct OpParams {
     float epsilon = 1e-5f;   // RMS_NORM
     float theta = 0.0f;      // ROPE
     size_t dilation = 1;     // CONV1D_CAUSAL
+    float scalar = 0.0f;     // SCALAR_*
     size_t window_size = 0;
     bool is_causal = true;
     Precision output_precision = Precision::INT8;
@@ -129,6 +131,11 @@ public:
     size_t divide(size_t input1, size_t input2);
     size_t silu(size_t input);
     size_t gelu(size_t input);
+    // graph.h:407-410; graph_builder.cpp:424-450
+    size_t scalar_add(size_t input, float value);
+    size_t scalar_subtract(size_t input, float value);
+    size_t scalar_multiply(size_t input, float value);
+    size_t scalar_divide(size_t input, float value);
     size_t reshape(size_t input, const std::vector<size_t>& new_shape);
     size_t embedding(size_t embedding_tensor, size_t indices);
     size_t rms_norm(size_t input, size_t weight, float epsilon = 1e-5f);
@@ -184,6 +191,8 @@ private:
     void compute_rope_node(GraphNode& n);
     void compute_embedding_node(GraphNode& n);
     void compute_conv1d_causal_node(GraphNode& n);
+    size_t scalar_node(OpType op, size_t input, float value);
+    void compute_scalar_node(GraphNode& n);
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;

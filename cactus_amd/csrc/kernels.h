@@ -147,6 +147,8 @@ hipError_t launch_rope(const uint16_t* in, uint16_t* out, const uint16_t* cos_t,
 hipError_t launch_unary(int op, const uint16_t* in, uint16_t* out, size_t n, hipStream_t st);     // 0 silu, 1 gelu
 hipError_t launch_binary(int op, const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n,
                          hipStream_t st);   // 0 add, 1 subtract, 2 multiply, 3 divide, 4 clipped add
+// cactus_scalar_op_f16's arithmetic ops: 0 add, 1 subtract, 2 multiply, 3 divide by half(scalar)
+hipError_t launch_scalar_op(int op, const uint16_t* a, float scalar, uint16_t* out, size_t n, hipStream_t st);
 hipError_t launch_embedding_int8(const int8_t* emb, const uint16_t* scales, const int32_t* indices, uint16_t* out,
                                  size_t num_indices, size_t vocab, size_t hidden, size_t group_size, int* bad,
                                  hipStream_t st);

@@ -23,6 +23,7 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_attention": (_l, [_vp, _sz, _sz, _sz, _f, _sz, _sz, _i]),
     "cactus_hip_graph_attention_int8_hybrid": (_l, [_vp, _sz, _sz, _sz, _f, _sz, _vp, _vp, _vp, _vp, _sz, _sz, _sz]),
     "cactus_hip_graph_binary": (_l, [_vp, _i, _sz, _sz]),
+    "cactus_hip_graph_scalar_op": (_l, [_vp, _i, _sz, _f]),
     "cactus_hip_graph_silu": (_l, [_vp, _sz]),
     "cactus_hip_graph_gelu": (_l, [_vp, _sz]),
     "cactus_hip_graph_reshape": (_l, [_vp, _sz, _szp, _sz]),
@@ -120,6 +121,18 @@ class CactusGraph:
 
     def _binary(self, op, a, b):
         return self._same(_node(lib.cactus_hip_graph_binary(self._g, op, a, b)), a)
+
+    def scalar_add(self, x, value):
+        return self._same(_node(lib.cactus_hip_graph_scalar_op(self._g, 0, x, value)), x)
+
+    def scalar_subtract(self, x, value):
+        return self._same(_node(lib.cactus_hip_graph_scalar_op(self._g, 1, x, value)), x)
+
+    def scalar_multiply(self, x, value):
+        return self._same(_node(lib.cactus_hip_graph_scalar_op(self._g, 2, x, value)), x)
+
+    def scalar_divide(self, x, value):
+        return self._same(_node(lib.cactus_hip_graph_scalar_op(self._g, 3, x, value)), x)
 
     def add(self, a, b):
         return self._binary(0, a, b)

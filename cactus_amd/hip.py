@@ -76,6 +76,7 @@ SIGNATURES = {
     "cactus_hip_add_rms_norm_f16_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _f, _vp]),
     "cactus_hip_qk_norm_rope_f16_dev": (_i, [_vp] * 6 + [_sz] * 5 + [_f, _sz, _f, _vp]),
     "cactus_hip_silu_multiply_f16_dev": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cactus_hip_scalar_op_f16_dev": (_i, [_vp, _vp, _sz, _f, _i, _vp]),
     "cactus_hip_conv1d_causal_depthwise_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_lfm2_conv_gate_f16_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_add_rms_norm_quant_f16_dev": (_i, [_vp] * 7 + [_sz, _sz, _f, _vp]),
@@ -493,6 +494,17 @@ def _binary(fn, a, b, out):
     assert a.shape == b.shape
     o = out if out is not None else torch.empty_like(a)
     _check(fn(_p(a), _p(b), _p(o), a.numel(), _stream()))
+    return o
+
+
+SCALAR_OPS = {"add": 0, "subtract": 1, "multiply": 2, "divide": 3, "exp": 4, "sqrt": 5, "cos": 6, "sin": 7}
+
+
+def scalar_op(op, x, value, out=None):
+    """x (op) half(value), element-wise on fp16."""
+    _dev(x, torch.float16)
+    o = out if out is not None else torch.empty_like(x)
+    _check(lib.cactus_hip_scalar_op_f16_dev(_p(x), _p(o), x.numel(), float(value), SCALAR_OPS[op], _stream()))
     return o
 
 

@@ -241,6 +241,12 @@ int cactus_hip_subtract_f16_dev(const cactus_half_t* a, const cactus_half_t* b, 
 int cactus_hip_multiply_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
 int cactus_hip_divide_f16_dev(const cactus_half_t* a, const cactus_half_t* b, cactus_half_t* output, size_t num_elements, void* stream);
 
+/* cactus_scalar_op_f16 (kernel.h:7-16, 39; kernel_scalar.cpp:7-154) for op_type ADD (0), SUBTRACT (1),
+ * MULTIPLY (2), DIVIDE (3): the scalar is rounded to binary16, then one fp16 operation per element.
+ * EXP / SQRT / COS / SIN (4..7) are not on the device: CACTUS_HIP_EINVAL. */
+int cactus_hip_scalar_op_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t num_elements,
+                                 float scalar_value, int op_type, void* stream);
+
 /* Sequences of the calls above that a decoder block makes back to back, in one launch each, with
  * the arithmetic of the separate calls (results are bit-identical to making them one by one):
  *   add_rms_norm    sum = cactus_add_f16(a, b); norm = cactus_rms_norm_f16(sum, weight)

@@ -46,6 +46,8 @@ long   cactus_hip_graph_attention_int8_hybrid(void* graph, size_t q, size_t key_
  * 0 add, 1 subtract, 2 multiply, 3 divide, 4 add_clipped; equal shapes only.  reshape is a view.
  * embedding: table node INT8 (with grouped scales) or FP16, indices node FP32 or INT8 values. */
 long   cactus_hip_graph_binary(void* graph, int op, size_t a, size_t b);
+/* CactusGraph::scalar_add / scalar_subtract / scalar_multiply / scalar_divide (graph.h:407-410): op 0..3. */
+long   cactus_hip_graph_scalar_op(void* graph, int op, size_t input, float value);
 long   cactus_hip_graph_silu(void* graph, size_t input);
 long   cactus_hip_graph_gelu(void* graph, size_t input);
 long   cactus_hip_graph_reshape(void* graph, size_t input, const size_t* shape, size_t ndim);

@@ -63,6 +63,7 @@ def _load():
     lib.oracle_sample_uniform.argtypes = [C.c_uint32]
     lib.oracle_logits_entropy_f16.restype = C.c_float
     lib.oracle_logits_entropy_f16.argtypes = [vp, sz]
+    lib.oracle_scalar_op_f16.argtypes = [vp, vp, sz, C.c_float, C.c_int]
     lib.oracle_conv1d_causal_depthwise_f16.argtypes = [vp, vp, vp, sz, sz, sz, sz, sz]
     lib.oracle_lfm2_conv_gate_f16.argtypes = [vp, vp, vp, vp, vp, vp, sz, sz, sz, sz]
     return lib
@@ -316,4 +317,11 @@ def lfm2_conv_gate(in_proj, weight, state):
     out = np.zeros((L, Cc), np.uint16)
     lib.oracle_lfm2_conv_gate_f16(_p(ip), _p(w), _p(state.rows), C.byref(state.head), C.byref(state.count),
                                   _p(out), L, Cc, w.shape[-1], state.W)
+    return out
+
+
+def scalar_op(op, x, value):
+    x = _c(x, np.uint16)
+    out = np.zeros(x.shape, np.uint16)
+    lib.oracle_scalar_op_f16(_p(x), _p(out), x.size, float(value), BINARY_OPS[op])
     return out

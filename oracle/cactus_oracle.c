@@ -1063,3 +1063,11 @@ void oracle_lfm2_conv_gate_f16(const uint16_t* in_proj, const uint16_t* weight, 
     free(cat);
     free(y);
 }
+
+/* cactus_scalar_op_f16, arithmetic ops: cactus/kernel/kernel_scalar.cpp:7-154.  The scalar is
+ * cast to fp16 once (:8); vector body and tail both apply one fp16 operation per element.
+ * op: 0 add, 1 subtract, 2 multiply, 3 divide. */
+void oracle_scalar_op_f16(const uint16_t* in, uint16_t* out, size_t n, float scalar, int op) {
+    const uint16_t sb = oracle_f2h(scalar);
+    for (size_t i = 0; i < n; i++) oracle_binary_f16(op, in + i, &sb, out + i, 1);
+}

@@ -113,6 +113,8 @@ float oracle_logits_entropy_f16(const uint16_t* logits, size_t vocab_size);
 int  oracle_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out,
                           size_t num_indices, size_t vocab_size, size_t hidden_dim);
 
+void oracle_scalar_op_f16(const uint16_t* in, uint16_t* out, size_t n, float scalar, int op);
+
 /* LFM2's short convolution (PARITY UNPINNED: the reference's tests hold nothing
  * for the causal convolution or the conv cache; checked against float64 sums). */
 void oracle_conv1d_causal_depthwise_f16(const uint16_t* input, const uint16_t* weight, uint16_t* output,

@@ -419,3 +419,35 @@ def test_qk_norm_rope_kv_append_row_for_row(H):
     wvq, wvs = O.quantize_kv(v.reshape(S, Hkv, D))
     assert np.array_equal(kc.cpu().numpy(), wkq) and np.array_equal(vc.cpu().numpy(), wvq)
     assert np.array_equal(ks.cpu().numpy().reshape(-1), wks.reshape(-1)) and np.array_equal(vs.cpu().numpy().reshape(-1), wvs.reshape(-1))
+
+
+# ------------------------------------------------------------------------------ scalar ops
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide"])
+@pytest.mark.parametrize("n", [1, 7, 8, 4099, 640 * 33])
+def test_scalar_op_bit_exact(H, op, n):
+    """kernel_scalar.cpp:7-154: scalar rounded to half, one fp16 operation per element."""
+    rng = np.random.default_rng(n)
+    x = halves(rng, n, 6.0)
+    for value in (25.298221, -0.3333, 2.0):
+        assert np.array_equal(bits(H.scalar_op(op, dev(x), value)), O.scalar_op(op, x, value)), (op, value)
+
+
+def test_scalar_op_graph_known_answers(H):
+    """tests/test_graph.cpp:10-33, 120-150 through the graph nodes; the transcendental scalar ops
+    are not on the device."""
+    import cactus_amd.graph as G
+    g = G.CactusGraph()
+    a, b = g.input((2, 3), G.FP16), g.input((2, 3), G.FP16)
+    r = g.scalar_multiply(g.multiply(g.add(a, b), a), 2.0)
+    c = g.input((4,), G.FP16)
+    r2 = g.scalar_multiply(g.scalar_add(c, 5.0), 2.0)
+    r3, r4 = g.scalar_subtract(c, 2.0), g.scalar_divide(c, 2.0)
+    da, db = np.array([[1, 2, 3], [4, 5, 6]], np.float16), np.array([[2, 3, 4], [5, 6, 7]], np.float16)
+    g.set_input(a, da); g.set_input(b, db); g.set_input(c, np.array([10, 8, 6, 4], np.float16))
+    g.execute()
+    assert np.array_equal(g.get_output(r), ((da + db) * da * np.float16(2)).astype(np.float16))
+    assert g.get_output(r2).tolist() == [30, 26, 22, 18]
+    assert g.get_output(r3).tolist() == [8, 6, 4, 2] and g.get_output(r4).tolist() == [5, 4, 3, 2]
+    g.close()
+    with pytest.raises(H.CactusHipError):
+        H.scalar_op("exp", dev(np.ones(8, np.float16)), 0.0)

@@ -111,3 +111,19 @@ def test_embedding_known_answers():
     half = np.full((4, 1), 0.5, np.float16)
     got = O.embedding(table, np.array([1], np.int32), half, 4).view(np.float16)
     assert got.tolist() == [[1, 3, 5, 1.5]]
+
+
+def test_scalar_op_known_answers_and_numpy():
+    """tests/test_graph.cpp:120-150 (exact small integers) and numpy's float16 arithmetic with the
+    scalar rounded to half first (kernel_scalar.cpp:8)."""
+    f = lambda v: np.array(v, np.float16)
+    add = O.scalar_op("add", f([1, 2, 3, 4]), 5.0)
+    assert O.scalar_op("multiply", add, 2.0).view(np.float16).tolist() == [12, 14, 16, 18]
+    assert O.scalar_op("subtract", f([10, 8, 6, 4]), 2.0).view(np.float16).tolist() == [8, 6, 4, 2]
+    assert O.scalar_op("divide", f([10, 8, 6, 4]), 2.0).view(np.float16).tolist() == [5, 4, 3, 2]
+    rng = np.random.default_rng(4)
+    x = halves(rng, 3001, 6.0)
+    sc = np.float16(25.298221)                       # sqrt(640), Gemma's embedding scale, rounds in half
+    with np.errstate(all="ignore"):
+        for op, fn in (("add", np.add), ("subtract", np.subtract), ("multiply", np.multiply), ("divide", np.divide)):
+            assert np.array_equal(O.scalar_op(op, x, 25.298221), fn(x, sc).view(np.uint16)), op
