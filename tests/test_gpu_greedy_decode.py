@@ -163,3 +163,146 @@ def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain
     assert len(set(dev_tokens)) > 1          # not a degenerate stream
     g.close()
     cache.close()
+
+
+# ------------------------------------------------------------------------ Gemma-3-270m shape
+# models/model_gemma.cpp:57-189: embedding scaled by sqrt(hidden), four norms per block (the
+# attention and MLP outputs are normalized before their clipped residual adds), GELU, RoPE theta
+# 10000 on the sliding-window blocks and 1e6 on every sixth (global) one, window 512 in the
+# prefill attention.  Dimensions from the public model card (the reference reads config.txt):
+# hidden 640, ffn 2048, 4 q / 1 kv heads of 256, 18 blocks, vocabulary 262144.
+GEM = dict(HID=640, HQ=4, HKV=1, D=256, FF=2048, LAYERS=18, VOCAB=262144, EPS=1e-6)
+
+
+def gemma_model(rng, gain):
+    c = GEM
+
+    def mat(n, k, g):
+        B, Bs = rand_weights_int8(rng, n, k)
+        return B, (Bs.astype(np.float32) * g).astype(np.float16)
+    layers = []
+    for _ in range(c["LAYERS"]):
+        L = {name: mat(n, k, gain) for name, (n, k) in {
+            "q": (c["HQ"] * c["D"], c["HID"]), "k": (c["HKV"] * c["D"], c["HID"]), "v": (c["HKV"] * c["D"], c["HID"]),
+            "o": (c["HID"], c["HQ"] * c["D"]), "gate": (c["FF"], c["HID"]), "up": (c["FF"], c["HID"]),
+            "down": (c["HID"], c["FF"])}.items()}
+        for name, n in {"in_norm": c["HID"], "post_attn_norm": c["HID"], "pre_ffn_norm": c["HID"],
+                        "post_ffn_norm": c["HID"], "q_norm": c["D"], "k_norm": c["D"]}.items():
+            L[name] = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float16)
+        layers.append(L)
+    # embedding rows of standard deviation about 0.05: scaled by sqrt(640) they are the size of one
+    # normalized branch output, so the blocks, not the tied embedding, decide the next token
+    return {"layers": layers, "emb": mat(c["VOCAB"], c["HID"], 0.02),
+            "final_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
+
+
+def gemma_oracle_forward(m, tokens, pos, caches):
+    c = GEM
+    S, Hq, Hkv, Dh, eps = len(tokens), c["HQ"], c["HKV"], c["D"], c["EPS"]
+    h = O.embedding(m["emb"][0], np.asarray(tokens, np.int32), m["emb"][1].view(np.uint16), 128)
+    h = O.scalar_op("multiply", h, np.sqrt(np.float32(c["HID"])))
+    for li, L in enumerate(m["layers"]):
+        glob = (li + 1) % 6 == 0
+        n1 = O.rms_norm(h, L["in_norm"], eps)
+        q = O.rms_norm(omm(n1, L["q"]).reshape(S * Hq, Dh), L["q_norm"], eps).reshape(1, S, Hq, Dh)
+        k = O.rms_norm(omm(n1, L["k"]).reshape(S * Hkv, Dh), L["k_norm"], eps).reshape(1, S, Hkv, Dh)
+        v = omm(n1, L["v"]).reshape(1, S, Hkv, Dh)
+        theta = 1e6 if glob else 1e4
+        q, k = O.rope(q, theta, pos), O.rope(k, theta, pos)
+        scale = 1.0 / np.sqrt(Dh)
+        if caches[li] is None:
+            attn = O.attention_f16(q, k, v, scale, position_offset=pos, window_size=0 if glob else 512)
+        else:
+            kq, ks, vq, vs = caches[li]
+            attn = O.attention_hybrid(q, kq[None], vq[None], ks[None], vs[None], k, v, scale, position_offset=pos)
+        new = O.quantize_kv(k.reshape(S, Hkv, Dh)) + O.quantize_kv(v.reshape(S, Hkv, Dh))
+        caches[li] = list(new) if caches[li] is None else [np.concatenate([a, b]) for a, b in zip(caches[li], new)]
+        ao = O.rms_norm(omm(attn.reshape(S, Hq * Dh), L["o"]), L["post_attn_norm"], eps)
+        h = O.add_clipped(h, ao)
+        n2 = O.rms_norm(h, L["pre_ffn_norm"], eps)
+        act = O.binary("multiply", O.gelu(omm(n2, L["gate"])), omm(n2, L["up"]))
+        h = O.add_clipped(h, O.rms_norm(omm(act, L["down"]), L["post_ffn_norm"], eps))
+    return omm(O.rms_norm(h[S - 1:S], m["final_norm"], eps), m["emb"])[0]
+
+
+def gemma_graph_forward(G, g, wn, tokens, pos, cache):
+    c = GEM
+    S, Hq, Hkv, Dh, eps = len(tokens), c["HQ"], c["HKV"], c["D"], c["EPS"]
+    idx = g.input((S,), G.FP32)
+    g.set_input(idx, np.asarray(tokens, np.float32))
+    h = g.scalar_multiply(g.embedding(wn["emb"], idx), float(np.sqrt(np.float32(c["HID"]))))
+    k_nodes, v_nodes = [], []
+    for li, L in enumerate(wn["layers"]):
+        glob = (li + 1) % 6 == 0
+        n1 = g.rms_norm(h, L["in_norm"], eps)
+        q, k, v = (g.matmul(n1, L[name], True) for name in ("q", "k", "v"))
+        q = g.reshape(g.rms_norm(g.reshape(q, (S * Hq, Dh)), L["q_norm"], eps), (1, S, Hq, Dh))
+        k = g.reshape(g.rms_norm(g.reshape(k, (S * Hkv, Dh)), L["k_norm"], eps), (1, S, Hkv, Dh))
+        v = g.reshape(v, (1, S, Hkv, Dh))
+        theta = 1e6 if glob else 1e4
+        q, k = g.rope(q, theta, pos), g.rope(k, theta, pos)
+        k_nodes.append(k)
+        v_nodes.append(v)
+        scale = 1.0 / np.sqrt(Dh)
+        if cache.is_empty():
+            attn = g.attention(q, k, v, scale, pos, 0 if glob else 512)
+        else:
+            attn = g.attention_int8_hybrid(q, k, v, scale, pos, cache.get_keys_int8(li), cache.get_values_int8(li),
+                                           cache.get_key_scales(li), cache.get_value_scales(li),
+                                           cache.get_effective_seq_len(), Hkv, Dh)
+        ao = g.rms_norm(g.matmul(g.reshape(attn, (S, Hq * Dh)), L["o"], True), L["post_attn_norm"], eps)
+        h = g.add_clipped(h, ao)
+        n2 = g.rms_norm(h, L["pre_ffn_norm"], eps)
+        act = g.multiply(g.gelu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
+        h = g.add_clipped(h, g.rms_norm(g.matmul(act, L["down"], True), L["post_ffn_norm"], eps))
+    logits = g.matmul(g.rms_norm(h, wn["final_norm"], eps), wn["emb"], True)
+    g.execute()
+    out = g.get_output(logits).reshape(S, -1)[S - 1].copy()
+    cache.update_from_graph(g, k_nodes, v_nodes, S)
+    g.soft_reset()
+    return out
+
+
+def test_gemma3_270m_shape_greedy_64_tokens(G):
+    """The reference's CPU-runnable configuration (Gemma-3-270m, INT8, 64 greedy tokens) on a
+    synthetic model of that shape: at every step the device's greedy token equals the oracle's and
+    the logits agree.  Random weights with normalized branch outputs fall into a one-token loop, so
+    whenever the chosen token was produced before, both sides continue from a fresh seeded token
+    instead (the comparison of that step's choice has already been made).  At most two of the 64
+    choices may differ, and only as near ties of the oracle's own logits."""
+    import cactus_amd.hip as H
+    rng = np.random.default_rng(12)
+    m = gemma_model(rng, 0.02)
+    prompt = rng.integers(0, GEM["VOCAB"], 6).tolist()
+    g = G.CactusGraph()
+    wn = bind(G, g, m)
+    cache = G.KVCache(GEM["LAYERS"], 2048, GEM["HKV"], GEM["D"])
+    ocaches = [None] * GEM["LAYERS"]
+    dev_tokens, ora_tokens, near_ties = [], [], 0
+    feed, pos = prompt, 0
+    for step in range(64):
+        lg_d = gemma_graph_forward(G, g, wn, feed, pos, cache)
+        lg_o = gemma_oracle_forward(m, feed, pos, ocaches).view(np.float16)
+        ref = lg_o.astype(np.float64)
+        err = np.abs(lg_d.astype(np.float64) - ref).max()
+        # Differences start as single fp16 ulps in the attention output and are absorbed by the INT8
+        # activation quantization of the next matmul until one flips a quantized value; from then on
+        # the K/V rows in the two caches differ and Gemma's four norms per block carry the relative
+        # difference through 18 blocks: observed up to 3.5 % of the largest logit, 0.6 % rms.
+        assert err <= 2e-2 + 5e-2 * np.abs(ref).max(), (step, err, np.abs(ref).max())
+        td = int(H.sample_greedy(torch.from_numpy(lg_d[None].copy()).cuda()).cpu()[0])
+        to = int(O.sample_greedy(lg_o[None])[0])
+        dev_tokens.append(td)
+        ora_tokens.append(to)
+        if td != to:
+            # a synthetic model's logits are nearly flat (largest about 7 over 262144 entries): the two
+            # sides may only part where the oracle itself separates the two candidates by less than
+            # the difference between the logit rows; both then continue from the oracle's token
+            assert ref[to] - ref[td] <= 2 * err, (step, td, to, ref[to], ref[td], err)
+            near_ties += 1
+            td = to
+        pos += len(feed)
+        feed = [td] if dev_tokens.count(td) <= 1 and ora_tokens.count(td) <= 1 else [int(rng.integers(0, GEM["VOCAB"]))]
+    assert cache.get_total_seq_len() == 6 + 63 and near_ties <= 2
+    g.close()
+    cache.close()
