@@ -167,6 +167,52 @@ size_t CactusGraph::reshape(size_t input, const std::vector<size_t>& new_shape) 
     return add_node(OpType::RESHAPE, {input}, new_shape);
 }
 
+size_t CactusGraph::slice(size_t input, int axis, size_t start, size_t length) {   // graph_builder.cpp:499-522
+    const auto& in = get_output_buffer(input);
+    if (in.shape.empty()) throw std::runtime_error("Cannot slice a scalar tensor");
+    if (axis < 0 || static_cast<size_t>(axis) >= in.shape.size()) throw std::runtime_error("Invalid axis for slice operation");
+    if (start + length > in.shape[axis]) throw std::runtime_error("Slice range extends beyond axis size");
+    std::vector<size_t> shape = in.shape;
+    shape[axis] = length;
+    OpParams p;
+    p.axis = axis; p.slice_start = start; p.slice_length = length; p.output_precision = in.precision;
+    return add_node(OpType::SLICE, {input}, shape, p);
+}
+
+size_t CactusGraph::concat(size_t input1, size_t input2, int axis) {   // graph_builder.cpp:348-375
+    const auto& b1 = get_output_buffer(input1);
+    const auto& b2 = get_output_buffer(input2);
+    if (b1.shape.size() != b2.shape.size()) throw std::runtime_error("Concat requires inputs with same number of dimensions");
+    const int nd = (int)b1.shape.size();
+    if (axis < 0) axis += nd;
+    if (axis < 0 || axis >= nd) throw std::runtime_error("Invalid axis for concat operation");
+    for (int i = 0; i < nd; i++)
+        if (i != axis && b1.shape[i] != b2.shape[i])
+            throw std::runtime_error("Concat inputs must have same shape except on concat axis");
+    std::vector<size_t> shape = b1.shape;
+    shape[axis] = b1.shape[axis] + b2.shape[axis];
+    OpParams p;
+    p.axis = axis;
+    return add_node(OpType::CONCAT, {input1, input2}, shape, p);
+}
+
+size_t CactusGraph::index(size_t input, size_t index_value, int dim) {   // graph_builder.cpp:125-160
+    const auto& in = get_output_buffer(input);
+    if (in.shape.empty()) throw std::invalid_argument("Cannot index a scalar tensor");
+    int d = dim < 0 ? dim + (int)in.shape.size() : dim;
+    if (d < 0 || static_cast<size_t>(d) >= in.shape.size()) throw std::invalid_argument("Index dimension out of bounds");
+    if (index_value >= in.shape[d])
+        throw std::invalid_argument("Index value " + std::to_string(index_value) + " out of bounds for dimension " +
+                                    std::to_string(d) + " with size " + std::to_string(in.shape[d]));
+    std::vector<size_t> shape;
+    for (size_t i = 0; i < in.shape.size(); i++)
+        if ((int)i != d) shape.push_back(in.shape[i]);
+    if (shape.empty()) shape = {1};
+    OpParams p;
+    p.axis = d; p.index_value = index_value; p.output_precision = in.precision;
+    return add_node(OpType::INDEX, {input}, shape, p);
+}
+
 size_t CactusGraph::embedding(size_t embedding_tensor, size_t indices) {   // graph_builder.cpp:524-539
     const auto& emb = get_output_buffer(embedding_tensor);
     if (emb.shape.size() != 2) throw std::runtime_error("Embedding tensor must be 2D [vocab_size, hidden_dim]");
@@ -597,6 +643,40 @@ void CactusGraph::compute_binary_node(GraphNode& n) {
     }
 }
 
+// graph_ops_tensor.cpp:138-224 (slice), 350-395 (index): `count` entries from `first` along the axis,
+// one strided device copy (axis 0 never gets here: it is a view).
+void CactusGraph::compute_slice_node(GraphNode& n) {
+    const BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    const size_t axis = (size_t)n.params.axis;
+    const bool is_index = n.op_type == OpType::INDEX;
+    const size_t first = is_index ? n.params.index_value : n.params.slice_start;
+    const size_t count = is_index ? 1 : (n.params.slice_length ? n.params.slice_length : in.shape[axis] - first);
+    size_t outer = 1, inner = precision_size(in.precision);
+    for (size_t i = 0; i < axis; i++) outer *= in.shape[i];
+    for (size_t i = axis + 1; i < in.shape.size(); i++) inner *= in.shape[i];
+    if (outer == 0 || count == 0 || inner == 0) return;
+    hip_check(hipMemcpy2DAsync(n.output_buffer.device_data, count * inner,
+                               static_cast<const char*>(in.device_data) + first * inner, in.shape[axis] * inner,
+                               count * inner, outer, hipMemcpyDeviceToDevice, nullptr), "slice copy");
+}
+
+// graph_ops_tensor.cpp:333-348
+void CactusGraph::compute_concat_node(GraphNode& n) {
+    const BufferDesc& a = node(n.input_ids[0]).output_buffer;
+    const BufferDesc& b = node(n.input_ids[1]).output_buffer;
+    if (a.precision != Precision::FP16 || b.precision != Precision::FP16)
+        throw std::runtime_error("Concat operation only supports FP16 precision");
+    const size_t axis = (size_t)n.params.axis;
+    size_t outer = 1, inner = precision_size(a.precision);
+    for (size_t i = 0; i < axis; i++) outer *= a.shape[i];
+    for (size_t i = axis + 1; i < a.shape.size(); i++) inner *= a.shape[i];
+    const size_t wa = a.shape[axis] * inner, wb = b.shape[axis] * inner;
+    char* out = static_cast<char*>(n.output_buffer.device_data);
+    if (outer == 0 || wa + wb == 0) return;
+    if (wa) hip_check(hipMemcpy2DAsync(out, wa + wb, a.device_data, wa, wa, outer, hipMemcpyDeviceToDevice, nullptr), "concat copy");
+    if (wb) hip_check(hipMemcpy2DAsync(out + wa, wa + wb, b.device_data, wb, wb, outer, hipMemcpyDeviceToDevice, nullptr), "concat copy");
+}
+
 // graph_ops_math.cpp:66-93 (the FP16 branch)
 void CactusGraph::compute_scalar_node(GraphNode& n) {
     const BufferDesc& in = node(n.input_ids[0]).output_buffer;
@@ -777,6 +857,18 @@ void CactusGraph::execute() {
             out.device_valid = true;
             continue;
         }
+        if ((n.op_type == OpType::SLICE || n.op_type == OpType::INDEX) && n.params.axis == 0) {
+            // a view of the input's rows (graph_ops_tensor.cpp:154-168, 361-366)
+            BufferDesc& in = node(n.input_ids[0]).output_buffer;
+            BufferDesc& out = n.output_buffer;
+            const size_t first = n.op_type == OpType::INDEX ? n.params.index_value : n.params.slice_start;
+            const size_t row_bytes = in.shape[0] ? in.byte_size / in.shape[0] : 0;
+            if (out.owns_device && out.device_data) (void)hipFree(out.device_data);
+            out.device_data = static_cast<char*>(in.device_data) + first * row_bytes;
+            out.owns_device = false;
+            out.device_valid = true;
+            continue;
+        }
         ensure_device(n.output_buffer);
         switch (n.op_type) {
             case OpType::ADD: case OpType::ADD_CLIPPED: case OpType::SUBTRACT: case OpType::MULTIPLY:
@@ -788,6 +880,8 @@ void CactusGraph::execute() {
             case OpType::CONV1D_CAUSAL: compute_conv1d_causal_node(n); break;
             case OpType::SCALAR_ADD: case OpType::SCALAR_SUBTRACT: case OpType::SCALAR_MULTIPLY:
             case OpType::SCALAR_DIVIDE: compute_scalar_node(n); break;
+            case OpType::SLICE: case OpType::INDEX: compute_slice_node(n); break;
+            case OpType::CONCAT: compute_concat_node(n); break;
             case OpType::MATMUL: compute_matmul_node(n); break;
             case OpType::ATTENTION: compute_attention_node(n); break;
             case OpType::ATTENTION_INT8_HYBRID: compute_attention_int8_hybrid_node(n); break;
@@ -1160,6 +1254,15 @@ long cactus_hip_graph_silu(void* g, size_t input) { return guarded<long>(-1, [&]
 long cactus_hip_graph_gelu(void* g, size_t input) { return guarded<long>(-1, [&] { return (long)G_(g)->gelu(input); }); }
 long cactus_hip_graph_reshape(void* g, size_t input, const size_t* shape, size_t ndim) {
     return guarded<long>(-1, [&] { return (long)G_(g)->reshape(input, std::vector<size_t>(shape, shape + ndim)); });
+}
+long cactus_hip_graph_slice(void* g, size_t input, int axis, size_t start, size_t length) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->slice(input, axis, start, length); });
+}
+long cactus_hip_graph_concat(void* g, size_t input1, size_t input2, int axis) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->concat(input1, input2, axis); });
+}
+long cactus_hip_graph_index(void* g, size_t input, size_t index_value, int dim) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->index(input, index_value, dim); });
 }
 long cactus_hip_graph_embedding(void* g, size_t table, size_t indices) {
     return guarded<long>(-1, [&] { return (long)G_(g)->embedding(table, indices); });

@@ -34,7 +34,8 @@ enum class OpType {
     // the ops between the hot kernels of a decoder block
     ADD, ADD_CLIPPED, SUBTRACT, MULTIPLY, DIVIDE, SILU, GELU, RMS_NORM, ROPE, RESHAPE, EMBEDDING,
     CONV1D_CAUSAL,   // LFM2's short convolution
-    SCALAR_ADD, SCALAR_SUBTRACT, SCALAR_MULTIPLY, SCALAR_DIVIDE
+    SCALAR_ADD, SCALAR_SUBTRACT, SCALAR_MULTIPLY, SCALAR_DIVIDE,
+    SLICE, CONCAT, INDEX
 };
 
 size_t precision_size(Precision p);   // bytes per element (INT4 counted as 1, graph.h:128-136)
@@ -77,6 +78,8 @@ struct OpParams {
     float theta = 0.0f;      // ROPE
     size_t dilation = 1;     // CONV1D_CAUSAL
     float scalar = 0.0f;     // SCALAR_*
+    int axis = 0;            // SLICE, CONCAT, INDEX
+    size_t slice_start = 0, slice_length = 0, index_value = 0;
     size_t window_size = 0;
     bool is_causal = true;
     Precision output_precision = Precision::INT8;
@@ -138,6 +141,11 @@ public:
     size_t scalar_divide(size_t input, float value);
     size_t reshape(size_t input, const std::vector<size_t>& new_shape);
     size_t embedding(size_t embedding_tensor, size_t indices);
+    // graph.h:426-428, 444; graph_builder.cpp:125-160, 348-375, 499-522.  Along axis 0 slice and index are
+    // views of their input's buffer (as in the reference), along other axes strided device copies.
+    size_t slice(size_t input, int axis, size_t start, size_t length);
+    size_t concat(size_t input1, size_t input2, int axis = 0);
+    size_t index(size_t input, size_t index_value, int dim);
     size_t rms_norm(size_t input, size_t weight, float epsilon = 1e-5f);
     size_t rope(size_t input, float theta, size_t position_offset = 0,
                 ComputeBackend backend = ComputeBackend::HIP);
@@ -193,6 +201,8 @@ private:
     void compute_conv1d_causal_node(GraphNode& n);
     size_t scalar_node(OpType op, size_t input, float value);
     void compute_scalar_node(GraphNode& n);
+    void compute_slice_node(GraphNode& n);     // SLICE and INDEX
+    void compute_concat_node(GraphNode& n);
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;

@@ -27,6 +27,9 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_silu": (_l, [_vp, _sz]),
     "cactus_hip_graph_gelu": (_l, [_vp, _sz]),
     "cactus_hip_graph_reshape": (_l, [_vp, _sz, _szp, _sz]),
+    "cactus_hip_graph_slice": (_l, [_vp, _sz, _i, _sz, _sz]),
+    "cactus_hip_graph_concat": (_l, [_vp, _sz, _sz, _i]),
+    "cactus_hip_graph_index": (_l, [_vp, _sz, _sz, _i]),
     "cactus_hip_graph_embedding": (_l, [_vp, _sz, _sz]),
     "cactus_hip_graph_rms_norm": (_l, [_vp, _sz, _sz, _f]),
     "cactus_hip_graph_rope": (_l, [_vp, _sz, _f, _sz]),
@@ -159,6 +162,29 @@ class CactusGraph:
         arr = (C.c_size_t * len(shape))(*shape)
         n = _node(lib.cactus_hip_graph_reshape(self._g, x, arr, len(shape)))
         self._shapes[n] = (tuple(shape), self._shapes[x][1])
+        return n
+
+    def slice(self, x, axis, start, length):
+        n = _node(lib.cactus_hip_graph_slice(self._g, x, axis, start, length))
+        shp = list(self._shapes[x][0])
+        shp[axis] = length
+        self._shapes[n] = (tuple(shp), self._shapes[x][1])
+        return n
+
+    def concat(self, a, b, axis=0):
+        n = _node(lib.cactus_hip_graph_concat(self._g, a, b, axis))
+        shp = list(self._shapes[a][0])
+        ax = axis + len(shp) if axis < 0 else axis
+        shp[ax] += self._shapes[b][0][ax]
+        self._shapes[n] = (tuple(shp), self._shapes[a][1])
+        return n
+
+    def index(self, x, index_value, dim):
+        n = _node(lib.cactus_hip_graph_index(self._g, x, index_value, dim))
+        shp = list(self._shapes[x][0])
+        d = dim + len(shp) if dim < 0 else dim
+        del shp[d]
+        self._shapes[n] = (tuple(shp) or (1,), self._shapes[x][1])
         return n
 
     def embedding(self, table, indices):

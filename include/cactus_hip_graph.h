@@ -51,6 +51,10 @@ long   cactus_hip_graph_scalar_op(void* graph, int op, size_t input, float value
 long   cactus_hip_graph_silu(void* graph, size_t input);
 long   cactus_hip_graph_gelu(void* graph, size_t input);
 long   cactus_hip_graph_reshape(void* graph, size_t input, const size_t* shape, size_t ndim);
+/* CactusGraph::slice / concat / index (graph.h:426-428, 444): along axis 0 slice and index are views. */
+long   cactus_hip_graph_slice(void* graph, size_t input, int axis, size_t start, size_t length);
+long   cactus_hip_graph_concat(void* graph, size_t input1, size_t input2, int axis);
+long   cactus_hip_graph_index(void* graph, size_t input, size_t index_value, int dim);
 long   cactus_hip_graph_embedding(void* graph, size_t table, size_t indices);
 long   cactus_hip_graph_rms_norm(void* graph, size_t input, size_t weight, float epsilon);
 long   cactus_hip_graph_rope(void* graph, size_t input, float theta, size_t position_offset);

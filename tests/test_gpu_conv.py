@@ -186,3 +186,71 @@ def test_lfm2_conv_decoder_block_bit_exact(H):
         g_act = H.silu_multiply(H.matmul_f16act(g_n2, *dw["gate"], 128), H.matmul_f16act(g_n2, *dw["up"], 128))
         got = H.add(g_after, H.matmul_f16act(g_act, *dw["down"], 128))
         assert np.array_equal(bits(got), want), L
+
+
+def test_graph_slice_concat_index_nodes(H):
+    """CactusGraph::slice / concat / index (graph_builder.cpp:125-160, 348-375, 499-522) against numpy,
+    along the first axis (views) and inner axes (strided copies)."""
+    import cactus_amd.graph as G
+    rng = np.random.default_rng(40)
+    a, b = halves(rng, (5, 3, 8)), halves(rng, (5, 2, 8))
+    g = G.CactusGraph()
+    na, nb = g.input(a.shape, G.FP16), g.input(b.shape, G.FP16)
+    nodes = {"s0": g.slice(na, 0, 1, 3), "s1": g.slice(na, 1, 1, 2), "s2": g.slice(na, 2, 3, 4),
+             "c1": g.concat(na, nb, 1), "c0": g.concat(na, na, 0), "cm": g.concat(na, nb, -2),
+             "i0": g.index(na, 4, 0), "i1": g.index(na, 2, 1), "i2": g.index(na, 7, -1)}
+    nodes["chain"] = g.add(g.slice(nodes["c1"], 1, 3, 2), nb)          # a slice of a concat feeds a kernel
+    g.set_input(na, a)
+    g.set_input(nb, b)
+    g.execute()
+    want = {"s0": a[1:4], "s1": a[:, 1:3], "s2": a[:, :, 3:7], "c1": np.concatenate([a, b], 1),
+            "c0": np.concatenate([a, a], 0), "cm": np.concatenate([a, b], 1), "i0": a[4], "i1": a[:, 2],
+            "i2": a[:, :, 7], "chain": b + b}
+    for k, v in want.items():
+        got = g.get_output(nodes[k])
+        assert got.shape == v.shape and np.array_equal(got, v), k
+    for bad in (lambda: g.slice(na, 1, 2, 2), lambda: g.concat(na, nb, 0), lambda: g.index(na, 3, 1)):
+        with pytest.raises(Exception):
+            bad()
+    g.close()
+
+
+def test_graph_lfm2_conv_block_as_the_reference_builds_it(H):
+    """LFM2Model::build_conv1d node by node (model_lfm2.cpp:136-204): reshape to [L, 3, C], three slices,
+    multiply, the cache window as input nodes concatenated in front, conv1d_causal, slice of the last
+    L rows, multiply -- two calls with the ConvCache rows carried on the host as the reference carries
+    them; equal to the oracle and to the one-launch block op."""
+    import cactus_amd.graph as G
+    rng = np.random.default_rng(41)
+    C, K, W = 64, 3, 2
+    w = halves(rng, (C, 1, K), 0.5)
+    state = torch.zeros((1, W, C), dtype=torch.float16, device="cuda")
+    cache = O.Lfm2ConvState(W, C)
+    window = np.zeros((0, C), np.float16)                       # rows held, oldest first
+    g = G.CactusGraph()
+    for L in (5, 1, 1):
+        ip = halves(rng, (L, 3 * C))
+        nin, nw = g.input((L, 3 * C), G.FP16), g.input((C, 1, K), G.FP16)
+        trip = g.reshape(nin, (L, 3, C))
+        Bn, Cg, X = (g.reshape(g.slice(trip, 1, i, 1), (L, C)) for i in range(3))
+        bx = g.multiply(Bn, X)
+        conv_in = bx
+        if len(window):
+            wn = g.input(window.shape, G.FP16)
+            g.set_input(wn, window)
+            conv_in = g.concat(wn, bx, 0)
+        total = len(window) + L
+        y = g.conv1d_causal(g.reshape(conv_in, (1, total, C)), nw, K, 1)
+        y = g.reshape(g.slice(y, 1, total - L, L), (L, C))
+        gated = g.multiply(Cg, y)
+        g.set_input(nin, ip)
+        g.set_input(nw, w)
+        g.execute()
+        got = g.get_output(gated).view(np.uint16)
+        want = O.lfm2_conv_gate(ip, w.reshape(C, K), cache)
+        assert np.array_equal(got, want), L
+        fused = bits(H.lfm2_conv_gate(dev(ip[None]), dev(w.reshape(C, K)), state))[0]
+        assert np.array_equal(fused, want), L
+        window = np.concatenate([window, g.get_output(bx)])[-W:]
+        g.soft_reset()
+    g.close()
