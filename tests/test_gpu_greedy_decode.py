@@ -124,9 +124,10 @@ def graph_forward(G, g, wn, tokens, pos, cache):
         n2 = g.rms_norm(h, L["post_norm"], EPS)
         act = g.multiply(g.silu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
         h = g.add(h, g.matmul(act, L["down"], True))
-    logits = g.matmul(g.rms_norm(h, wn["final_norm"], EPS), wn["emb"], True)     # every row; the last one is used
+    last = g.reshape(g.index(g.rms_norm(h, wn["final_norm"], EPS), S - 1, 0), (1, HID))   # engine_model.cpp:241-246
+    logits = g.matmul(last, wn["emb"], True)
     g.execute()
-    out = g.get_output(logits).reshape(S, -1)[S - 1].copy()
+    out = g.get_output(logits).reshape(-1).copy()
     cache.update_from_graph(g, k_nodes, v_nodes, S)
     g.soft_reset()
     return out
@@ -255,9 +256,10 @@ def gemma_graph_forward(G, g, wn, tokens, pos, cache):
         n2 = g.rms_norm(h, L["pre_ffn_norm"], eps)
         act = g.multiply(g.gelu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
         h = g.add_clipped(h, g.rms_norm(g.matmul(act, L["down"], True), L["post_ffn_norm"], eps))
-    logits = g.matmul(g.rms_norm(h, wn["final_norm"], eps), wn["emb"], True)
+    last = g.reshape(g.index(g.rms_norm(h, wn["final_norm"], eps), S - 1, 0), (1, c["HID"]))
+    logits = g.matmul(last, wn["emb"], True)
     g.execute()
-    out = g.get_output(logits).reshape(S, -1)[S - 1].copy()
+    out = g.get_output(logits).reshape(-1).copy()
     cache.update_from_graph(g, k_nodes, v_nodes, S)
     g.soft_reset()
     return out
