@@ -1,5 +1,6 @@
 // Device-resident mirror of the reference's graph dispatch for the hot path (see graph.h).
 #include "graph.h"
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 
@@ -211,6 +212,20 @@ size_t CactusGraph::index(size_t input, size_t index_value, int dim) {   // grap
     OpParams p;
     p.axis = d; p.index_value = index_value; p.output_precision = in.precision;
     return add_node(OpType::INDEX, {input}, shape, p);
+}
+
+size_t CactusGraph::sample(size_t logits, float temperature, float top_p, size_t top_k, uint32_t random_seed) {
+    if (get_output_buffer(logits).shape.empty()) throw std::runtime_error("Sample requires non-empty logits tensor");
+    OpParams p;
+    p.temperature = temperature; p.top_p = top_p; p.top_k = top_k;
+    p.random_seed = random_seed ? random_seed
+                                : (uint32_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();
+    p.output_precision = Precision::FP32;
+    return add_node(OpType::SAMPLE, {logits}, {1}, p);
+}
+
+void CactusGraph::reset_sample_history() {
+    if (sample_state_) hip_check(hipMemset(sample_state_, 0, 132 * sizeof(uint32_t)), "hipMemset (sample history)");
 }
 
 size_t CactusGraph::embedding(size_t embedding_tensor, size_t indices) {   // graph_builder.cpp:524-539
@@ -660,6 +675,36 @@ void CactusGraph::compute_slice_node(GraphNode& n) {
                                count * inner, outer, hipMemcpyDeviceToDevice, nullptr), "slice copy");
 }
 
+// graph_ops_sample.cpp:8-39: the last row of the logits through cactus_sample_f16.
+void CactusGraph::compute_sample_node(GraphNode& n) {
+    const BufferDesc& lg = node(n.input_ids[0]).output_buffer;
+    if (lg.shape.size() != 2) throw std::runtime_error("Sample expects 2D logits tensor [seq_len, vocab_size]");
+    if (lg.precision != Precision::FP16) throw std::runtime_error("Sample supports FP16 logits on the device");
+    const size_t seq_len = lg.shape[0], vocab = lg.shape[1];
+    if (seq_len == 0) throw std::runtime_error("Sample requires non-empty logits tensor");
+    if (!sample_state_) {   // [0,128) history, [128] count, [129] draw, [130] status
+        sample_state_ = static_cast<uint32_t*>(dev_alloc(132 * sizeof(uint32_t)));
+        hip_check(hipMemset(sample_state_, 0, 132 * sizeof(uint32_t)), "hipMemset (sample state)");
+    }
+    if (sample_work_vocab_ < vocab) {
+        if (sample_work_) (void)hipFree(sample_work_);
+        sample_work_ = dev_alloc(vocab * sizeof(cactus_half_t));
+        sample_work_vocab_ = vocab;
+    }
+    const float draw = cactus_hip_sample_uniform(n.params.random_seed);
+    hip_check(hipMemcpy(sample_state_ + 129, &draw, sizeof draw, hipMemcpyHostToDevice), "hipMemcpy H2D (draw)");
+    hip_check(hipMemset(sample_state_ + 130, 0, sizeof(int)), "hipMemset (sample status)");
+    abi_check(cactus_hip_sample_f16_dev(static_cast<const cactus_half_t*>(lg.device_data) + (seq_len - 1) * vocab,
+                                        static_cast<uint32_t*>(n.output_buffer.device_data), 1, vocab,
+                                        n.params.temperature, n.params.top_p, n.params.top_k,
+                                        reinterpret_cast<const float*>(sample_state_ + 129), sample_state_,
+                                        sample_state_ + 128, static_cast<cactus_half_t*>(sample_work_),
+                                        reinterpret_cast<int*>(sample_state_ + 130), nullptr));
+    int status = 0;
+    hip_check(hipMemcpy(&status, sample_state_ + 130, sizeof status, hipMemcpyDeviceToHost), "hipMemcpy D2H (sample status)");
+    if (status != 0) throw std::runtime_error("Sample: more logits survive top-k than the device sampler holds");
+}
+
 // graph_ops_tensor.cpp:333-348
 void CactusGraph::compute_concat_node(GraphNode& n) {
     const BufferDesc& a = node(n.input_ids[0]).output_buffer;
@@ -882,6 +927,7 @@ void CactusGraph::execute() {
             case OpType::SCALAR_DIVIDE: compute_scalar_node(n); break;
             case OpType::SLICE: case OpType::INDEX: compute_slice_node(n); break;
             case OpType::CONCAT: compute_concat_node(n); break;
+            case OpType::SAMPLE: compute_sample_node(n); break;
             case OpType::MATMUL: compute_matmul_node(n); break;
             case OpType::ATTENTION: compute_attention_node(n); break;
             case OpType::ATTENTION_INT8_HYBRID: compute_attention_int8_hybrid_node(n); break;
@@ -942,6 +988,11 @@ void CactusGraph::hard_reset() {
     if (index_scratch_) (void)hipFree(index_scratch_);
     index_scratch_ = nullptr;
     index_scratch_count_ = 0;
+    if (sample_state_) (void)hipFree(sample_state_);
+    if (sample_work_) (void)hipFree(sample_work_);
+    sample_state_ = nullptr;
+    sample_work_ = nullptr;
+    sample_work_vocab_ = 0;
     next_node_id_ = 0;
 }
 
@@ -1263,6 +1314,12 @@ long cactus_hip_graph_concat(void* g, size_t input1, size_t input2, int axis) {
 }
 long cactus_hip_graph_index(void* g, size_t input, size_t index_value, int dim) {
     return guarded<long>(-1, [&] { return (long)G_(g)->index(input, index_value, dim); });
+}
+long cactus_hip_graph_sample(void* g, size_t logits, float temperature, float top_p, size_t top_k, uint32_t seed) {
+    return guarded<long>(-1, [&] { return (long)G_(g)->sample(logits, temperature, top_p, top_k, seed); });
+}
+int cactus_hip_graph_reset_sample_history(void* g) {
+    return guarded<int>(-1, [&] { G_(g)->reset_sample_history(); return 0; });
 }
 long cactus_hip_graph_embedding(void* g, size_t table, size_t indices) {
     return guarded<long>(-1, [&] { return (long)G_(g)->embedding(table, indices); });

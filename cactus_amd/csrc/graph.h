@@ -35,7 +35,7 @@ enum class OpType {
     ADD, ADD_CLIPPED, SUBTRACT, MULTIPLY, DIVIDE, SILU, GELU, RMS_NORM, ROPE, RESHAPE, EMBEDDING,
     CONV1D_CAUSAL,   // LFM2's short convolution
     SCALAR_ADD, SCALAR_SUBTRACT, SCALAR_MULTIPLY, SCALAR_DIVIDE,
-    SLICE, CONCAT, INDEX
+    SLICE, CONCAT, INDEX, SAMPLE
 };
 
 size_t precision_size(Precision p);   // bytes per element (INT4 counted as 1, graph.h:128-136)
@@ -80,6 +80,9 @@ struct OpParams {
     float scalar = 0.0f;     // SCALAR_*
     int axis = 0;            // SLICE, CONCAT, INDEX
     size_t slice_start = 0, slice_length = 0, index_value = 0;
+    float temperature = 0.0f, top_p = 0.0f;   // SAMPLE
+    size_t top_k = 0;
+    uint32_t random_seed = 0;
     size_t window_size = 0;
     bool is_causal = true;
     Precision output_precision = Precision::INT8;
@@ -146,6 +149,12 @@ public:
     size_t slice(size_t input, int axis, size_t start, size_t length);
     size_t concat(size_t input1, size_t input2, int axis = 0);
     size_t index(size_t input, size_t index_value, int dim);
+    // graph.h:446; graph_builder.cpp:396-420.  One token (uint32 in an FP32-sized node) from the last row of
+    // logits [seq_len, vocab].  The reference seeds its generator from the clock per node; here the seed is an
+    // argument (0: the clock) and the history of sampled tokens belongs to the graph, not the process.  The
+    // logit bias the reference accepts never changes its result and is not taken.
+    size_t sample(size_t logits, float temperature, float top_p, size_t top_k, uint32_t random_seed = 0);
+    void reset_sample_history();
     size_t rms_norm(size_t input, size_t weight, float epsilon = 1e-5f);
     size_t rope(size_t input, float theta, size_t position_offset = 0,
                 ComputeBackend backend = ComputeBackend::HIP);
@@ -203,6 +212,7 @@ private:
     void compute_scalar_node(GraphNode& n);
     void compute_slice_node(GraphNode& n);     // SLICE and INDEX
     void compute_concat_node(GraphNode& n);
+    void compute_sample_node(GraphNode& n);
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;
@@ -217,6 +227,10 @@ private:
     std::unordered_map<std::string, size_t> weight_cache_;   // file name -> node id
     int32_t* index_scratch_ = nullptr;   // int32 copy of an EMBEDDING node's indices + one flag word
     size_t index_scratch_count_ = 0;
+    // SAMPLE: device history uint32[128], its count, the draw, the status word; workspace half[vocab]
+    uint32_t* sample_state_ = nullptr;
+    void* sample_work_ = nullptr;
+    size_t sample_work_vocab_ = 0;
 };
 
 // Header of a CACT tensor file (graph_io.cpp:11-16, 497-566): 80 bytes, little endian: magic

@@ -30,6 +30,8 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_slice": (_l, [_vp, _sz, _i, _sz, _sz]),
     "cactus_hip_graph_concat": (_l, [_vp, _sz, _sz, _i]),
     "cactus_hip_graph_index": (_l, [_vp, _sz, _sz, _i]),
+    "cactus_hip_graph_sample": (_l, [_vp, _sz, _f, _f, _sz, C.c_uint32]),
+    "cactus_hip_graph_reset_sample_history": (_i, [_vp]),
     "cactus_hip_graph_embedding": (_l, [_vp, _sz, _sz]),
     "cactus_hip_graph_rms_norm": (_l, [_vp, _sz, _sz, _f]),
     "cactus_hip_graph_rope": (_l, [_vp, _sz, _f, _sz]),
@@ -186,6 +188,16 @@ class CactusGraph:
         del shp[d]
         self._shapes[n] = (tuple(shp) or (1,), self._shapes[x][1])
         return n
+
+    def sample(self, logits, temperature, top_p, top_k, random_seed=0):
+        """One token from the last logits row; get_output gives a float32-typed [1] array whose bits are
+        the uint32 token (use .view(np.uint32))."""
+        n = _node(lib.cactus_hip_graph_sample(self._g, logits, temperature, top_p, top_k, random_seed))
+        self._shapes[n] = ((1,), FP32)
+        return n
+
+    def reset_sample_history(self):
+        _ok(lib.cactus_hip_graph_reset_sample_history(self._g))
 
     def embedding(self, table, indices):
         n = _node(lib.cactus_hip_graph_embedding(self._g, table, indices))

@@ -55,6 +55,12 @@ long   cactus_hip_graph_reshape(void* graph, size_t input, const size_t* shape, 
 long   cactus_hip_graph_slice(void* graph, size_t input, int axis, size_t start, size_t length);
 long   cactus_hip_graph_concat(void* graph, size_t input1, size_t input2, int axis);
 long   cactus_hip_graph_index(void* graph, size_t input, size_t index_value, int dim);
+/* CactusGraph::sample (graph.h:446; graph_ops_sample.cpp:8-39): one token from the last row of FP16 logits
+ * [seq_len, vocab]; read it with cactus_hip_graph_get_output (4 bytes, uint32).  random_seed 0: the clock, as
+ * the reference seeds every node.  The history of sampled tokens (repetition penalty) is kept per graph. */
+long   cactus_hip_graph_sample(void* graph, size_t logits, float temperature, float top_p, size_t top_k,
+                               uint32_t random_seed);
+int    cactus_hip_graph_reset_sample_history(void* graph);
 long   cactus_hip_graph_embedding(void* graph, size_t table, size_t indices);
 long   cactus_hip_graph_rms_norm(void* graph, size_t input, size_t weight, float epsilon);
 long   cactus_hip_graph_rope(void* graph, size_t input, float theta, size_t position_offset);

@@ -153,3 +153,48 @@ def test_logits_entropy_matches_oracle(H, rows, vocab):
     for r in range(rows):
         assert got[r] == pytest.approx(O.logits_entropy(x[r]), rel=1e-6, abs=1e-7), r
     assert got[0] == pytest.approx(1.0, rel=1e-6)
+
+
+def test_graph_sample_node(H):
+    """CactusGraph::sample (graph_builder.cpp:396-420, graph_ops_sample.cpp:8-39): one token from the
+    last logits row, the draw taken from the node's seed, the token history carried by the graph from
+    step to step; against the oracle with the same draws and history."""
+    import cactus_amd.graph as G
+    rng = np.random.default_rng(77)
+    vocab = 32000
+    g = G.CactusGraph()
+    history = []
+    for step in range(6):
+        x = logits_rows(rng, 3, vocab, "normal")
+        if history:
+            x[2, history[-1]] = np.float16(12.0)     # the last token again: the repetition penalty must act
+        n = g.input(x.shape, G.FP16)
+        tok = g.sample(n, 0.7, 0.9, 20, random_seed=1000 + step)
+        g.set_input(n, x)
+        g.execute()
+        got = int(g.get_output(tok).view(np.uint32)[0])
+        want, history = O.sample(x[2], 0.7, 0.9, 20, O.sample_uniform(1000 + step), history)
+        assert got == want, step
+        g.soft_reset()
+    # greedy parameters: the first maximum of the last row, no history update
+    x = logits_rows(rng, 2, vocab, "ties")
+    n = g.input(x.shape, G.FP16)
+    tok = g.sample(n, 0.0, 0.0, 0, random_seed=5)
+    g.set_input(n, x)
+    g.execute()
+    assert int(g.get_output(tok).view(np.uint32)[0]) == int(O.sample_greedy(x[1:2])[0])
+    g.soft_reset()
+    # a cleared history samples like a fresh process
+    g.reset_sample_history()
+    x = logits_rows(rng, 1, vocab, "normal")
+    n = g.input(x.shape, G.FP16)
+    tok = g.sample(n, 0.7, 0.9, 20, random_seed=9)
+    g.set_input(n, x)
+    g.execute()
+    assert int(g.get_output(tok).view(np.uint32)[0]) == O.sample(x[0], 0.7, 0.9, 20, O.sample_uniform(9), [])[0]
+    bad = g.input((vocab,), G.FP16)
+    g.sample(bad, 0.7, 0.9, 20, 1)
+    g.set_input(bad, x[0])
+    with pytest.raises(Exception, match="2D logits"):
+        g.execute()
+    g.close()
