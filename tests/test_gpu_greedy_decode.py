@@ -308,3 +308,156 @@ def test_gemma3_270m_shape_greedy_64_tokens(G):
     assert cache.get_total_seq_len() == 6 + 63 and near_ties <= 2
     g.close()
     cache.close()
+
+
+# ---------------------------------------------------------------------------- LFM2-1.2B shape
+# models/model_lfm2.cpp:123-331: blocks with the short convolution (in-projection to [L, 3, C], B * X,
+# the ConvCache rows in front, 3-tap causal depthwise convolution, C gate, out-projection) or with
+# attention (per-head q/k norms, RoPE, INT8 KV cache), each followed by the SwiGLU MLP.  Dimensions
+# from the public model card (hidden 2048, ffn 8192, 32 q / 8 kv heads of 64, vocabulary 65536,
+# conv_L_cache 3, eps 1e-5), all 16 blocks with attention in blocks 2, 5, 8, 10, 12, 14.
+LFM = dict(HID=2048, HQ=32, HKV=8, D=64, FF=8192, VOCAB=65536, EPS=1e-5, THETA=1e6, K=3, W=2,
+           TYPES="ccaccaccacacacac")
+
+
+def lfm2_model(rng, gain):
+    c = LFM
+
+    def mat(n, k, g):
+        B, Bs = rand_weights_int8(rng, n, k)
+        return B, (Bs.astype(np.float32) * g).astype(np.float16)
+    layers = []
+    for t in c["TYPES"]:
+        L = {"gate": mat(c["FF"], c["HID"], gain), "up": mat(c["FF"], c["HID"], gain), "down": mat(c["HID"], c["FF"], gain),
+             "in_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16),
+             "post_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
+        if t == "a":
+            L.update(q=mat(c["HQ"] * c["D"], c["HID"], gain), k=mat(c["HKV"] * c["D"], c["HID"], gain),
+                     v=mat(c["HKV"] * c["D"], c["HID"], gain), o=mat(c["HID"], c["HQ"] * c["D"], gain),
+                     q_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16),
+                     k_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16))
+        else:
+            L.update(in_proj=mat(3 * c["HID"], c["HID"], gain), out_proj=mat(c["HID"], c["HID"], gain),
+                     conv_w=(rng.standard_normal((c["HID"], 1, c["K"])) * 0.5).astype(np.float16))
+        layers.append(L)
+    return {"layers": layers, "emb": mat(c["VOCAB"], c["HID"], 1.0),
+            "final_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
+
+
+def lfm2_oracle_forward(m, tokens, pos, kv, conv):
+    c = LFM
+    S, Hq, Hkv, Dh, eps = len(tokens), c["HQ"], c["HKV"], c["D"], c["EPS"]
+    h = O.embedding(m["emb"][0], np.asarray(tokens, np.int32), m["emb"][1].view(np.uint16), 128)
+    for li, L in enumerate(m["layers"]):
+        n1 = O.rms_norm(h, L["in_norm"], eps)
+        if "q" in L:
+            q = O.rms_norm(omm(n1, L["q"]).reshape(S * Hq, Dh), L["q_norm"], eps).reshape(1, S, Hq, Dh)
+            k = O.rms_norm(omm(n1, L["k"]).reshape(S * Hkv, Dh), L["k_norm"], eps).reshape(1, S, Hkv, Dh)
+            v = omm(n1, L["v"]).reshape(1, S, Hkv, Dh)
+            q, k = O.rope(q, c["THETA"], pos), O.rope(k, c["THETA"], pos)
+            scale = 1.0 / np.sqrt(Dh)
+            if kv[li] is None:
+                attn = O.attention_f16(q, k, v, scale, position_offset=pos)
+            else:
+                kq, ks, vq, vs = kv[li]
+                attn = O.attention_hybrid(q, kq[None], vq[None], ks[None], vs[None], k, v, scale, position_offset=pos)
+            new = O.quantize_kv(k.reshape(S, Hkv, Dh)) + O.quantize_kv(v.reshape(S, Hkv, Dh))
+            kv[li] = list(new) if kv[li] is None else [np.concatenate([a, b]) for a, b in zip(kv[li], new)]
+            block = omm(attn.reshape(S, Hq * Dh), L["o"])
+        else:
+            gated = O.lfm2_conv_gate(omm(n1, L["in_proj"]), L["conv_w"].reshape(c["HID"], c["K"]), conv[li])
+            block = omm(gated, L["out_proj"])
+        h = O.binary("add", h, block)
+        n2 = O.rms_norm(h, L["post_norm"], eps)
+        act = O.binary("multiply", O.silu(omm(n2, L["gate"])), omm(n2, L["up"]))
+        h = O.binary("add", h, omm(act, L["down"]))
+    return omm(O.rms_norm(h[S - 1:S], m["final_norm"], eps), m["emb"])[0]
+
+
+def lfm2_graph_forward(G, g, wn, m, tokens, pos, cache, windows):
+    """The node sequence of LFM2Model::forward; `windows` holds each conv block's ConvCache rows on
+    the host (oldest first), fed back as input nodes the way the reference feeds its circular views."""
+    c = LFM
+    S, Hq, Hkv, Dh, eps, C_, K_, W_ = len(tokens), c["HQ"], c["HKV"], c["D"], c["EPS"], c["HID"], c["K"], c["W"]
+    idx = g.input((S,), G.FP32)
+    g.set_input(idx, np.asarray(tokens, np.float32))
+    h = g.embedding(wn["emb"], idx)
+    k_nodes, v_nodes, bx_nodes = [], [], {}
+    ai = 0
+    for li, L in enumerate(wn["layers"]):
+        n1 = g.rms_norm(h, L["in_norm"], eps)
+        if "q" in L:
+            q, k, v = (g.matmul(n1, L[name], True) for name in ("q", "k", "v"))
+            q = g.reshape(g.rms_norm(g.reshape(q, (S * Hq, Dh)), L["q_norm"], eps), (1, S, Hq, Dh))
+            k = g.reshape(g.rms_norm(g.reshape(k, (S * Hkv, Dh)), L["k_norm"], eps), (1, S, Hkv, Dh))
+            v = g.reshape(v, (1, S, Hkv, Dh))
+            q, k = g.rope(q, c["THETA"], pos), g.rope(k, c["THETA"], pos)
+            k_nodes.append(k)
+            v_nodes.append(v)
+            scale = 1.0 / np.sqrt(Dh)
+            if cache.is_empty():
+                attn = g.attention(q, k, v, scale, pos)
+            else:
+                attn = g.attention_int8_hybrid(q, k, v, scale, pos, cache.get_keys_int8(ai), cache.get_values_int8(ai),
+                                               cache.get_key_scales(ai), cache.get_value_scales(ai),
+                                               cache.get_effective_seq_len(), Hkv, Dh)
+            ai += 1
+            block = g.matmul(g.reshape(attn, (S, Hq * Dh)), L["o"], True)
+        else:
+            trip = g.reshape(g.matmul(n1, L["in_proj"], True), (S, 3, C_))
+            Bn, Cg, X = (g.reshape(g.slice(trip, 1, i, 1), (S, C_)) for i in range(3))
+            bx = g.multiply(Bn, X)
+            bx_nodes[li] = bx
+            conv_in, total = bx, S
+            if len(windows[li]):
+                wnode = g.input(windows[li].shape, G.FP16)
+                g.set_input(wnode, windows[li])
+                conv_in, total = g.concat(wnode, bx, 0), S + len(windows[li])
+            y = g.conv1d_causal(g.reshape(conv_in, (1, total, C_)), L["conv_w"], K_, 1)
+            y = g.reshape(g.slice(y, 1, total - S, S), (S, C_))
+            block = g.matmul(g.multiply(Cg, y), L["out_proj"], True)
+        h = g.add(h, block)
+        n2 = g.rms_norm(h, L["post_norm"], eps)
+        act = g.multiply(g.silu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
+        h = g.add(h, g.matmul(act, L["down"], True))
+    last = g.reshape(g.index(g.rms_norm(h, wn["final_norm"], eps), S - 1, 0), (1, C_))
+    logits = g.matmul(last, wn["emb"], True)
+    g.execute()
+    out = g.get_output(logits).reshape(-1).copy()
+    cache.update_from_graph(g, k_nodes, v_nodes, S)
+    for li, bx in bx_nodes.items():                                   # ConvCache::update
+        windows[li] = np.concatenate([windows[li], g.get_output(bx)])[-W_:]
+    g.soft_reset()
+    return out
+
+
+def test_lfm2_shape_greedy_tokens(G):
+    import cactus_amd.hip as H
+    c = LFM
+    rng = np.random.default_rng(21)
+    m = lfm2_model(rng, 0.008)
+    prompt = rng.integers(0, c["VOCAB"], 7).tolist()
+    g = G.CactusGraph()
+    wn = bind(G, g, m)
+    n_attn = c["TYPES"].count("a")
+    cache = G.KVCache(n_attn, 2048, c["HKV"], c["D"])
+    kv = [None] * len(c["TYPES"])
+    conv = [O.Lfm2ConvState(c["W"], c["HID"]) for _ in c["TYPES"]]
+    windows = [np.zeros((0, c["HID"]), np.float16) for _ in c["TYPES"]]
+    toks, feed, pos = [], prompt, 0
+    for step in range(12):
+        lg_d = lfm2_graph_forward(G, g, wn, m, feed, pos, cache, windows)
+        lg_o = lfm2_oracle_forward(m, feed, pos, kv, conv).view(np.float16)
+        ref = lg_o.astype(np.float64)
+        err = np.abs(lg_d.astype(np.float64) - ref).max()
+        assert err <= 2e-2 + 2e-2 * np.abs(ref).max(), (step, err, np.abs(ref).max())
+        td = int(H.sample_greedy(torch.from_numpy(lg_d[None].copy()).cuda()).cpu()[0])
+        to = int(O.sample_greedy(lg_o[None])[0])
+        assert td == to, (step, toks, td, to, np.sort(ref)[-2:])
+        toks.append(td)
+        pos += len(feed)
+        # a synthetic model soon repeats one token: continue from a fresh seeded one when it does
+        feed = [td] if toks.count(td) == 1 else [int(rng.integers(0, c["VOCAB"]))]
+    assert cache.get_total_seq_len() == 7 + 11
+    g.close()
+    cache.close()
