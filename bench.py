@@ -325,7 +325,7 @@ def sharded_decode(H, gen, world):
     return out
 
 
-def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
+def qwen3_decode_step(H, gen, batch, cache_len, layers=28, mixed=False):
     """One decode step of the Qwen3-0.6B op sequence (hidden 1024, 16 q / 8 kv heads of 128, ffn
     3072, vocab 151936: cactus/engine/engine.h:44-59; op order model_qwen.cpp:51-129, 169-172):
     per layer input norm, q/k/v projections, per-head q/k norms, RoPE, attention over the INT8
@@ -336,11 +336,16 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
     the device -- with the back-to-back small ops going out as the library's one-launch
     sequences (add + norm, q/k norm + RoPE, SiLU x up, K + V quantization).  The embedding lookup and the sampler are outside the timed step.  Synthetic
     INT8 weights, distinct per layer (596 MB in total, streamed from HBM every step); the whole
-    step is one HIP graph."""
+    step is one HIP graph.  mixed (batches above 4): the converter's MIXED policy for a model of this
+    size (python/src/precision_config.py:52-68, 110-124): INT8 for the embedding / lm_head, attn_q,
+    attn_k and the first and last two blocks, packed INT4 for attn_v, attn_output and the MLP elsewhere."""
     Hd, Hq, Hkv, D, F, V = 1024, 16, 8, 128, 3072, 151936
-    mk = lambda N, K: make_weights(K, N, False, gen)
-    Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), gate=mk(F, Hd),
-               up=mk(F, Hd), down=mk(Hd, F)) for _ in range(layers)]
+    if mixed and batch <= 4:
+        raise ValueError("the mixed-precision step is written for batches above 4")
+    is4 = lambda li: mixed and 2 <= li < layers - 2
+    mk = lambda N, K, i4=False: make_weights(K, N, i4, gen)
+    Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd, is4(li)), o=mk(Hd, Hq * D, is4(li)),
+               gate=mk(F, Hd, is4(li)), up=mk(F, Hd, is4(li)), down=mk(Hd, F, is4(li))) for li in range(layers)]
     head = mk(V, Hd)
     nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
     for L in Ls:
@@ -381,13 +386,16 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
         head_p = H.MatmulProduced([(head[0], head[1], logits)], 128)
     shared = []
     if batch > 4:
-        for L in Ls:
-            shared.append((H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko),
-                                           (L["v"][0], L["v"][1], vo)], 128),
-                           H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128)))
+        for li, L in enumerate(Ls):
+            qkv = [(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko)]
+            if not is4(li):
+                qkv.append((L["v"][0], L["v"][1], vo))
+            shared.append((H.MatmulShared(qkv, 128),
+                           H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128,
+                                          int4=is4(li))))
 
-    def proj(inp, w, out):
-        H.matmul_f16act(inp, w[0], w[1], 128, out=out)
+    def proj(inp, w, out, int4=False):
+        H.matmul_f16act(inp, w[0], w[1], 128, int4=int4, out=out)
 
     def step():
         H.embedding(head[0], tok, head[1], 128, out=h0, check=False)
@@ -406,6 +414,8 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                     res = hid
             else:
                 shared[li][0].run(xq, xs)      # quantized by the norm launch that produced it
+                if is4(li):
+                    H.matmul_int4(xq, xs, L["v"][0], L["v"][1], 128, out=vo)
             # q/k norm + RoPE, and the new token's K and V join the cache (slot cache_len of every
             # sequence; the attention of this step reads them as FP16), one launch
             H.qk_norm_rope_kv_append(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D),
@@ -413,7 +423,7 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                                      128, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
             a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
                                            kr.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
-            proj(a.view(batch, Hq * D), L["o"], oo)
+            proj(a.view(batch, Hq * D), L["o"], oo, is4(li))
             nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
             if batch <= 4:
                 produced[li][1].run_norm(res, oo, L["post_norm"], eps, h2)   # add + norm + gate/up
@@ -422,7 +432,7 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
                 H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
                 shared[li][1].run(xq2, xs2)
                 H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
-                H.matmul_int8(aq, asc, L["down"][0], L["down"][1], 128, out=do)
+                (H.matmul_int4 if is4(li) else H.matmul_int8)(aq, asc, L["down"][0], L["down"][1], 128, out=do)
                 last = li + 1 == layers   # the lm_head below takes the FP16 row
                 H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq,
                                      out_scales=xs)
@@ -447,12 +457,15 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
-    wbytes = layers * sum(gemv_bytes(batch, K, N) for N, K in ((Hq * D, Hd), (Hkv * D, Hd), (Hkv * D, Hd), (Hd, Hq * D),
-                                                                  (F, Hd), (F, Hd), (Hd, F))) + gemv_bytes(batch, Hd, V)
+    wbytes = gemv_bytes(batch, Hd, V)
+    for li in range(layers):
+        wbytes += sum(gemv_bytes(batch, K, N) for N, K in ((Hq * D, Hd), (Hkv * D, Hd)))
+        wbytes += sum(gemv_bytes(batch, K, N, is4(li)) for N, K in ((Hkv * D, Hd), (Hd, Hq * D), (F, Hd), (F, Hd), (Hd, F)))
     kvbytes = layers * batch * 2 * cache_len * Hkv * (D + 4)
     return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
             "cache_len": cache_len, "GBps": round((wbytes + kvbytes) / (ms * 1e-3) / 1e9, 1),
-            "note": "a whole Qwen3-0.6B decode step: embedding lookup to greedy sampler, token ids stay on the device"}
+            "note": "a whole Qwen3-0.6B decode step: embedding lookup to greedy sampler, token ids stay on the device"
+                    + ("; MIXED precision policy (INT4 attn_v / attn_output / MLP in blocks 2..25)" if mixed else "")}
 
 
 def lfm2_decode_step(H, gen, batch, cache_len):
@@ -776,7 +789,8 @@ def extra_table(H, gen, big):
     ex["qwen3_0p6b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256)}
     torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
-                                       "b256_c512": qwen3_decode_step(H, gen, 256, 512)}
+                                       "b256_c512": qwen3_decode_step(H, gen, 256, 512),
+                                       "b256_c512_mixed_int4": qwen3_decode_step(H, gen, 256, 512, mixed=True)}
     torch.cuda.empty_cache()
     # config 4 (1024 independent LFM2-1.2B sequences sharded over the GPUs of a node): what one GPU
     # runs at 8 GPUs (128 sequences) and at 1 GPU (1024)
