@@ -254,3 +254,19 @@ def test_graph_lfm2_conv_block_as_the_reference_builds_it(H):
         window = np.concatenate([window, g.get_output(bx)])[-W:]
         g.soft_reset()
     g.close()
+
+
+def test_lfm2_conv_gate_empty_and_invalid(H):
+    C, K, W = 16, 3, 2
+    w = dev(np.ones((C, K), np.float16))
+    state = torch.zeros((1, W, C), dtype=torch.float16, device="cuda")
+    empty = torch.empty((1, 0, 3 * C), dtype=torch.float16, device="cuda")
+    assert H.lfm2_conv_gate(empty, w, state).numel() == 0              # no rows: nothing launched
+    assert float(state.abs().sum()) == 0.0
+    ip = dev(np.ones((1, 2, 3 * C), np.float16))
+    out = torch.empty((1, 2, C), dtype=torch.float16, device="cuda")
+    rc = H.lib.cactus_hip_lfm2_conv_gate_f16_dev(ip.data_ptr(), w.data_ptr(), None, out.data_ptr(), 1, 2, C, K, W, None)
+    assert rc != 0 and b"null operand" in H.lib.cactus_hip_last_error()   # carried rows asked for, no state given
+    rc = H.lib.cactus_hip_lfm2_conv_gate_f16_dev(ip.data_ptr(), w.data_ptr(), state.data_ptr(), out.data_ptr(), 1, 2, C, 0, W,
+                                                 None)
+    assert rc != 0

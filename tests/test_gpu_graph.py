@@ -580,3 +580,40 @@ def test_mmap_weights_errors(G, tmp_path):
     with pytest.raises(G.CactusHipError, match="missing CACT magic"):
         g.mmap_weights(bad)
     g.close()
+
+
+def test_ring_whole_sequence_update_restarts_the_ring(G):
+    """A whole-sequence update of a ring cache rewrites the window in temporal order (ring head 0);
+    appends after it wrap again."""
+    rng = np.random.default_rng(6)
+    Hkv, D, W, sink = 2, 64, 16, 2
+    cache = G.KVCache(1, 2048, Hkv, D)
+    cache.set_window_size(W, sink)
+    cache.set_ring(True)
+    g = G.CactusGraph()
+    k = rng.normal(0, 1, (40, Hkv, D)).astype(np.float16)
+    v = rng.normal(0, 1, (40, Hkv, D)).astype(np.float16)
+    _fill_cache(G, g, cache, [k[:10]], [v[:10]])
+    g.soft_reset()
+    _fill_cache(G, g, cache, [k[10:19]], [v[10:19]])          # fills and wraps: 19 tokens into 16 slots
+    assert cache.ring_head() == 3
+    g.soft_reset()
+    # whole-sequence node: the 16 tokens held (temporal order) followed by 11 new ones
+    held = np.concatenate([np.arange(sink), np.arange(19 - (W - sink), 19)])
+    allk = np.concatenate([k[held], k[19:30]])
+    allv = np.concatenate([v[held], v[19:30]])
+    _fill_cache(G, g, cache, [allk], [allv], seq_len=11)
+    assert cache.ring_head() == 0 and cache.get_total_seq_len() == 30
+    kq, ks, _, _ = cache.download(0)
+    okq, oks = O.quantize_kv(np.concatenate([k[:sink], k[30 - (W - sink):30]]))
+    assert (kq == okq).all() and (ks == oks).all()
+    g.soft_reset()
+    _fill_cache(G, g, cache, [k[30:35]], [v[30:35]])
+    assert cache.ring_head() == 5
+    kq, ks, _, _ = cache.download(0)
+    R = W - sink
+    order = np.concatenate([np.arange(sink), sink + (5 + np.arange(R)) % R])
+    okq, oks = O.quantize_kv(np.concatenate([k[:sink], k[35 - R:35]]))
+    assert (kq[order] == okq).all() and (ks[order] == oks).all()
+    g.close()
+    cache.close()
