@@ -509,6 +509,7 @@ def lfm2_decode_step(H, gen, batch, cache_len):
     i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
     f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
     xq, xs, xq2, xs2, aq, asc = i8(batch, Hd), f32(batch), i8(batch, Hd), f32(batch), i8(batch, F), f32(batch)
+    cq, cs = i8(batch, Hd), f32(batch)
     for L in Ls:
         if L["attn"]:
             L["qkv"] = H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko), (L["v"][0], L["v"][1], vo)], 128)
@@ -530,8 +531,10 @@ def lfm2_decode_step(H, gen, batch, cache_len):
                 ai += 1
             else:
                 H.matmul_int8(xq, xs, L["in_proj"][0], L["in_proj"][1], 128, out=ipj)
-                H.lfm2_conv_gate(ipj.view(batch, 1, 3 * Hd), L["conv_w"], L["state"], out=gated.view(batch, 1, Hd))
-                H.matmul_f16act(gated, L["out_proj"][0], L["out_proj"][1], 128, out=oo)
+                # B * X, convolution over the carried rows, C gate, state update and the out-projection's
+                # row quantization, one launch
+                H.lfm2_conv_gate_quant(ipj.view(batch, 1, 3 * Hd), L["conv_w"], L["state"], out_q=cq, out_scales=cs)
+                H.matmul_int8(cq, cs, L["out_proj"][0], L["out_proj"][1], 128, out=oo)
             H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
             L["gu"].run(xq2, xs2)
             H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)

@@ -703,6 +703,21 @@ int cactus_hip_lfm2_conv_gate_f16_dev(const cactus_half_t* in_proj, const cactus
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "lfm2_conv_gate launch", e);
     return CACTUS_HIP_OK;
 }
+int cactus_hip_lfm2_conv_gate_quant_f16_dev(const cactus_half_t* in_proj, const cactus_half_t* weight,
+                                            cactus_half_t* state, cactus_half_t* gated, int8_t* q_output,
+                                            float* scales_output, size_t num_seqs, size_t L, size_t C, size_t K,
+                                            size_t W, void* stream) {
+    if (num_seqs == 0 || L == 0 || C == 0) return CACTUS_HIP_OK;
+    if (!in_proj || !weight || !q_output || !scales_output || (W > 0 && !state))
+        return fail(CACTUS_HIP_EINVAL, "lfm2_conv_gate_quant: null operand");
+    if (!lfm2_conv_gate_quant_ok(C, K))
+        return fail(CACTUS_HIP_EINVAL, "lfm2_conv_gate_quant: C must be a multiple of 512 up to 2048 and K 2..4");
+    if (num_seqs > 65535) return fail(CACTUS_HIP_EINVAL, "lfm2_conv_gate_quant: more than 65535 sequences per call");
+    hipError_t e = launch_lfm2_conv_gate_quant(in_proj, weight, state, gated, q_output, scales_output, num_seqs, L, C,
+                                               K, W, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "lfm2_conv_gate_quant launch", e);
+    return CACTUS_HIP_OK;
+}
 int cactus_hip_scalar_op_f16_dev(const cactus_half_t* input, cactus_half_t* output, size_t num_elements,
                                  float scalar_value, int op_type, void* stream) {
     if (op_type < 0 || op_type > 3)

@@ -90,13 +90,20 @@ __global__ __launch_bounds__(256) void conv1d_causal_dw_kernel(const uint16_t* _
 // chunk at least K - 1 rows, so later chunks reach back only into this call's rows); 2: state only.
 // KT: the tap count when it is 2, 3 or 4 (weights and the last KT - 1 rows stay in registers, a row
 // of the in-projection is read once per chunk), 0 for any other K.
-template <int VEC, int KT>
+// QUANT (VEC 8, KT > 0, one workgroup of C / 8 threads -- whole waves -- per row chunk): every gated row is
+// also quantized for the out-projection the way quantize_activations_fp16_to_int8 does it
+// (graph_ops_nn.cpp:35-66: scale = max(absmax / 127, 1e-10), q = sat8(rne(clamp(x * (1 / scale))))), into
+// q_out int8 [rows, C] and scales_out float [rows]; gated may then be null.
+template <int VEC, int KT, bool QUANT = false>
 __global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __restrict__ in_proj,
                                                              const uint16_t* __restrict__ w,
                                                              uint16_t* __restrict__ state,
                                                              uint16_t* __restrict__ gated, size_t L, size_t C,
-                                                             size_t K, size_t W, size_t rows_per_chunk, int mode) {
-    const size_t cv = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                             size_t K, size_t W, size_t rows_per_chunk, int mode,
+                                                             int8_t* __restrict__ q_out = nullptr,
+                                                             float* __restrict__ scales_out = nullptr) {
+    __shared__ float q_red[2][4];
+    const size_t cv = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cv * VEC >= C) return;
     const size_t c0 = cv * VEC, n = blockIdx.z;
     const uint16_t* ip = in_proj + n * L * 3 * C + c0;
@@ -166,8 +173,35 @@ __global__ __launch_bounds__(256) void lfm2_conv_gate_kernel(const uint16_t* __r
                 for (int e = 0; e < VEC; e++) hist[KT - 2][e] = cur[e];
             }
             uint16_t* g = gated + (n * L + t) * C + c0;
-            if (VEC == 8) *reinterpret_cast<v4i*>(g) = *reinterpret_cast<const v4i*>(o);
-            else g[0] = o[0];
+            if (!QUANT || gated != nullptr) {
+                if (VEC == 8) *reinterpret_cast<v4i*>(g) = *reinterpret_cast<const v4i*>(o);
+                else g[0] = o[0];
+            }
+            if constexpr (QUANT) {
+                // the block holds the whole row: absmax over its waves (two LDS rows alternate, one barrier per row)
+                float m = 0.0f;
+#pragma unroll
+                for (int e = 0; e < VEC; e++) m = fmaxf(m, fabsf(h2f(o[e])));
+                m = wave_max(m);
+                float* red = q_red[t & 1];
+                if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+                __syncthreads();
+                const int nw = (int)(blockDim.x >> 6);
+                m = red[0];
+                for (int i = 1; i < nw; i++) m = fmaxf(m, red[i]);
+                float scale = m / 127.0f;
+                if (scale < 1e-10f) scale = 1e-10f;
+                const float inv = 1.0f / scale;
+                uint32_t packed[2] = {0, 0};
+#pragma unroll
+                for (int e = 0; e < VEC; e++) {
+                    float q = h2f(o[e]) * inv;
+                    q = fmaxf(fminf(q, 127.0f), -128.0f);
+                    packed[(e >> 2) & 1] |= (uint32_t)(clamp_i8(rne_i32(q)) & 0xFF) << (8 * (e & 3));
+                }
+                *reinterpret_cast<uint2*>(q_out + (n * L + t) * C + c0) = make_uint2(packed[0], packed[1]);
+                if (threadIdx.x == 0) scales_out[n * L + t] = scale;
+            }
         }
     }
     if (mode != 2 && KT == 0) {
@@ -238,6 +272,32 @@ hipError_t launch_conv1d_causal_depthwise(const uint16_t* x, const uint16_t* w, 
     const size_t blocks = (total + 255) / 256;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     conv1d_causal_dw_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(x, w, y, total, L, C, K, dilation);
+    return hipGetLastError();
+}
+
+bool lfm2_conv_gate_quant_ok(size_t C, size_t K) { return C % 512 == 0 && C <= 2048 && K >= 2 && K <= 4; }
+
+hipError_t launch_lfm2_conv_gate_quant(const uint16_t* in_proj, const uint16_t* w, uint16_t* state, uint16_t* gated,
+                                       int8_t* q_out, float* scales_out, size_t nseq, size_t L, size_t C, size_t K,
+                                       size_t W, hipStream_t st) {
+    if (nseq == 0 || L == 0) return hipSuccess;
+    if (!lfm2_conv_gate_quant_ok(C, K) || nseq > 65535) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(in_proj) | reinterpret_cast<uintptr_t>(state) | reinterpret_cast<uintptr_t>(gated) |
+         reinterpret_cast<uintptr_t>(q_out)) & 15)
+        return hipErrorInvalidValue;
+    const size_t threads = C / 8;
+    size_t rpc = L;
+    while (rpc > 4 && nseq * threads * ((L + rpc - 1) / rpc) < 131072) rpc = (rpc + 1) / 2;
+    if (rpc + 1 < K) rpc = K - 1 < L ? K - 1 : L;
+    const size_t chunks = (L + rpc - 1) / rpc;
+    if (chunks > 65535) return hipErrorInvalidValue;
+    const dim3 grid(1, (unsigned)chunks, (unsigned)nseq), block((unsigned)threads);
+    const int mode = W > 0 ? 1 : 0;
+#define CACTUS_CONV_GOQ(T) lfm2_conv_gate_kernel<8, T, true><<<grid, block, 0, st>>>(in_proj, w, state, gated, L, C, K, W, rpc, mode, q_out, scales_out)
+    if (K == 2) CACTUS_CONV_GOQ(2);
+    else if (K == 3) CACTUS_CONV_GOQ(3);
+    else CACTUS_CONV_GOQ(4);
+#undef CACTUS_CONV_GOQ
     return hipGetLastError();
 }
 

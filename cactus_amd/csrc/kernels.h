@@ -178,6 +178,11 @@ hipError_t launch_embedding_f16(const uint16_t* emb, const int32_t* indices, uin
 // (B * X, convolution over the carried state rows and the new rows, C-gate product, state update)
 hipError_t launch_conv1d_causal_depthwise(const uint16_t* x, const uint16_t* w, uint16_t* y, size_t N, size_t L,
                                           size_t C, size_t K, size_t dilation, hipStream_t st);
+// the same launch also quantizes every gated row for the out-projection (C a multiple of 512 up to 2048, 2..4 taps)
+bool lfm2_conv_gate_quant_ok(size_t C, size_t K);
+hipError_t launch_lfm2_conv_gate_quant(const uint16_t* in_proj, const uint16_t* w, uint16_t* state, uint16_t* gated,
+                                       int8_t* q_out, float* scales_out, size_t nseq, size_t L, size_t C, size_t K,
+                                       size_t W, hipStream_t st);
 hipError_t launch_lfm2_conv_gate(const uint16_t* in_proj, const uint16_t* w, uint16_t* state, uint16_t* gated,
                                  size_t nseq, size_t L, size_t C, size_t K, size_t W, hipStream_t st);
 

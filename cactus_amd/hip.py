@@ -79,6 +79,7 @@ SIGNATURES = {
     "cactus_hip_scalar_op_f16_dev": (_i, [_vp, _vp, _sz, _f, _i, _vp]),
     "cactus_hip_conv1d_causal_depthwise_f16_dev": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_lfm2_conv_gate_f16_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_lfm2_conv_gate_quant_f16_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_add_rms_norm_quant_f16_dev": (_i, [_vp] * 7 + [_sz, _sz, _f, _vp]),
     "cactus_hip_silu_multiply_quant_f16_dev": (_i, [_vp] * 5 + [_sz, _sz, _vp]),
     "cactus_hip_gelu_multiply_quant_f16_dev": (_i, [_vp] * 5 + [_sz, _sz, _vp]),
@@ -433,6 +434,23 @@ def lfm2_conv_gate(in_proj, weight, state, out=None):
     _check(lib.cactus_hip_lfm2_conv_gate_f16_dev(_p(in_proj), _p(weight), _p(state), _p(o), nseq, L, Cc, K, W,
                                                  _stream()))
     return o
+
+
+def lfm2_conv_gate_quant(in_proj, weight, state, out_q=None, out_scales=None, out=None, want_gated=False):
+    """lfm2_conv_gate whose gated rows leave quantized for the out-projection: returns (q int8 [num_seqs * L, C],
+    scales float32 [num_seqs * L]) and, with want_gated or out, the fp16 rows as well."""
+    _dev(in_proj, torch.float16); _dev(weight, torch.float16)
+    nseq, L, C3 = in_proj.shape
+    Cc = C3 // 3
+    W = 0 if state is None else state.shape[1]
+    q = out_q if out_q is not None else torch.empty((nseq * L, Cc), dtype=torch.int8, device=in_proj.device)
+    sc = out_scales if out_scales is not None else torch.empty((nseq * L,), dtype=torch.float32, device=in_proj.device)
+    o = out
+    if o is None and want_gated:
+        o = torch.empty((nseq, L, Cc), dtype=torch.float16, device=in_proj.device)
+    _check(lib.cactus_hip_lfm2_conv_gate_quant_f16_dev(_p(in_proj), _p(weight), _p(state), _p(o), _p(q), _p(sc), nseq, L,
+                                                       Cc, weight.shape[-1], W, _stream()))
+    return (q, sc, o) if o is not None else (q, sc)
 
 
 def silu_multiply(gate, up, out=None):

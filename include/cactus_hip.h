@@ -306,6 +306,17 @@ int cactus_hip_lfm2_conv_gate_f16_dev(const cactus_half_t* in_proj, const cactus
                                       cactus_half_t* state, cactus_half_t* gated, size_t num_seqs, size_t L,
                                       size_t C, size_t K, size_t W, void* stream);
 
+/* cactus_hip_lfm2_conv_gate_f16_dev plus the activation quantization of the out-projection that consumes
+ * the gated rows (quantize_activations_fp16_to_int8, graph_ops_nn.cpp:35-66), one launch: q_output
+ * int8[num_seqs * L, C], scales_output float[num_seqs * L], bit for bit what
+ * cactus_hip_quantize_activations_dev gives on the gated rows; gated may be NULL.  C a multiple of 512 up
+ * to 2048 and K in 2..4 (LFM2: 2048, 3), 16-byte aligned buffers; otherwise CACTUS_HIP_EINVAL and the two
+ * separate calls apply. */
+int cactus_hip_lfm2_conv_gate_quant_f16_dev(const cactus_half_t* in_proj, const cactus_half_t* weight,
+                                            cactus_half_t* state, cactus_half_t* gated, int8_t* q_output,
+                                            float* scales_output, size_t num_seqs, size_t L, size_t C, size_t K,
+                                            size_t W, void* stream);
+
 /* A row producer followed by the activation quantization of the matmul that consumes it
  * (quantize_activations_fp16_to_int8, graph_ops_nn.cpp:35-66), one launch, one workgroup per row:
  * results equal cactus_hip_add_rms_norm_f16_dev / cactus_hip_silu_multiply_f16_dev /

@@ -270,3 +270,31 @@ def test_lfm2_conv_gate_empty_and_invalid(H):
     rc = H.lib.cactus_hip_lfm2_conv_gate_f16_dev(ip.data_ptr(), w.data_ptr(), state.data_ptr(), out.data_ptr(), 1, 2, C, 0, W,
                                                  None)
     assert rc != 0
+
+
+@pytest.mark.parametrize("C,K,W", [(2048, 3, 2), (512, 2, 1), (1536, 4, 3), (1024, 3, 0)])
+def test_lfm2_conv_gate_quant_equals_separate_calls(H, C, K, W):
+    """The one-launch conv block + activation quantization gives the gated rows, the carried state and the
+    INT8 rows / row scales of the two separate calls, bit for bit (and the oracle's quantization)."""
+    rng = np.random.default_rng(C + K)
+    nseq = 3
+    w = dev(halves(rng, (C, K), 0.5))
+    st_a = torch.zeros((nseq, W, C), dtype=torch.float16, device="cuda") if W else None
+    st_b = torch.zeros((nseq, W, C), dtype=torch.float16, device="cuda") if W else None
+    for L in (6, 1, 1, 70, 1):
+        ip = dev(halves(rng, (nseq, L, 3 * C), 2.0))
+        if L == 6:
+            ip[1, 2] = 0                                     # a zero row: scale floor 1e-10
+        want = H.lfm2_conv_gate(ip, w, st_a)
+        wq, ws = H.quantize_activations(want.view(nseq * L, C))
+        q, sc, got = H.lfm2_conv_gate_quant(ip, w, st_b, want_gated=True)
+        assert torch.equal(got, want) and torch.equal(q, wq), L
+        assert torch.equal(sc.view(torch.int32), ws.view(torch.int32)), L
+        if W:
+            assert torch.equal(st_a, st_b), L
+        oq, osc = O.quantize_activations(bits(want.view(nseq * L, C)))
+        assert np.array_equal(q.cpu().numpy(), oq) and np.array_equal(sc.cpu().numpy().view(np.uint32), osc.view(np.uint32))
+    q2, sc2 = H.lfm2_conv_gate_quant(ip, w, st_b)            # gated rows not wanted
+    assert q2.shape == (nseq, C) and sc2.shape == (nseq,)
+    with pytest.raises(H.CactusHipError):
+        H.lfm2_conv_gate_quant(dev(halves(rng, (1, 2, 3 * 24))), dev(halves(rng, (24, 3))), None)
