@@ -258,7 +258,7 @@ struct GemmBatch {
 };
 
 // NI: 16-row MFMA tiles per wave along m (4: 128-row workgroup tile, 2: 64-row tile for launches whose
-// 128-row tiles would leave most of the chip idle, 1 (INT8): 32-row tile when 64-row tiles still number fewer
+// 128-row tiles would leave most of the chip idle, 1: 32-row tile when 64-row tiles still number fewer
 // than half the CUs -- a workgroup then re-reads its weight tile for a quarter of the rows, from L2).
 template <bool INT4, int NI = 4>
 __global__ __launch_bounds__(512) void gemm2_kernel(
@@ -698,7 +698,7 @@ static hipError_t gemm2_allow_lds() {
     return hipSuccess;
 }
 
-// 32-row tiles (INT8) when even 64-row tiles would leave more than half of the CUs without a workgroup
+// 32-row tiles when even 64-row tiles would leave more than half of the CUs without a workgroup
 static bool gemm2_tiny_tiles(size_t M, size_t nbn) {
     return ((M + 63) / 64) * nbn < 128;
 }
@@ -718,15 +718,13 @@ static hipError_t launch_gemm2(const int8_t* A, const float* A_scales, const voi
     const int nbn = (int)((N + GM_BN - 1) / GM_BN);
     GemmBatch none;
     none.count = 0;
-    if constexpr (!INT4) {
-        if (gemm2_tiny_tiles(M, (size_t)nbn)) {
-            hipError_t et = gemm2_allow_lds<false, 1>();
-            if (et != hipSuccess) return et;
-            const int nbm = (int)((M + 31) / 32), nwg = nbm * nbn;
-            gemm2_kernel<false, 1><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales,
-                                                                               C, (int)M, (int)K, (int)N, G, nbm, nwg, none);
-            return hipGetLastError();
-        }
+    if (gemm2_tiny_tiles(M, (size_t)nbn)) {
+        hipError_t et = gemm2_allow_lds<INT4, 1>();
+        if (et != hipSuccess) return et;
+        const int nbm = (int)((M + 31) / 32), nwg = nbm * nbn;
+        gemm2_kernel<INT4, 1><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, (const uint8_t*)B, B_scales,
+                                                                          C, (int)M, (int)K, (int)N, G, nbm, nwg, none);
+        return hipGetLastError();
     }
     if (gemm2_small_tiles(M, (size_t)nbn)) {
         hipError_t es = gemm2_allow_lds<INT4, 2>();
@@ -755,13 +753,10 @@ static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, con
     size_t nbn_all = 0;
     for (size_t i = 0; i < count; i++) nbn_all += (pr[i].N + GM_BN - 1) / GM_BN;
     const bool small = gemm2_small_tiles(M, nbn_all);
-    bool tiny = false;
-    if constexpr (!INT4) tiny = gemm2_tiny_tiles(M, nbn_all);
+    const bool tiny = gemm2_tiny_tiles(M, nbn_all);
     hipError_t e = small ? gemm2_allow_lds<INT4, 2>() : gemm2_allow_lds<INT4, 4>();
     if (e != hipSuccess) return e;
-    if constexpr (!INT4) {
-        if (tiny && (e = gemm2_allow_lds<false, 1>()) != hipSuccess) return e;
-    }
+    if (tiny && (e = gemm2_allow_lds<INT4, 1>()) != hipSuccess) return e;
     const int nbm = tiny ? (int)((M + 31) / 32) : small ? (int)((M + 63) / 64) : (int)((M + GM_BM - 1) / GM_BM);
     size_t nbn = 0;
     for (size_t i = 0; i < count; i++) {
@@ -775,12 +770,10 @@ static hipError_t launch_gemm2_batch(const int8_t* A, const float* A_scales, con
     }
     const int nwg = nbm * (int)nbn;
     if (nwg == 0) return hipSuccess;
-    if constexpr (!INT4) {
-        if (tiny) {
-            gemm2_kernel<false, 1><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr,
-                                                                               (int)M, (int)K, 0, G, nbm, nwg, bt);
-            return hipGetLastError();
-        }
+    if (tiny) {
+        gemm2_kernel<INT4, 1><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr,
+                                                                          (int)M, (int)K, 0, G, nbm, nwg, bt);
+        return hipGetLastError();
     }
     if (small) {
         gemm2_kernel<INT4, 2><<<dim3((unsigned)nwg), dim3(512), lds, st>>>(A, A_scales, nullptr, nullptr, nullptr,

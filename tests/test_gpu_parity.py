@@ -156,7 +156,7 @@ SHAPES = [
     (40, 12288, 48),                                                        # 96 groups: largest scale panel in LDS
     (24, 25600, 32),                                                        # 200 groups: falls back to the plain tile kernel
     (512, 384, 8192), (520, 256, 8200),                                     # >= 256 tiles: 128-row tiles (fewer: 64-row tiles)
-    (512, 256, 2048), (1000, 384, 2100),                                    # 128 or more 64-row tiles, fewer than 256 128-row tiles: 64-row tiles (INT8 below that: 32-row tiles)
+    (512, 256, 2048), (1000, 384, 2100),                                    # 128 or more 64-row tiles, fewer than 256 128-row tiles: 64-row tiles (below that: 32-row tiles)
 ]
 
 
