@@ -79,6 +79,34 @@ int workspace(size_t bytes, void** out) {
     return CACTUS_HIP_OK;
 }
 
+// Scratch of the allocation-free attention entry point: the split-KV records (max, sum, O row per
+// query head and key range) that the library otherwise keeps in the grow-only workspace above.
+// The array lives in the code object, so every device that loads the library holds its own copy
+// for the life of the process.  `scratch` is only a host-side handle: the address kernels and
+// memsets use is the one hipGetSymbolAddress returns for the current device (noalloc_scratch).
+constexpr size_t NOALLOC_SCRATCH_BYTES = size_t(16) << 20;
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[NOALLOC_MAX_DEVICES];
+
+// device address of `scratch` on the current device, resolved once per device
+int noalloc_scratch(void** out) {
+    *out = nullptr;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(CACTUS_HIP_EINVAL, "noalloc: device index above 63");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail(CACTUS_HIP_ERUNTIME, "hipGetSymbolAddress(scratch)", e);
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return CACTUS_HIP_OK;
+}
+
 int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const cactus_half_t* Bs,
              cactus_half_t* C, int32_t* gsums, size_t M, size_t K, size_t N, size_t gs, void* stream) {
     if (M == 0 || K == 0 || N == 0) return CACTUS_HIP_OK;  // kernel_gemm.cpp:137, :338
@@ -156,15 +184,22 @@ int matmul_q_f16act_batch(bool int4, const cactus_hip_matmul_problem* pr, size_t
     return CACTUS_HIP_OK;
 }
 
-int attention(const AttnArgs& a, void* stream) {
+// fixed_ws: use this buffer of fixed_bytes for the split records and never allocate
+int attention(const AttnArgs& a, void* stream, void* fixed_ws = nullptr, size_t fixed_bytes = 0) {
     if (a.B == 0 || a.S == 0 || a.Hq == 0 || a.D == 0) return CACTUS_HIP_OK;
     if (a.Hkv == 0 || a.Hq % a.Hkv != 0) return fail(CACTUS_HIP_EINVAL, "attention: Hq must be a multiple of Hkv");
     if (a.D > 8000) return fail(CACTUS_HIP_EINVAL, "attention: head_dim above 8000");
     if (!a.f16_mode && a.qgs == 0) return fail(CACTUS_HIP_EINVAL, "attention: KV group_size must be nonzero");
     if (!a.q || !a.out) return fail(CACTUS_HIP_EINVAL, "attention: null operand");
     void* ws = nullptr;
-    int rc = workspace(attn_workspace_bytes(a), &ws);
-    if (rc != CACTUS_HIP_OK) return rc;
+    if (fixed_ws) {
+        if (attn_workspace_bytes(a) > fixed_bytes)
+            return fail(CACTUS_HIP_EINVAL, "attention_hybrid_noalloc: split-KV records exceed the 16 MiB scratch");
+        ws = fixed_ws;
+    } else {
+        int rc = workspace(attn_workspace_bytes(a), &ws);
+        if (rc != CACTUS_HIP_OK) return rc;
+    }
     hipError_t e = launch_attention(a, ws, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "attention launch", e);
     return CACTUS_HIP_OK;
@@ -177,7 +212,8 @@ extern "C" {
 int cactus_hip_init(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
-    return CACTUS_HIP_OK;
+    void* sp = nullptr;
+    return noalloc_scratch(&sp);   // the allocation-free entry point's scratch address, per device
 }
 
 int cactus_hip_device_count(void) {
@@ -940,6 +976,34 @@ int cactus_hip_attention_hybrid_int8_fp16_dev(
         return fail(CACTUS_HIP_EINVAL, "attention_hybrid: null cache");
     if (new_len && (!keys_new || !values_new)) return fail(CACTUS_HIP_EINVAL, "attention_hybrid: null new K/V");
     return attention(a, stream);
+}
+
+size_t cactus_hip_noalloc_scratch_bytes(void) { return NOALLOC_SCRATCH_BYTES; }
+
+int cactus_hip_attention_hybrid_int8_fp16_noalloc_dev(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales, const cactus_half_t* keys_new,
+    const cactus_half_t* values_new, cactus_half_t* output, size_t batch_size, size_t seq_len,
+    size_t cache_len, size_t new_len, size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+    float scale, size_t position_offset, int is_causal, size_t group_size, void* stream) {
+    AttnArgs a{};
+    a.q = queries; a.k_cached = keys_cached; a.v_cached = values_cached;
+    a.k_scales = k_scales; a.v_scales = v_scales; a.k_new = keys_new; a.v_new = values_new;
+    a.out = output; a.B = batch_size; a.S = seq_len; a.cache_len = cache_len; a.new_len = new_len;
+    a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.D = head_dim; a.scale = scale;
+    a.position_offset = position_offset; a.is_causal = is_causal; a.qgs = group_size;
+    a.cache_batch_stride = cache_len * num_kv_heads * head_dim;
+    a.scale_batch_stride = 0;
+    a.f16_mode = 0;
+    if (cache_len && (!keys_cached || !values_cached || !k_scales || !v_scales))
+        return fail(CACTUS_HIP_EINVAL, "attention_hybrid_noalloc: null cache");
+    if (new_len && (!keys_new || !values_new)) return fail(CACTUS_HIP_EINVAL, "attention_hybrid_noalloc: null new K/V");
+    void* sp = nullptr;
+    int rc = noalloc_scratch(&sp);
+    if (rc != CACTUS_HIP_OK) return rc;
+    // every record a merge reads is written by the split that owns it in the same call, so nothing
+    // in the scratch has to start at zero
+    return attention(a, stream, sp, NOALLOC_SCRATCH_BYTES);
 }
 
 int cactus_hip_attention_hybrid_int8_fp16_batched_dev(

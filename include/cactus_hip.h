@@ -414,6 +414,28 @@ int cactus_hip_attention_hybrid_int8_fp16_dev(
     size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
     float scale, size_t position_offset, int is_causal, size_t group_size, void* stream);
 
+/* No counterpart in the reference (its kernels borrow nothing but their arguments and the host
+ * heap).  For callers that cannot allocate device memory: code under HIP stream capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same arguments and the same results, bit for
+ * bit, as cactus_hip_attention_hybrid_int8_fp16_dev, but the split-KV records (running maximum,
+ * sum and unnormalised output row per query head and key range) go to a fixed 16 MiB array that
+ * is part of the library's code object instead of the grow-only workspace, so the call makes no
+ * hipMalloc / hipFree and calls no allocating routine.  A shape whose records need more than
+ * cactus_hip_noalloc_scratch_bytes() is rejected with CACTUS_HIP_EINVAL (decode steps need
+ * Hq * splits * (D + 2) * 4 bytes per sequence with at most 256 splits: 2.1 MiB for one Qwen3
+ * sequence at any context length; nothing when the batch alone fills the chip).  Each device
+ * holds one array for the life of the process; cactus_hip_init(device) resolves its address
+ * (call it before capturing).  Calls on one device share the array: two that overlap (different
+ * streams, or threads) race.  Nothing in it has to be cleared between calls. */
+size_t cactus_hip_noalloc_scratch_bytes(void);
+int cactus_hip_attention_hybrid_int8_fp16_noalloc_dev(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales,
+    const cactus_half_t* keys_new, const cactus_half_t* values_new, cactus_half_t* output,
+    size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+    float scale, size_t position_offset, int is_causal, size_t group_size, void* stream);
+
 /* Batched-decode form of the same kernel for independent sequences (one per
  * batch row): per-sequence cache length and position offset, and cache/scales
  * addressed with explicit per-sequence strides (in elements).  Has no

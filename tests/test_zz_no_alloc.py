@@ -1,0 +1,79 @@
+"""GPU test of the allocation-free attention entry point
+(cactus_hip_attention_hybrid_int8_fp16_noalloc_dev): called through the C ABI, its output equals that of
+cactus_hip_attention_hybrid_int8_fp16_dev bit for bit (same kernels, only the home of the split-KV records
+differs), on two calls in a row, the second with a smaller input so that records of the first call are
+still lying in the scratch; a shape whose records exceed the scratch is rejected, not truncated."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import f16
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def bits(t):
+    return t.cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def _case(rng, B, S, Hq, Hkv, D, cache, new):
+    q = rng.uniform(-1, 1, (B, S, Hq, D)).astype(np.float16)
+    kq, ks = O.quantize_kv(rng.uniform(-2, 2, (cache, Hkv, D)).astype(np.float16), 128)
+    vq, vs = O.quantize_kv(rng.uniform(-2, 2, (cache, Hkv, D)).astype(np.float16), 128)
+    kn = rng.uniform(-2, 2, (B, new, Hkv, D)).astype(np.float16)
+    vn = rng.uniform(-2, 2, (B, new, Hkv, D)).astype(np.float16)
+    return q, kq, vq, ks, vs, kn, vn
+
+
+def test_noalloc_attention_equals_allocating_entry_point_twice():
+    import cactus_amd.hip as H
+    H.init(0)
+    assert H.lib.cactus_hip_noalloc_scratch_bytes() == 16 << 20
+    rng = np.random.default_rng(2024)
+    # first a long cache (many key ranges -> many records in the scratch), then a shorter one with fewer
+    # heads: its records land on top of the first call's; last a prefill chunk (the matrix-core path)
+    shapes = [(1, 1, 16, 8, 128, 4096, 1), (1, 1, 4, 2, 128, 700, 1), (1, 64, 4, 2, 128, 300, 64)]
+    for (B, S, Hq, Hkv, D, cache, new) in shapes:
+        arrs = [dev(a) for a in _case(rng, B, S, Hq, Hkv, D, cache, new)]
+        ref = H.attention_hybrid(*arrs, 0.0, position_offset=cache, cache_len=cache)
+        torch.cuda.synchronize()
+        out = torch.full_like(ref, 7.0)
+        got = H.attention_hybrid(*arrs, 0.0, position_offset=cache, cache_len=cache, out=out, noalloc=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(got), bits(ref)), (B, S, Hq, Hkv, D, cache, new)
+        if cache <= 700 and S == 1:   # and against the oracle, at a size it finishes quickly
+            q, kq, vq, ks, vs, kn, vn = [a.cpu().numpy() for a in arrs]
+            want = O.attention_hybrid(q, kq, vq, ks, vs, kn, vn, 0.0, position_offset=cache, cache_len=cache)
+            assert np.abs(f16(bits(got)) - f16(want)).max() <= 2e-3
+
+
+def test_noalloc_attention_rejects_records_beyond_the_scratch():
+    import cactus_amd.hip as H
+    H.init(0)
+    # a 1024-query chunk of 32 heads: 256 query tiles -> 2 key ranges each -> 32768 rows x 2 records x 130
+    # floats = 34 MB of records.  Buffers have their real sizes: a build that needs no records for this
+    # shape simply computes it.
+    rng = np.random.default_rng(5)
+    B, S, Hq, Hkv, D, cache = 1, 1024, 32, 8, 128, 4096
+    q = torch.zeros((B, S, Hq, D), dtype=torch.float16, device="cuda")
+    kc = torch.zeros((cache, Hkv, D), dtype=torch.int8, device="cuda")
+    sc = torch.ones((cache, Hkv, 1), dtype=torch.float32, device="cuda")
+    kn = torch.zeros((B, S, Hkv, D), dtype=torch.float16, device="cuda")
+    out = torch.zeros_like(q)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = H.lib.cactus_hip_attention_hybrid_int8_fp16_noalloc_dev(
+        p(q), p(kc), p(kc), p(sc), p(sc), p(kn), p(kn), p(out), B, S, cache, S, Hq, Hkv, D, 0.0, cache, 1, 128, None)
+    torch.cuda.synchronize()
+    assert rc == -1 and b"scratch" in H.lib.cactus_hip_last_error()
+    # the allocating entry point takes the same call
+    assert H.lib.cactus_hip_attention_hybrid_int8_fp16_dev(
+        p(q), p(kc), p(kc), p(sc), p(sc), p(kn), p(kn), p(out), B, S, cache, S, Hq, Hkv, D, 0.0, cache, 1, 128, None) == 0
+    torch.cuda.synchronize()
