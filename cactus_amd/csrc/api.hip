@@ -48,11 +48,16 @@ namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-// Grow-only device scratch (split-KV partials).  One per device; calls that overlap on a
-// device and both need it must be on one stream (they share the buffer).
+// Grow-only device scratch (split-KV partials, quantized activation rows).  One per device; calls
+// that overlap on a device and both need it must be on one stream (they share the buffer).  A
+// buffer that is outgrown is retired, not freed: kernels already enqueued and HIP graphs captured
+// earlier keep a valid address (sizes grow geometrically, so the retired ones add up to less than
+// twice the live one).  Growing allocates, which stream capture forbids: reserve the size first
+// (cactus_hip_workspace_reserve).
 struct Workspace {
     void* ptr = nullptr;
     size_t bytes = 0;
+    std::vector<void*> retired;
 };
 std::mutex g_ws_mu;
 std::unordered_map<int, Workspace> g_ws;
@@ -65,14 +70,11 @@ int workspace(size_t bytes, void** out) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     Workspace& w = g_ws[dev];
     if (w.bytes < bytes) {
-        if (w.ptr) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(w.ptr));
-            w.ptr = nullptr;
-            w.bytes = 0;
-        }
-        size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes + bytes / 2;
-        if (hipMalloc(&w.ptr, want) != hipSuccess) return fail(CACTUS_HIP_ENOMEM, "workspace hipMalloc");
+        const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes + bytes / 2;
+        void* np = nullptr;
+        if (hipMalloc(&np, want) != hipSuccess) return fail(CACTUS_HIP_ENOMEM, "workspace hipMalloc");
+        if (w.ptr) w.retired.push_back(w.ptr);
+        w.ptr = np;
         w.bytes = want;
     }
     *out = w.ptr;
@@ -107,6 +109,13 @@ int noalloc_scratch(void** out) {
     return CACTUS_HIP_OK;
 }
 
+// The streaming (M <= 16) kernels address a weight matrix through one buffer descriptor with 32-bit
+// byte offsets whose top bit marks "out of range": the whole matrix must lie below 2 GiB.  Larger
+// ones take the tile kernel (64-bit tile bases).
+bool skinny_addressable(bool int4, size_t K, size_t N) {
+    return N * (int4 ? K / 2 : K) < (size_t(1) << 31);
+}
+
 int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const cactus_half_t* Bs,
              cactus_half_t* C, int32_t* gsums, size_t M, size_t K, size_t N, size_t gs, void* stream) {
     if (M == 0 || K == 0 || N == 0) return CACTUS_HIP_OK;  // kernel_gemm.cpp:137, :338
@@ -125,7 +134,7 @@ int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const c
     const bool tiled_ok = gs == 128 && (K % 128) == 0 && aligned(A, 16) && aligned(B, 16) &&
                           K < (size_t(1) << 30) && N < (size_t(1) << 30);
     hipError_t e;
-    if (tiled_ok && M <= 16 && (!int4 || K % 256 == 0))
+    if (tiled_ok && M <= 16 && (!int4 || K % 256 == 0) && skinny_addressable(int4, K, N))
         e = launch_matmul_skinny(int4, A, As, B, Bs, C, gsums, M, K, N, S(stream));
     else if (tiled_ok)
         e = launch_matmul_gemm(int4, A, As, B, Bs, C, gsums, M, K, N, S(stream));
@@ -142,7 +151,8 @@ int matmul_q_f16act(bool int4, const cactus_half_t* X, const void* B, const cact
     if (M == 0 || K == 0 || N == 0) return CACTUS_HIP_OK;
     if (!X || !B || !Bs || !C) return fail(CACTUS_HIP_EINVAL, "matmul_f16act: null operand");
     if (gs == 128 && K % 128 == 0 && aligned(X, 16) && aligned(B, 16) && aligned(Bs, 2) &&
-        K < (size_t(1) << 30) && N < (size_t(1) << 30) && skinny_fused_quant_ok(int4, M, K)) {
+        K < (size_t(1) << 30) && N < (size_t(1) << 30) && skinny_addressable(int4, K, N) &&
+        skinny_fused_quant_ok(int4, M, K)) {
         hipError_t e = launch_matmul_skinny_fq(int4, X, nullptr, B, Bs, C, M, K, N, S(stream));
         if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_f16act launch", e);
         return CACTUS_HIP_OK;
@@ -168,7 +178,8 @@ int matmul_q_f16act_batch(bool int4, const cactus_hip_matmul_problem* pr, size_t
         if (q.M == 0 || q.K == 0 || q.N == 0) continue;
         if (!q.X || !q.B || !q.B_scales || !q.C) return fail(CACTUS_HIP_EINVAL, "matmul_f16act_batch: null operand");
         const bool ok = gs == 128 && q.K % 128 == 0 && aligned(q.X, 16) && aligned(q.B, 16) &&
-                        q.K < (size_t(1) << 30) && q.N < (size_t(1) << 30) && skinny_fused_quant_ok(int4, q.M, q.K);
+                        q.K < (size_t(1) << 30) && q.N < (size_t(1) << 30) && skinny_addressable(int4, q.K, q.N) &&
+                        skinny_fused_quant_ok(int4, q.M, q.K);
         if (ok) {
             fused.push_back(SkinnyProblem{q.X, q.B, q.B_scales, q.C, q.M, q.K, q.N});
         } else {
@@ -250,6 +261,11 @@ int cactus_hip_synchronize(void* stream) {
     return CACTUS_HIP_OK;
 }
 
+int cactus_hip_workspace_reserve(size_t bytes) {
+    void* ws = nullptr;
+    return workspace(bytes, &ws);
+}
+
 int cactus_hip_matmul_int8_dev(const int8_t* A, const float* A_scales, const int8_t* B,
                                const cactus_half_t* B_scales, cactus_half_t* C, size_t M, size_t K,
                                size_t N, size_t group_size, void* stream) {
@@ -301,7 +317,10 @@ int matmul_q_shared(bool int4, const int8_t* A, const float* As, const cactus_hi
     for (size_t i = 0; i < count; i++)
         if (ws[i].N && (!ws[i].B || !ws[i].B_scales || !ws[i].C)) return fail(CACTUS_HIP_EINVAL, "matmul_shared: null operand");
     // one launch when the pipelined kernel takes the shape, otherwise one call per weight
-    if (M > 16 && gs == 128 && K > 0 && A && As) {
+    bool dma_ok = M > 16 && gs == 128 && K > 0 && A && As && aligned(A, 16) && K < (size_t(1) << 30);
+    for (size_t i = 0; dma_ok && i < count; i++)
+        dma_ok = aligned(ws[i].B, 16) && ws[i].N < (size_t(1) << 30);
+    if (dma_ok) {
         size_t i = 0;
         bool all = true;
         while (i < count && all) {
@@ -351,7 +370,7 @@ int matmul_q_produced(bool int4, int kind, const cactus_half_t* x, const cactus_
                  (!x2 || aligned(x2, 16)) && (!w || aligned(w, 16)) && (!sum_out || aligned(sum_out, 16)) &&
                  K < (size_t(1) << 30) && skinny_fq_pro_ok(int4, kind, M, K);
     for (size_t i = 0; fused && i < count; i++)
-        fused = wt[i].N > 0 && wt[i].N < (size_t(1) << 30) && aligned(wt[i].B, 16);
+        fused = wt[i].N > 0 && wt[i].N < (size_t(1) << 30) && aligned(wt[i].B, 16) && skinny_addressable(int4, K, wt[i].N);
     if (fused) {
         SkinnyProblem pr[16];
         for (size_t i = 0; i < count; i++) pr[i] = SkinnyProblem{x, wt[i].B, wt[i].B_scales, wt[i].C, M, K, wt[i].N};
@@ -584,11 +603,8 @@ int rope_rows(size_t head_dim, float theta, size_t start_pos, size_t seq, const 
         }
         HIP_TRY(hipMemcpy(nc, t->cos_h.data(), bytes, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ns, t->sin_h.data(), bytes, hipMemcpyHostToDevice));
-        if (d.cos) {   // kernels still reading the old rows finish before the free returns
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(d.cos));
-            HIP_TRY(hipFree(d.sin));
-        }
+        // the outgrown tables stay allocated: kernels in flight and captured graphs may hold their rows
+        // (tables double, so the retired ones add up to less than the live one)
         d.cos = nc; d.sin = ns; d.npos = t->npos;
     }
     *cos_out = d.cos + start_pos * half_dim;
@@ -1036,16 +1052,34 @@ namespace {
 struct DevBuf {
     void* ptr = nullptr;
     size_t bytes = 0;
+    uint64_t sig = 0;   // content signature of a resident weight
+};
+struct HostKey {
+    int dev;
+    const void* host;
+    bool operator==(const HostKey& o) const { return dev == o.dev && host == o.host; }
+};
+struct HostKeyHash {
+    size_t operator()(const HostKey& k) const {
+        return std::hash<const void*>()(k.host) ^ (std::hash<int>()(k.dev) * 0x9E3779B97F4A7C15ull);
+    }
 };
 std::mutex g_host_mu;
-std::unordered_map<const void*, DevBuf> g_weights;  // host address -> resident device copy
-std::vector<DevBuf> g_stage;                        // per-call staging slots, grow-only
+std::unordered_map<HostKey, DevBuf, HostKeyHash> g_weights;   // (device, host address) -> resident copy
+std::unordered_map<int, std::vector<DevBuf>> g_stage;         // per device: per-call staging slots, grow-only
+
+int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
 
 void* stage(size_t slot, size_t bytes) {
-    if (g_stage.size() <= slot) g_stage.resize(slot + 1);
-    DevBuf& b = g_stage[slot];
+    std::vector<DevBuf>& slots = g_stage[current_device()];
+    if (slots.size() <= slot) slots.resize(slot + 1);
+    DevBuf& b = slots[slot];
     if (b.bytes < bytes) {
-        if (b.ptr) (void)hipFree(b.ptr);
+        if (b.ptr) (void)hipFree(b.ptr);   // the family is synchronous: nothing in flight reads it
         b.ptr = nullptr;
         b.bytes = 0;
         const size_t want = bytes + bytes / 4 + 256;
@@ -1069,10 +1103,41 @@ void* upload(size_t slot, const void* host, size_t bytes) {
     return d;
 }
 
-// Weights are immutable mmap'd regions: upload once, keep resident, key by address.
+// FNV-1a over 64 evenly spaced 64-byte samples (the whole buffer when it is small) and the size: a
+// few microseconds per call, enough to notice that an address now holds other data (a freed and
+// reused heap buffer, a scratch buffer a caller refills).
+uint64_t content_signature(const void* host, size_t bytes) {
+    const unsigned char* p = static_cast<const unsigned char*>(host);
+    uint64_t h = 1469598103934665603ull ^ bytes;
+    auto mix = [&](const unsigned char* q, size_t n) {
+        for (size_t i = 0; i < n; i++) h = (h ^ q[i]) * 1099511628211ull;
+    };
+    if (bytes <= 64 * 64) {
+        mix(p, bytes);
+    } else {
+        const size_t stride = (bytes - 64) / 63;
+        for (size_t i = 0; i < 64; i++) mix(p + i * stride, 64);
+    }
+    return h;
+}
+
+// Weights of the quantized matmuls are immutable mmap'd regions in the reference (graph_io.cpp:43-45):
+// upload once per (device, address), keep resident.  The key is re-validated on every call by size and
+// content signature, so an address whose contents changed is uploaded again instead of multiplying
+// stale data.
 void* resident(const void* host, size_t bytes) {
-    auto it = g_weights.find(host);
-    if (it != g_weights.end() && it->second.bytes == bytes) return it->second.ptr;
+    const HostKey key{current_device(), host};
+    const uint64_t sig = content_signature(host, bytes);
+    auto it = g_weights.find(key);
+    if (it != g_weights.end() && it->second.bytes == bytes && it->second.sig == sig) return it->second.ptr;
+    if (it != g_weights.end() && it->second.bytes == bytes) {   // same place, new contents
+        if (bytes && hipMemcpy(it->second.ptr, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            fail(CACTUS_HIP_ERUNTIME, "weight hipMemcpy");
+            return nullptr;
+        }
+        it->second.sig = sig;
+        return it->second.ptr;
+    }
     if (it != g_weights.end()) {
         (void)hipFree(it->second.ptr);
         g_weights.erase(it);
@@ -1083,12 +1148,13 @@ void* resident(const void* host, size_t bytes) {
         return nullptr;
     }
     b.bytes = bytes;
+    b.sig = sig;
     if (bytes && hipMemcpy(b.ptr, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(b.ptr);
         fail(CACTUS_HIP_ERUNTIME, "weight hipMemcpy");
         return nullptr;
     }
-    g_weights[host] = b;
+    g_weights[key] = b;
     return b.ptr;
 }
 
@@ -1128,7 +1194,7 @@ extern "C" {
 void cactus_hip_release_weights(const void* host_ptr) {
     std::lock_guard<std::mutex> lk(g_host_mu);
     if (host_ptr) {
-        auto it = g_weights.find(host_ptr);
+        auto it = g_weights.find(HostKey{current_device(), host_ptr});
         if (it != g_weights.end()) {
             (void)hipFree(it->second.ptr);
             g_weights.erase(it);
@@ -1155,7 +1221,9 @@ void cactus_hip_matmul_f16(const cactus_half_t* a, const cactus_half_t* bT, cact
                            size_t K, size_t N) {
     if (M == 0 || N == 0) return;
     std::lock_guard<std::mutex> lk(g_host_mu);
-    void* dB = resident(bT, N * K * 2);
+    // b_transposed is staged per call: the reference's callers pass a scratch buffer they refill
+    // (graph_ops_nn.cpp:222-228) and per-document vectors (engine_index.cpp:18), not a weight file
+    void* dB = upload(1, bT, N * K * 2);
     void* dA = upload(0, a, M * K * 2);
     void* dC = stage(2, M * N * 2);
     if (!dB || !dA || !dC) return;

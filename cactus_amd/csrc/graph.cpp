@@ -51,6 +51,38 @@ size_t precision_size(Precision p) {
     return 1;
 }
 
+// ------------------------------------------------------------------------- DevicePool
+
+void* CactusGraph::DevicePool::acquire(size_t bytes) {
+    const size_t rounded = ((bytes ? bytes : 1) + 255) & ~size_t(255);
+    auto it = free_.find(rounded);
+    if (it != free_.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        return p;
+    }
+    void* p = dev_alloc(rounded);
+    size_of_[p] = rounded;
+    allocations_++;
+    return p;
+}
+
+void CactusGraph::DevicePool::release(void* p) {
+    if (!p) return;
+    auto it = size_of_.find(p);
+    if (it == size_of_.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    free_[it->second].push_back(p);
+}
+
+void CactusGraph::DevicePool::clear() {
+    for (auto& kv : size_of_) (void)hipFree(kv.first);
+    size_of_.clear();
+    free_.clear();
+}
+
 // ------------------------------------------------------------------------- CactusGraph
 
 CactusGraph::CactusGraph() = default;
@@ -269,7 +301,7 @@ size_t CactusGraph::conv1d_causal(size_t input, size_t weight, size_t, size_t di
 
 void CactusGraph::ensure_device(BufferDesc& b) {
     if (b.device_data == nullptr) {
-        b.device_data = dev_alloc(b.byte_size);
+        b.device_data = pool_.acquire(b.byte_size);
         b.owns_device = true;
     }
 }
@@ -277,8 +309,8 @@ void CactusGraph::ensure_device(BufferDesc& b) {
 void* CactusGraph::resident_copy(const void* host, size_t bytes) {
     auto it = resident_.find(host);
     if (it != resident_.end() && it->second.bytes == bytes) return it->second.dev;
-    if (it != resident_.end()) {
-        (void)hipFree(it->second.dev);
+    if (it != resident_.end()) {   // nodes bound earlier may still point at the old copy: it stays until hard_reset
+        retired_.push_back(it->second.dev);
         resident_.erase(it);
     }
     void* d = dev_alloc(bytes);
@@ -301,7 +333,7 @@ void CactusGraph::set_external_input(size_t node_id, void* data, Precision) {
     auto& n = node(node_id);
     if (n.op_type != OpType::INPUT) throw std::invalid_argument("Can only set data on input nodes");
     BufferDesc& b = n.output_buffer;
-    if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
+    if (b.owns_device && b.device_data) pool_.release(b.device_data);
     b.device_data = resident_copy(data, b.byte_size);
     b.owns_device = false;
     b.device_valid = true;
@@ -312,7 +344,7 @@ void CactusGraph::set_device_input(size_t node_id, void* device_ptr, Precision) 
     auto& n = node(node_id);
     if (n.op_type != OpType::INPUT) throw std::invalid_argument("Can only set data on input nodes");
     BufferDesc& b = n.output_buffer;
-    if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
+    if (b.owns_device && b.device_data) pool_.release(b.device_data);
     b.device_data = device_ptr;
     b.owns_device = false;
     b.device_valid = true;
@@ -472,33 +504,46 @@ size_t CactusGraph::mmap_weights(const std::string& filename) {   // graph_io.cp
     if (h.precision > 3) throw std::runtime_error("Unknown precision in tensor file: " + filename);
     const bool int4 = h.precision == (uint32_t)Precision::INT4;
     const Precision prec = int4 ? Precision::INT8 : static_cast<Precision>(h.precision);   // effective_precision()
-    const size_t id = input(shape, prec);
-    BufferDesc& b = node(id).output_buffer;
+    // the file is validated as a whole before the graph gains a node: a matmul trusts these sizes
+    const size_t elements = product(shape);
+    const size_t need_bytes = int4 ? (elements + 1) / 2 : elements * precision_size(prec);
+    if (h.data_bytes < need_bytes)
+        throw std::runtime_error("File corrupted: payload smaller than the tensor: " + filename);
+    const bool grouped = h.group_size > 0 && h.scales_bytes > 0 && (int4 || prec == Precision::INT8);
+    if (grouped) {
+        if (shape.empty() || h.scales_bytes < shape[0] * (size_t)h.num_groups * sizeof(uint16_t) ||
+            h.scales_offset + h.scales_bytes > file_size)
+            throw std::runtime_error("File corrupted: group scales smaller than [rows, groups]: " + filename);
+    }
     const char* base = static_cast<const char*>(map);
     void* dev = dev_alloc(h.data_bytes);
-    hip_check(hipMemcpy(dev, base + h.data_offset, h.data_bytes, hipMemcpyHostToDevice), "hipMemcpy H2D (weights)");
+    hipError_t ce = hipMemcpy(dev, base + h.data_offset, h.data_bytes, hipMemcpyHostToDevice);
+    void* dev_scales = nullptr;
+    if (ce == hipSuccess && grouped) {
+        if (hipMalloc(&dev_scales, h.scales_bytes) != hipSuccess) ce = hipErrorOutOfMemory;
+        else ce = hipMemcpy(dev_scales, base + h.scales_offset, h.scales_bytes, hipMemcpyHostToDevice);
+    }
+    if (ce != hipSuccess) {
+        (void)hipFree(dev);
+        if (dev_scales) (void)hipFree(dev_scales);
+        hip_check(ce, "hipMemcpy H2D (weights)");
+    }
+    const size_t id = input(shape, prec);
+    BufferDesc& b = node(id).output_buffer;
     if (int4) {
         b.packed_int4_device = dev;
         b.packed_int4_size = h.data_bytes;
         b.owns_packed = true;
     } else {
-        if (h.data_bytes < b.byte_size) {
-            (void)hipFree(dev);
-            throw std::runtime_error("File corrupted: payload smaller than the tensor: " + filename);
-        }
         b.device_data = dev;
         b.owns_device = true;
     }
     b.device_valid = true;
-    if (h.group_size > 0 && h.scales_bytes > 0 && (int4 || prec == Precision::INT8)) {
-        if (shape.empty() || h.scales_bytes < shape[0] * (size_t)h.num_groups * sizeof(uint16_t))
-            throw std::runtime_error("File corrupted: group scales smaller than [rows, groups]: " + filename);
+    if (grouped) {
         b.group_size = h.group_size;
         b.num_groups = h.num_groups;
-        b.scales_device = dev_alloc(h.scales_bytes);
+        b.scales_device = dev_scales;
         b.owns_scales = true;
-        hip_check(hipMemcpy(b.scales_device, base + h.scales_offset, h.scales_bytes, hipMemcpyHostToDevice),
-                  "hipMemcpy H2D (scales)");
     }
     is_weight_[id] = true;
     weight_cache_[filename] = id;
@@ -544,9 +589,9 @@ void CactusGraph::compute_matmul_node(GraphNode& n) {
             // quantize once per FP16 node and step; q/k/v (and gate/up) share one input node
             QuantCache& qc = quant_cache_[n.input_ids[0]];
             if (qc.q == nullptr || qc.M != M || qc.K != K) {
-                if (qc.q) { (void)hipFree(qc.q); (void)hipFree(qc.scales); }
-                qc.q = dev_alloc(M * K);
-                qc.scales = dev_alloc(M * sizeof(float));
+                if (qc.q) { pool_.release(qc.q); pool_.release(qc.scales); }
+                qc.q = pool_.acquire(M * K);
+                qc.scales = pool_.acquire(M * sizeof(float));
                 qc.M = M; qc.K = K;
                 abi_check(cactus_hip_quantize_activations_dev(static_cast<const cactus_half_t*>(lhs.device_data),
                                                               static_cast<int8_t*>(qc.q),
@@ -575,13 +620,12 @@ void CactusGraph::compute_matmul_node(GraphNode& n) {
     } else {
         // rhs is [K, N]: transpose into a scratch buffer, then the same kernel
         // (graph_ops_nn.cpp:222-229 does the same on the host)
-        void* bt = dev_alloc(N * K * 2);
+        void* bt = pool_.acquire(N * K * 2);
         hipError_t e = launch_transpose_f16(static_cast<const uint16_t*>(rhs.device_data),
                                             static_cast<uint16_t*>(bt), K, N, nullptr);
         int rc = CACTUS_HIP_OK;
         if (e == hipSuccess) rc = cactus_hip_matmul_f16_dev(a, static_cast<const cactus_half_t*>(bt), out, M, K, N, nullptr);
-        (void)hipStreamSynchronize(nullptr);
-        (void)hipFree(bt);
+        pool_.release(bt);   // whoever takes it next runs behind this matmul on the same stream
         hip_check(e, "transpose launch");
         abi_check(rc);
     }
@@ -596,8 +640,8 @@ void CactusGraph::compute_quantize_activations_node(GraphNode& n) {
     const size_t M = in.total_size / K;
     BufferDesc& out = n.output_buffer;
     if (!out.has_activation_scales() || out.num_rows_for_activation_scales != M) {
-        if (out.activation_scales_device) (void)hipFree(out.activation_scales_device);
-        out.activation_scales_device = dev_alloc(M * sizeof(float));
+        if (out.activation_scales_device) pool_.release(out.activation_scales_device);
+        out.activation_scales_device = pool_.acquire(M * sizeof(float));
         out.num_rows_for_activation_scales = M;
     }
     abi_check(cactus_hip_quantize_activations_dev(static_cast<const cactus_half_t*>(in.device_data),
@@ -846,9 +890,13 @@ bool CactusGraph::batchable_matmul(const GraphNode& n, bool* int4) const {
 
 void CactusGraph::execute() {
     for (auto& kv : quant_cache_) {
-        if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
+        if (kv.second.q) { pool_.release(kv.second.q); pool_.release(kv.second.scales); }
     }
     quant_cache_.clear();
+    // Every computed node is stale until this pass reaches it: a graph may be executed again after
+    // set_input without a reset, and "is this input valid yet" is what orders the batched matmul runs.
+    for (auto& up : nodes_)
+        if (up->op_type != OpType::INPUT) up->output_buffer.device_valid = false;
     for (size_t idx = 0; idx < nodes_.size(); idx++) {
         GraphNode& n = *nodes_[idx];
         if (n.op_type == OpType::INPUT) {
@@ -896,7 +944,7 @@ void CactusGraph::execute() {
         if (n.op_type == OpType::RESHAPE) {   // a view: same bytes, new shape
             BufferDesc& in = node(n.input_ids[0]).output_buffer;
             BufferDesc& out = n.output_buffer;
-            if (out.owns_device && out.device_data) (void)hipFree(out.device_data);
+            if (out.owns_device && out.device_data) pool_.release(out.device_data);
             out.device_data = in.device_data;
             out.owns_device = false;
             out.device_valid = true;
@@ -908,7 +956,7 @@ void CactusGraph::execute() {
             BufferDesc& out = n.output_buffer;
             const size_t first = n.op_type == OpType::INDEX ? n.params.index_value : n.params.slice_start;
             const size_t row_bytes = in.shape[0] ? in.byte_size / in.shape[0] : 0;
-            if (out.owns_device && out.device_data) (void)hipFree(out.device_data);
+            if (out.owns_device && out.device_data) pool_.release(out.device_data);
             out.device_data = static_cast<char*>(in.device_data) + first * row_bytes;
             out.owns_device = false;
             out.device_valid = true;
@@ -948,10 +996,12 @@ void* CactusGraph::get_output(size_t node_id) {   // graph_execute.cpp:223-229; 
     return b.host_copy.data();
 }
 
-static void free_node(GraphNode& n) {
+// node buffers and scratch go back to the pool (a weight file's payload, which the pool did not hand
+// out, is freed by it)
+static void free_node(GraphNode& n, CactusGraph::DevicePool& pool) {
     BufferDesc& b = n.output_buffer;
-    if (b.owns_device && b.device_data) (void)hipFree(b.device_data);
-    if (b.activation_scales_device) (void)hipFree(b.activation_scales_device);
+    if (b.owns_device && b.device_data) pool.release(b.device_data);
+    if (b.activation_scales_device) pool.release(b.activation_scales_device);
     if (b.owns_scales && b.scales_device) (void)hipFree(b.scales_device);
     if (b.owns_packed && b.packed_int4_device) (void)hipFree(b.packed_int4_device);
     b.scales_device = nullptr;
@@ -964,27 +1014,31 @@ void CactusGraph::soft_reset() {   // graph_execute.cpp:640-675: weights survive
     std::vector<std::unique_ptr<GraphNode>> keep;
     for (auto& up : nodes_) {
         if (is_weight_.count(up->id)) keep.push_back(std::move(up));
-        else free_node(*up);
+        else free_node(*up, pool_);
     }
     nodes_ = std::move(keep);
     node_index_map_.clear();
     for (size_t i = 0; i < nodes_.size(); i++) node_index_map_[nodes_[i]->id] = i;
     for (auto& kv : quant_cache_)
-        if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
+        if (kv.second.q) { pool_.release(kv.second.q); pool_.release(kv.second.scales); }
     quant_cache_.clear();
 }
 
 void CactusGraph::hard_reset() {
-    for (auto& up : nodes_) free_node(*up);
+    for (auto& up : nodes_) free_node(*up, pool_);
     nodes_.clear();
     node_index_map_.clear();
     is_weight_.clear();
     weight_cache_.clear();
     for (auto& kv : resident_) (void)hipFree(kv.second.dev);
     resident_.clear();
+    for (void* p : retired_) (void)hipFree(p);
+    retired_.clear();
     for (auto& kv : quant_cache_)
-        if (kv.second.q) { (void)hipFree(kv.second.q); (void)hipFree(kv.second.scales); }
+        if (kv.second.q) { pool_.release(kv.second.q); pool_.release(kv.second.scales); }
     quant_cache_.clear();
+    (void)hipDeviceSynchronize();   // pooled buffers may still be read by kernels in flight
+    pool_.clear();
     if (index_scratch_) (void)hipFree(index_scratch_);
     index_scratch_ = nullptr;
     index_scratch_count_ = 0;
@@ -1422,6 +1476,7 @@ int cactus_hip_graph_hard_reset(void* g) {
     return guarded<int>(-1, [&] { G_(g)->hard_reset(); return 0; });
 }
 size_t cactus_hip_graph_node_count(void* g) { return G_(g)->get_node_count(); }
+size_t cactus_hip_graph_pool_allocations(void* g) { return G_(g)->pool_device_allocations(); }
 
 void* cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim) {
     auto* c = new KVCache();

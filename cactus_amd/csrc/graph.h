@@ -185,11 +185,30 @@ public:
     void* get_device_output(size_t node_id);   // device pointer, no synchronisation
     const BufferDesc& get_output_buffer(size_t node_id) const;
     size_t get_node_count() const { return nodes_.size(); }
+    // hipMalloc calls made for node buffers and scratch so far (stays flat once the pool is warm)
+    size_t pool_device_allocations() const { return pool_.device_allocations(); }
     void hard_reset();
     void soft_reset();   // drops every node that is not a weight (external) input
 
     size_t add_node(OpType op_type, const std::vector<size_t>& inputs,
                     const std::vector<size_t>& output_shape, const OpParams& params = {});
+
+    // Device buffers of node outputs and per-step scratch (activation quantization, transposes), kept
+    // across execute() and soft_reset() and handed out again by size: a model that rebuilds the same
+    // graph every token allocates on its first step only (the reference's BufferPool,
+    // graph_execute.cpp:640-675).  All node kernels run on one stream, so a buffer released by one
+    // step is safely reused by the next.  Emptied by hard_reset().
+    class DevicePool {
+    public:
+        void* acquire(size_t bytes);
+        void release(void* p);   // a pointer the pool did not hand out is freed
+        void clear();
+        size_t device_allocations() const { return allocations_; }
+    private:
+        std::unordered_map<size_t, std::vector<void*>> free_;   // rounded size -> idle buffers
+        std::unordered_map<void*, size_t> size_of_;             // every buffer handed out -> rounded size
+        size_t allocations_ = 0;
+    };
 
 private:
     GraphNode& node(size_t id);
@@ -213,6 +232,9 @@ private:
     void compute_slice_node(GraphNode& n);     // SLICE and INDEX
     void compute_concat_node(GraphNode& n);
     void compute_sample_node(GraphNode& n);
+
+    DevicePool pool_;
+    std::vector<void*> retired_;   // resident copies replaced under the same host address
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;

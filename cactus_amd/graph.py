@@ -50,6 +50,7 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_soft_reset": (_i, [_vp]),
     "cactus_hip_graph_hard_reset": (_i, [_vp]),
     "cactus_hip_graph_node_count": (_sz, [_vp]),
+    "cactus_hip_graph_pool_allocations": (_sz, [_vp]),
     "cactus_hip_kvcache_create": (_vp, [_sz, _sz, _sz, _sz]),
     "cactus_hip_kvcache_destroy": (None, [_vp]),
     "cactus_hip_kvcache_set_window": (_i, [_vp, _sz, _sz]),
@@ -283,6 +284,9 @@ class CactusGraph:
 
     def get_node_count(self):
         return lib.cactus_hip_graph_node_count(self._g)
+
+    def pool_allocations(self):
+        return lib.cactus_hip_graph_pool_allocations(self._g)
 
 
 def parse_cact_header(data):

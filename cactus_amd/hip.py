@@ -32,6 +32,7 @@ SIGNATURES = {
     "cactus_hip_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
     "cactus_hip_synchronize": (_i, [_vp]),
     "cactus_hip_release_weights": (None, [_vp]),
+    "cactus_hip_workspace_reserve": (_i, [_sz]),
     "cactus_hip_matmul_int8_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),

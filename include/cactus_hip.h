@@ -15,11 +15,14 @@
  *                             path.
  *   cactus_hip_<op>(...)      operands are HOST pointers with exactly the
  *                             reference's signature; results are complete on
- *                             return (the reference's contract).  Weight and
- *                             weight-scale pointers are uploaded once and cached
- *                             by address (they are mmap'd file regions that live
- *                             as long as the graph: graph_io.cpp:43-45), every
- *                             other operand is staged per call.
+ *                             return (the reference's contract).  The weights and
+ *                             weight scales of the quantized matmuls are uploaded
+ *                             once and cached by (device, address) (they are mmap'd
+ *                             file regions that live as long as the graph:
+ *                             graph_io.cpp:43-45) and re-validated per call by size
+ *                             and a sampled content signature; every other operand,
+ *                             cactus_hip_matmul_f16's b_transposed included, is
+ *                             staged per call.
  *
  * Errors: the reference kernels return void and cannot fail.  The *_dev family
  * returns 0 or a negative CACTUS_HIP_E* code; the host family records the
@@ -60,8 +63,15 @@ int   cactus_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stre
 int   cactus_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int   cactus_hip_synchronize(void* stream);
 
+/* The library keeps one grow-only device workspace per device (split-KV records of the attention
+ * kernels, quantized activation rows of the FP16-activation matmuls with more than 4 rows).  It
+ * grows by allocating, which HIP stream capture forbids: reserve the largest size a captured
+ * sequence needs beforehand (or run the sequence once uncaptured).  An outgrown workspace stays
+ * allocated, so graphs captured earlier remain valid.  No counterpart in the reference. */
+int   cactus_hip_workspace_reserve(size_t bytes);
+
 /* Host-pointer family: drop cached device copies of weights (all, or the one
- * registered under host_ptr). */
+ * registered under host_ptr on the current device). */
 void cactus_hip_release_weights(const void* host_ptr);
 
 /* ------------------------------------------------- device-resident hot path */

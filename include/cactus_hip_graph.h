@@ -108,6 +108,10 @@ void*  cactus_hip_graph_get_device_output(void* graph, size_t node);
 int    cactus_hip_graph_soft_reset(void* graph);
 int    cactus_hip_graph_hard_reset(void* graph);
 size_t cactus_hip_graph_node_count(void* graph);
+/* Device allocations made so far for node outputs and per-step scratch.  The graph keeps those
+ * buffers in a pool across execute() and soft_reset() (the reference's BufferPool,
+ * graph_execute.cpp:640-675), so the count stops growing once a step has run. */
+size_t cactus_hip_graph_pool_allocations(void* graph);
 
 void*  cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim);
 void   cactus_hip_kvcache_destroy(void* cache);

@@ -85,3 +85,23 @@ def test_model_config_defaults_comments_and_errors(tmp_path):
     p.write_text("vocab_size=abc\n")           # std::stoul throws in the reference
     with pytest.raises(Exception):
         G.load_model_config(str(p))
+
+
+def test_mmap_weights_rejects_truncated_payload_before_touching_the_graph(tmp_path):
+    """A packed INT4 file whose payload is shorter than rows x K/2 (or an INT8 one shorter than rows x K)
+    would make a matmul read past its device allocation: the file is refused while it is being
+    validated on the host, and the graph gains no node."""
+    import struct
+    import cactus_amd.graph as G
+    for kind in ("file_int4", "file_int8"):
+        raw = bytearray(np.load(os.path.join(GOLD, FIXTURES[0]))[kind].tobytes())
+        h = G.parse_cact_header(bytes(raw))
+        short = h["data_bytes"] // 2
+        struct.pack_into("<Q", raw, 56, short)                       # header claims half the payload
+        p = tmp_path / (kind + ".weights")
+        p.write_bytes(bytes(raw[: h["data_offset"] + short]))
+        g = G.CactusGraph()
+        with pytest.raises(Exception, match="payload smaller than the tensor"):
+            g.mmap_weights(str(p))
+        assert g.get_node_count() == 0
+        g.close()

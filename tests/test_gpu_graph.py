@@ -617,3 +617,66 @@ def test_ring_whole_sequence_update_restarts_the_ring(G):
     assert (kq[order] == okq).all() and (ks[order] == oks).all()
     g.close()
     cache.close()
+
+
+# ---------------------------------------------------------------------------- re-execution and the buffer pool
+@pytest.mark.parametrize("int4", [False, True])
+def test_chained_decode_matmuls_reexecuted_with_new_input(G, int4):
+    """x -> matmul -> matmul executed twice with different inputs and no reset in between: the second
+    matmul reads the first one's output of the SAME pass (it must not join the first one's batched
+    launch on the strength of last pass's validity flags)."""
+    rng = np.random.default_rng(91 + int4)
+    K, N1, N2 = 1024, 2048, 512
+    mk = rand_weights_int4 if int4 else rand_weights_int8
+    om = O.matmul_int4 if int4 else O.matmul_int8
+    g = G.CactusGraph()
+    xin = g.input((1, K), G.FP16)
+    B1, S1 = mk(rng, N1, K)
+    B2, S2 = mk(rng, N2, N1)
+    w1 = g.input((N1, K), G.INT8); w2 = g.input((N2, N1), G.INT8)
+    (g.set_packed_int4 if int4 else g.set_external_input)(w1, B1)
+    (g.set_packed_int4 if int4 else g.set_external_input)(w2, B2)
+    g.set_grouped_scales(w1, 128, K // 128, S1)
+    g.set_grouped_scales(w2, 128, N1 // 128, S2)
+    h = g.matmul(xin, w1, True)
+    y = g.matmul(h, w2, True)
+    for rep in range(3):
+        x = rand_act_f16(rng, 1, K) * (rep + 1)
+        g.set_input(xin, x)
+        g.execute()
+        q, s = O.quantize_activations(x)
+        h_ref = om(q, s, B1, S1, 128)
+        q2, s2 = O.quantize_activations(h_ref.view(np.float16))
+        assert (u16(g.get_output(h)) == h_ref).all(), rep
+        assert (u16(g.get_output(y)) == om(q2, s2, B2, S2, 128)).all(), rep
+    g.close()
+
+
+def test_buffer_pool_survives_soft_reset(G):
+    """A model rebuilds its graph every token (model_qwen.cpp:142: soft_reset, then the same nodes):
+    after the first step the node buffers and the activation-quantization scratch come from the
+    pool, so the number of device allocations stops growing, and results stay right."""
+    rng = np.random.default_rng(17)
+    M, K, N = 8, 1024, 512      # M > 4: the quantized rows go through the graph's scratch
+    B, Bs = rand_weights_int8(rng, N, K)
+    g = G.CactusGraph()
+    w = g.input((N, K), G.INT8)
+    g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, K // 128, Bs)
+    counts = []
+    for step in range(4):
+        x = rand_act_f16(rng, M, K)
+        xin = g.input((M, K), G.FP16)
+        y = g.matmul(xin, w, True)
+        z = g.add(y, y)
+        g.set_input(xin, x)
+        g.execute()
+        q, s = O.quantize_activations(x)
+        ref = O.matmul_int8(q, s, B, Bs, 128)
+        assert (u16(g.get_output(y)) == ref).all()
+        assert (u16(g.get_output(z)) == O.binary("add", ref, ref)).all()
+        counts.append(g.pool_allocations())
+        g.soft_reset()
+        assert g.get_node_count() == 1     # the weight survives
+    assert counts[0] > 0 and counts[1] == counts[0] and counts[3] == counts[0], counts
+    g.close()

@@ -196,6 +196,77 @@ def test_matmul_int4_bit_exact(H, M, K, N):
     _check_matmul(H, M, K, N, 128, True, M + K + N + 1)
 
 
+# Deep-K shapes for every row-tile variant of the pipelined tile kernel, so that its steady-state loop
+# (the branch-free body with counted waits, entered once there are at least 5 K steps) runs under test:
+#   128-row tiles (256 or more of them), 64-row tiles (fewer), 32-row tiles (fewer than 128 64-row tiles).
+DEEP_K = [
+    (512, 1024, 8192),     # 128-row tiles, 8 K steps
+    (512, 8192, 8192),     # the benchmark's GEMM shape, 64 K steps
+    (256, 1024, 151936),   # lm_head of a batch-256 decode step: 128-row tiles, ragged last n tile
+    (512, 1024, 2048),     # 64-row tiles, 8 K steps
+    (200, 2048, 3072),     # 64-row tiles, ragged m
+    (256, 3072, 1024),     # 32-row tiles, 24 K steps (down projection of a prefill chunk)
+    (48, 4096, 640),       # 32-row tiles, ragged m tile
+]
+
+
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,N", DEEP_K)
+def test_matmul_tile_kernel_steady_state_bit_exact(H, M, K, N, int4):
+    rng = np.random.default_rng(M + K + N + 3 * int4)
+    B, Bs = (rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K)
+    A, As = O.quantize_activations(rand_act_f16(rng, M, K))
+    want = (O.matmul_int4 if int4 else O.matmul_int8)(A, As, B, Bs, 128)
+    got = bits((H.matmul_int4 if int4 else H.matmul_int8)(dev(A), dev(As), dev(B), dev(Bs), 128))
+    assert (got == want).all(), f"max ulp {ulp_diff_f16(got, want).max()}"
+
+
+@pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,N", [(512, 2048, 8192), (512, 1024, 2048), (96, 1024, 512)])
+def test_matmul_tile_kernel_group_sums_through_outputs(H, M, K, N, int4):
+    """The INT32 group sums of the pipelined tile kernel itself (the group-sum entry point runs the
+    plain tile kernel for M > 16): with activations in {-1, 0, 1} and small weights every group sum
+    is an integer that binary16 holds exactly, so a scale panel that is 1 in one group and 0
+    elsewhere makes the fp16 output equal that group's INT32 sum."""
+    rng = np.random.default_rng(M + N + int4)
+    G = K // 128
+    A = rng.integers(-1, 2, (M, K), dtype=np.int8)
+    As = np.ones((M,), np.float32)
+    if int4:
+        B = rng.integers(0, 256, (N, K // 2), dtype=np.uint8)
+        lo = (B & 0xF).astype(np.int16); hi = (B >> 4).astype(np.int16)
+        lo = np.where(lo > 7, lo - 16, lo); hi = np.where(hi > 7, hi - 16, hi)
+        Bu = np.empty((N, K), np.int16); Bu[:, 0::2] = lo; Bu[:, 1::2] = hi
+    else:
+        B = rng.integers(-15, 16, (N, K), dtype=np.int8)
+        Bu = B.astype(np.int16)
+    dA, dAs, dB = dev(A), dev(As), dev(B)
+    fn = H.matmul_int4 if int4 else H.matmul_int8
+    for g in sorted({0, 1, G // 2, G - 2, G - 1}):
+        Bs = np.zeros((N, G), np.float16)
+        Bs[:, g] = 16.0 if int4 else 1.0     # INT4: the kernels fold an exact 1/16 into the scale
+        got = fn(dA, dAs, dB, dev(Bs), 128).cpu().numpy().astype(np.float64)
+        sl = slice(g * 128, (g + 1) * 128)
+        want = A[:, sl].astype(np.int64) @ Bu[:, sl].astype(np.int64).T * (16 if int4 else 1)
+        assert np.abs(want).max() <= 2048 * (16 if int4 else 1)
+        assert np.array_equal(got, want.astype(np.float64)), g
+
+
+@pytest.mark.parametrize("int4", [False, True])
+def test_matmul_shared_activations_128_row_tiles(H, int4):
+    """q/k/v-style shared launch large enough for 128-row tiles in steady state (16 K steps)."""
+    rng = np.random.default_rng(31 + int4)
+    M, K, Ns = 512, 2048, (4096, 2048, 2048 + 40)
+    q, s = O.quantize_activations(rand_act_f16(rng, M, K))
+    ws = [(rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K) for N in Ns]
+    outs = [torch.full((M, N), 7.0, dtype=torch.float16, device="cuda") for N in Ns]
+    sh = H.MatmulShared([(dev(B), dev(Bs.view(np.float16)), o) for (B, Bs), o in zip(ws, outs)], 128, int4)
+    sh.run(dev(q), dev(s))
+    for (B, Bs), o in zip(ws, outs):
+        want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
+        assert np.array_equal(bits(o), want)
+
+
 @pytest.mark.parametrize("int4", [False, True])
 @pytest.mark.parametrize("M,K,N,gs", [(2, 128, 4, 64), (3, 256, 9, 64), (2, 512, 5, 256), (1, 192, 3, 128)])
 def test_matmul_other_group_sizes(H, M, K, N, gs, int4):
@@ -292,6 +363,107 @@ def test_host_pointer_family_matches_device_family(H):
     oq, os_ = O.quantize_kv(kv)
     assert (q == oq).all() and (s == os_).all()
     H.lib.cactus_hip_release_weights(None)
+
+
+def test_host_pointer_drop_ins_against_the_oracle(H):
+    """Every host-pointer entry with the reference's signature (kernel.h:45-50, 87-104, 148, 163), numpy
+    buffers in and out, against the oracle: INT4 matmul, FP16 matmul, both attentions, fp16_to_int8,
+    unpack_int4_to_int8."""
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L = H.lib
+    L.cactus_hip_clear_error()
+    rng = np.random.default_rng(12)
+    # cactus_matmul_int4
+    M, K, N = 3, 1024, 200
+    Bp, Bs = rand_weights_int4(rng, N, K)
+    A, As = O.quantize_activations(rand_act_f16(rng, M, K))
+    Cc = np.zeros((M, N), np.uint16)
+    L.cactus_hip_matmul_int4(p(A), p(As), p(Bp), p(Bs), p(Cc), M, K, N, 128)
+    assert (Cc == O.matmul_int4(A, As, Bp, Bs, 128)).all()
+    # cactus_matmul_f16
+    a = rng.uniform(-1, 1, (5, 256)).astype(np.float16); b = rng.uniform(-1, 1, (33, 256)).astype(np.float16)
+    c = np.zeros((5, 33), np.uint16)
+    L.cactus_hip_matmul_f16(p(a), p(b), p(c), 5, 256, 33)
+    exact = a.astype(np.float64) @ b.astype(np.float64).T
+    assert np.abs(f16(c) - exact).max() <= np.abs(f16(O.matmul_f16(a, b)) - exact).max() + np.abs(exact).max() * 2.0 ** -10
+    # cactus_attention_f16 (window + offset) and cactus_attention_hybrid_int8_fp16
+    q = rng.uniform(-1, 1, (1, 9, 4, 64)).astype(np.float16)
+    k = rng.uniform(-1, 1, (1, 50, 2, 64)).astype(np.float16); v = rng.uniform(-1, 1, (1, 50, 2, 64)).astype(np.float16)
+    out = np.zeros(q.shape, np.uint16)
+    L.cactus_hip_attention_f16(p(q), p(k), p(v), p(out), 1, 9, 50, 4, 2, 64, 0.0, None, 41, 16, 1)
+    want = O.attention_f16(q, k, v, 0.0, position_offset=41, window_size=16)
+    assert (np.abs(f16(out) - f16(want)) <= 2e-3 + 4e-3 * np.abs(f16(want))).all()
+    q, kq, vq, ks, vs, kn, vn = _hybrid_case(rng, 1, 2, 16, 8, 128, 300, 2)
+    out = np.zeros(q.shape, np.uint16)
+    L.cactus_hip_attention_hybrid_int8_fp16(p(q), p(kq), p(vq), p(ks), p(vs), p(kn), p(vn), p(out), 1, 2, 300, 2, 16, 8,
+                                            128, 0.0, 300, 1, 128)
+    want = O.attention_hybrid(q, kq, vq, ks, vs, kn, vn, 0.0, position_offset=300, cache_len=300)
+    assert (np.abs(f16(out) - f16(want)) <= 2e-3 + 4e-3 * np.abs(f16(want))).all()
+    # cactus_fp16_to_int8 (vector body half-to-even, tail half-away) and cactus_unpack_int4_to_int8
+    x = rng.uniform(-3, 3, 1003).astype(np.float16)
+    x[-3:] = np.array([0.5, 1.5, -2.5], np.float16)
+    d = np.zeros(1003, np.int8)
+    L.cactus_hip_fp16_to_int8(p(x), p(d), 1003, C.c_float(1.0))
+    assert (d == O.fp16_to_int8(x, 1.0)).all()
+    packed = rng.integers(0, 256, 517, dtype=np.uint8)
+    un = np.full(1033, 99, np.int8)
+    L.cactus_hip_unpack_int4_to_int8(p(packed), p(un), 1033)
+    assert (un == O.unpack_int4(packed, 1033)).all()
+    assert L.cactus_hip_last_error() == b""
+    L.cactus_hip_release_weights(None)
+
+
+def test_host_pointer_matmuls_see_new_contents_at_an_old_address(H):
+    """The reference's callers refill buffers in place: the FP16 matmul's b_transposed is a reused
+    transpose scratch (graph_ops_nn.cpp:222-228), and a heap buffer holding quantized weights can be
+    freed and handed out again.  A second call from the same address with other contents must
+    multiply the new contents."""
+    import ctypes as C
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L = H.lib
+    rng = np.random.default_rng(13)
+    a = rng.uniform(-1, 1, (4, 128)).astype(np.float16)
+    b = np.zeros((16, 128), np.float16)
+    c = np.zeros((4, 16), np.uint16)
+    for rep in range(3):
+        b[...] = rng.uniform(-1, 1, b.shape).astype(np.float16)      # same address, new data
+        L.cactus_hip_matmul_f16(p(a), p(b), p(c), 4, 128, 16)
+        exact = a.astype(np.float64) @ b.astype(np.float64).T
+        assert np.abs(f16(c) - exact).max() <= 0.02, rep
+    M, K, N = 2, 512, 64
+    A, As = O.quantize_activations(rand_act_f16(rng, M, K))
+    B = np.zeros((N, K), np.int8); Bs = np.zeros((N, K // 128), np.float16)
+    Cc = np.zeros((M, N), np.uint16)
+    for rep in range(3):
+        nb, nbs = rand_weights_int8(rng, N, K)
+        B[...] = nb; Bs[...] = nbs
+        L.cactus_hip_matmul_int8(p(A), p(As), p(B), p(Bs), p(Cc), M, K, N, 128)
+        assert (Cc == O.matmul_int8(A, As, B, Bs, 128)).all(), rep
+    L.cactus_hip_release_weights(None)
+
+
+def test_matmul_weights_of_two_gib_take_the_tile_kernel(H):
+    """The streaming (M <= 16) kernels address weights with 32-bit offsets below 2 GiB; a larger matrix
+    must be routed to a kernel that can address it, not read as zeros.  262144 x 8192 INT8 = 2 GiB:
+    sampled weight rows across the whole range, the last ones included, against the oracle, for
+    pre-quantized and for FP16 activations."""
+    N, K = 262144, 8192
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda", generator=g)
+    Bs = (0.01 + torch.rand((N, K // 128), device="cuda", generator=g) * 0.05).half()
+    rng = np.random.default_rng(4)
+    x = rand_act_f16(rng, 1, K)
+    A, As = O.quantize_activations(x)
+    c1 = H.matmul_int8(dev(A), dev(As), B, Bs)
+    c2 = H.matmul_f16act(dev(x), B, Bs)
+    rows = np.array([0, 5, 131071, 131072, 200001, N - 17, N - 1])
+    want = O.matmul_int8(A, As, host(B[rows]), bits(Bs[rows]), 128)
+    assert (bits(c1[:, rows].contiguous()) == want).all()
+    assert (bits(c2[:, rows].contiguous()) == want).all()
+    assert torch.equal(c1.view(torch.int16), c2.view(torch.int16))
+    del B, Bs
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------ FP16 matmul
