@@ -325,124 +325,8 @@ def sharded_decode(H, gen, world):
     return out
 
 
-def qwen3_decode_step(H, gen, batch, cache_len, layers=28, mixed=False):
-    """One decode step of the Qwen3-0.6B op sequence (hidden 1024, 16 q / 8 kv heads of 128, ffn
-    3072, vocab 151936: cactus/engine/engine.h:44-59; op order model_qwen.cpp:51-129, 169-172):
-    per layer input norm, q/k/v projections, per-head q/k norms, RoPE, attention over the INT8
-    cache plus the new FP16 token, KV quantization of the new token into the cache, o projection,
-    residual add, post-attention norm, gate/up, SiLU x up, down, residual add; then the final norm
-    and the lm_head, framed by the embedding lookup of the previous token (the table is the tied
-    lm_head weight) and the greedy sampler that picks the next one, so the token loop never leaves
-    the device -- with the back-to-back small ops going out as the library's one-launch
-    sequences (add + norm, q/k norm + RoPE, SiLU x up, K + V quantization).  The embedding lookup and the sampler are outside the timed step.  Synthetic
-    INT8 weights, distinct per layer (596 MB in total, streamed from HBM every step); the whole
-    step is one HIP graph.  mixed (batches above 4): the converter's MIXED policy for a model of this
-    size (python/src/precision_config.py:52-68, 110-124): INT8 for the embedding / lm_head, attn_q,
-    attn_k and the first and last two blocks, packed INT4 for attn_v, attn_output and the MLP elsewhere."""
-    Hd, Hq, Hkv, D, F, V = 1024, 16, 8, 128, 3072, 151936
-    if mixed and batch <= 4:
-        raise ValueError("the mixed-precision step is written for batches above 4")
-    is4 = lambda li: mixed and 2 <= li < layers - 2
-    mk = lambda N, K, i4=False: make_weights(K, N, i4, gen)
-    Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd, is4(li)), o=mk(Hd, Hq * D, is4(li)),
-               gate=mk(F, Hd, is4(li)), up=mk(F, Hd, is4(li)), down=mk(Hd, F, is4(li))) for li in range(layers)]
-    head = mk(V, Hd)
-    nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
-    for L in Ls:
-        L.update(in_norm=nw(Hd), post_norm=nw(Hd), q_norm=nw(D), k_norm=nw(D))
-    final_norm = nw(Hd)
-    theta, eps, pos = 1e6, 1e-6, cache_len
-    H.rope_reserve(D, theta, pos + 1)
-    half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
-    h0 = half(batch, Hd)                                                          # embedding output
-    tok = torch.randint(0, V, (batch,), dtype=torch.int32, device="cuda", generator=gen)
-    hid, x = half(batch, Hd), half(batch, Hd)
-    kc = torch.randint(-127, 128, (layers, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-    vc = torch.randint(-127, 128, (layers, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-    ksc = torch.rand((layers, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
-    vsc = torch.rand((layers, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
-    lens = torch.full((batch,), cache_len, dtype=torch.int32, device="cuda")
-    qo, ko, vo = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hkv * D)
-    oo, go, uo, do, logits = half(batch, Hd), half(batch, F), half(batch, F), half(batch, Hd), half(batch, V)
-    qr, kr, h2, xn2, act = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hd), half(batch, Hd), half(batch, F)
-    ao = [None]
-    i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
-    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
-    xq, xs, xq2, xs2, aq, asc = i8(batch, Hd), f32(batch), i8(batch, Hd), f32(batch), i8(batch, F), f32(batch)
-    batches = []
-    if batch <= 4:
-        for L in Ls:
-            batches.append((H.MatmulBatch([(x, L["q"][0], L["q"][1], qo), (x, L["k"][0], L["k"][1], ko),
-                                           (x, L["v"][0], L["v"][1], vo)], 128),
-                            H.MatmulBatch([(xn2, L["gate"][0], L["gate"][1], go), (xn2, L["up"][0], L["up"][1], uo)], 128)))
-
-    produced = []
-    if batch <= 4:   # norm / activation folded into the launch of the matmuls that read it
-        for L in Ls:
-            produced.append((H.MatmulProduced([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko),
-                                               (L["v"][0], L["v"][1], vo)], 128),
-                             H.MatmulProduced([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128),
-                             H.MatmulProduced([(L["down"][0], L["down"][1], do)], 128)))
-        head_p = H.MatmulProduced([(head[0], head[1], logits)], 128)
-    shared = []
-    if batch > 4:
-        for li, L in enumerate(Ls):
-            qkv = [(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko)]
-            if not is4(li):
-                qkv.append((L["v"][0], L["v"][1], vo))
-            shared.append((H.MatmulShared(qkv, 128),
-                           H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128,
-                                          int4=is4(li))))
-
-    def proj(inp, w, out, int4=False):
-        H.matmul_f16act(inp, w[0], w[1], 128, int4=int4, out=out)
-
-    def step():
-        H.embedding(head[0], tok, head[1], 128, out=h0, check=False)
-        if batch <= 4:
-            pass                         # the first norm rides in layer 0's q/k/v launch
-        else:
-            H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
-        res = h0
-        for li, L in enumerate(Ls):
-            if batch <= 4:
-                # residual add of the previous block + this block's input norm + q/k/v, one launch
-                if li == 0:
-                    produced[li][0].run_norm(h0, None, L["in_norm"], eps)
-                else:
-                    produced[li][0].run_norm(h2, do, L["in_norm"], eps, hid)
-                    res = hid
-            else:
-                shared[li][0].run(xq, xs)      # quantized by the norm launch that produced it
-                if is4(li):
-                    H.matmul_int4(xq, xs, L["v"][0], L["v"][1], 128, out=vo)
-            # q/k norm + RoPE, and the new token's K and V join the cache (slot cache_len of every
-            # sequence; the attention of this step reads them as FP16), one launch
-            H.qk_norm_rope_kv_append(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D),
-                                     L["q_norm"], L["k_norm"], eps, theta, pos, kc[li], vc[li], ksc[li], vsc[li], lens,
-                                     128, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
-            a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[li], vc[li], ksc[li], vsc[li],
-                                           kr.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
-            proj(a.view(batch, Hq * D), L["o"], oo, is4(li))
-            nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
-            if batch <= 4:
-                produced[li][1].run_norm(res, oo, L["post_norm"], eps, h2)   # add + norm + gate/up
-                produced[li][2].run_act(go, uo, "silu")                      # silu x up + down
-            else:   # norm / activation launches that also quantize the next matmul's input rows
-                H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
-                shared[li][1].run(xq2, xs2)
-                H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
-                (H.matmul_int4 if is4(li) else H.matmul_int8)(aq, asc, L["down"][0], L["down"][1], 128, out=do)
-                last = li + 1 == layers   # the lm_head below takes the FP16 row
-                H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq,
-                                     out_scales=xs)
-                res = hid
-        if batch <= 4:   # last residual add + final norm + lm_head
-            head_p.run_norm(h2, do, final_norm, eps, hid)
-        else:
-            proj(x, head, logits)
-        H.sample_greedy(logits, out=tok)
-
+def _time_graph_of(step, reps=5):
+    """One call of step() captured into a HIP graph (after one plain call that sizes workspaces), replayed."""
     step()
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -452,16 +336,28 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28, mixed=False):
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5):
+    for _ in range(reps):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
-    wbytes = gemv_bytes(batch, Hd, V)
-    for li in range(layers):
-        wbytes += sum(gemv_bytes(batch, K, N) for N, K in ((Hq * D, Hd), (Hkv * D, Hd)))
-        wbytes += sum(gemv_bytes(batch, K, N, is4(li)) for N, K in ((Hkv * D, Hd), (Hd, Hq * D), (F, Hd), (F, Hd), (Hd, F)))
-    kvbytes = layers * batch * 2 * cache_len * Hkv * (D + 4)
+    return e0.elapsed_time(e1) / reps
+
+
+def qwen3_decode_step(H, gen, batch, cache_len, layers=28, mixed=False):
+    """One decode step of the Qwen3-0.6B op sequence for `batch` sequences that each hold `cache_len`
+    cached tokens (cactus_amd/steps.py: Qwen3Decode; embedding lookup to greedy sampler, token ids stay on
+    the device).  Synthetic weights, distinct per layer (596 MB of INT8 in total, streamed from HBM every
+    step); the whole step is one HIP graph, replayed at fixed positions so every replay does the same work.
+    mixed: the converter's MIXED policy (INT4 attn_v / attn_output / MLP in blocks 2..25)."""
+    from cactus_amd import steps as ST
+    cfg = dict(ST.QWEN3_0P6B, layers=layers)
+    w = ST.qwen3_synthetic_weights(gen, cfg, mixed)
+    dec = ST.Qwen3Decode(w, cfg, batch, cache_len + 1, cache_gen=gen)
+    dec.kv.set_positions([cache_len] * batch)
+    dec.kv.tok.copy_(torch.randint(0, cfg["vocab"], (batch,), dtype=torch.int32, device="cuda", generator=gen))
+    ms = _time_graph_of(lambda: dec.step(advance=False))
+    wbytes = dec.weight_bytes()
+    kvbytes = layers * batch * 2 * cache_len * cfg["kv_heads"] * (cfg["head_dim"] + 4)
     return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
             "cache_len": cache_len, "GBps": round((wbytes + kvbytes) / (ms * 1e-3) / 1e9, 1),
             "note": "a whole Qwen3-0.6B decode step: embedding lookup to greedy sampler, token ids stay on the device"
@@ -469,97 +365,18 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28, mixed=False):
 
 
 def lfm2_decode_step(H, gen, batch, cache_len):
-    """One decode step of the LFM2-1.2B op sequence (model_lfm2.cpp:123-331) for `batch` independent
-    sequences on one GPU: 16 blocks, 10 with the short convolution (in-projection to 3 x hidden,
-    B*X / 3-tap causal conv over the carried rows / C-gate in one launch, out-projection) and 6 with
-    attention (q/k/v, per-head q/k norms, RoPE, INT8 cache append, attention over the cache, o), each
-    followed by residual add, norm, gate/up, SiLU x up, down, residual add; final norm, lm_head,
-    greedy sampler; embedding lookup of the previous token in front.  Dimensions are the public model
-    card's (hidden 2048, ffn 8192, 32 q / 8 kv heads of 64, vocab 65536, conv_L_cache 3, attention in
-    blocks 2, 5, 8, 10, 12, 14): the reference reads them from config.txt.  Synthetic INT8 weights, one
-    HIP graph per step."""
-    Hd, Hq, Hkv, D, F, V, layers, Kc, Wc = 2048, 32, 8, 64, 8192, 65536, 16, 3, 2
-    attn_at = (2, 5, 8, 10, 12, 14)
-    mk = lambda N, K: make_weights(K, N, False, gen)
-    nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
-    half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
-    Ls = []
-    for li in range(layers):
-        L = dict(gate=mk(F, Hd), up=mk(F, Hd), down=mk(Hd, F), in_norm=nw(Hd), post_norm=nw(Hd), attn=li in attn_at)
-        if L["attn"]:
-            L.update(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), q_norm=nw(D), k_norm=nw(D))
-        else:
-            L.update(in_proj=mk(3 * Hd, Hd), out_proj=mk(Hd, Hd),
-                     conv_w=((torch.rand((Hd, Kc), device="cuda", generator=gen) - 0.5)).half(),
-                     state=((torch.rand((batch, Wc, Hd), device="cuda", generator=gen) - 0.5)).half())
-        Ls.append(L)
-    head, final_norm = mk(V, Hd), nw(Hd)
-    theta, eps, pos = 1e6, 1e-5, cache_len
-    H.rope_reserve(D, theta, pos + 1)
-    na = len(attn_at)
-    kc = torch.randint(-127, 128, (na, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-    vc = torch.randint(-127, 128, (na, batch, cache_len + 1, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-    ksc = torch.rand((na, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
-    vsc = torch.rand((na, batch, cache_len + 1, Hkv, 1), device="cuda", generator=gen) * 0.02
-    lens = torch.full((batch,), cache_len, dtype=torch.int32, device="cuda")
-    tok = torch.randint(0, V, (batch,), dtype=torch.int32, device="cuda", generator=gen)
-    h0, hid, x, h2 = half(batch, Hd), half(batch, Hd), half(batch, Hd), half(batch, Hd)
-    qo, ko, vo, qr, kr = half(batch, Hq * D), half(batch, Hkv * D), half(batch, Hkv * D), half(batch, Hq * D), half(batch, Hkv * D)
-    ipj, gated, oo, go, uo, do, logits = half(batch, 3 * Hd), half(batch, Hd), half(batch, Hd), half(batch, F), half(batch, F), half(batch, Hd), half(batch, V)
-    i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
-    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
-    xq, xs, xq2, xs2, aq, asc = i8(batch, Hd), f32(batch), i8(batch, Hd), f32(batch), i8(batch, F), f32(batch)
-    cq, cs = i8(batch, Hd), f32(batch)
-    for L in Ls:
-        if L["attn"]:
-            L["qkv"] = H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko), (L["v"][0], L["v"][1], vo)], 128)
-        L["gu"] = H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128)
-
-    def step():
-        H.embedding(head[0], tok, head[1], 128, out=h0, check=False)
-        H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
-        res, ai = h0, 0
-        for li, L in enumerate(Ls):
-            if L["attn"]:
-                L["qkv"].run(xq, xs)
-                H.qk_norm_rope_kv_append(qo.view(batch, 1, Hq, D), ko.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D),
-                                         L["q_norm"], L["k_norm"], eps, theta, pos, kc[ai], vc[ai], ksc[ai], vsc[ai], lens,
-                                         128, out_q=qr.view(batch, 1, Hq, D), out_k=kr.view(batch, 1, Hkv, D))
-                a = H.attention_hybrid_batched(qr.view(batch, 1, Hq, D), kc[ai], vc[ai], ksc[ai], vsc[ai],
-                                               kr.view(batch, 1, Hkv, D), vo.view(batch, 1, Hkv, D), 0.0, lens, lens)
-                H.matmul_f16act(a.view(batch, Hq * D), L["o"][0], L["o"][1], 128, out=oo)
-                ai += 1
-            else:
-                H.matmul_int8(xq, xs, L["in_proj"][0], L["in_proj"][1], 128, out=ipj)
-                # B * X, convolution over the carried rows, C gate, state update and the out-projection's
-                # row quantization, one launch
-                H.lfm2_conv_gate_quant(ipj.view(batch, 1, 3 * Hd), L["conv_w"], L["state"], out_q=cq, out_scales=cs)
-                H.matmul_int8(cq, cs, L["out_proj"][0], L["out_proj"][1], 128, out=oo)
-            H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
-            L["gu"].run(xq2, xs2)
-            H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
-            H.matmul_int8(aq, asc, L["down"][0], L["down"][1], 128, out=do)
-            last = li + 1 == layers
-            nxt = final_norm if last else Ls[li + 1]["in_norm"]
-            H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq, out_scales=xs)
-            res = hid
-        H.matmul_f16act(x, head[0], head[1], 128, out=logits)
-        H.sample_greedy(logits, out=tok)
-
-    step()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        step()
-    g.replay()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
+    """One decode step of the LFM2-1.2B op sequence for `batch` independent sequences on one GPU
+    (cactus_amd/steps.py: Lfm2Decode; 10 blocks with the short convolution, 6 with attention; dimensions from
+    the public model card).  Synthetic INT8 weights, one HIP graph per step."""
+    from cactus_amd import steps as ST
+    cfg = ST.LFM2_1P2B
+    w = ST.lfm2_synthetic_weights(gen, batch, cfg)
+    dec = ST.Lfm2Decode(w, cfg, batch, cache_len + 1, cache_gen=gen)
+    for st in dec.state.values():
+        st.copy_((torch.rand(st.shape, device="cuda", generator=gen) - 0.5).half())
+    dec.kv.set_positions([cache_len] * batch)
+    dec.kv.tok.copy_(torch.randint(0, cfg["vocab"], (batch,), dtype=torch.int32, device="cuda", generator=gen))
+    ms = _time_graph_of(lambda: dec.step(advance=False))
     return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
             "cache_len": cache_len,
             "note": "a whole LFM2-1.2B-shape decode step (10 conv + 6 attention blocks): embedding lookup to greedy "
@@ -567,77 +384,20 @@ def lfm2_decode_step(H, gen, batch, cache_len):
 
 
 def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28):
-    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence, the way the engine walks a
-    long prompt (Model::prefill, engine_model.cpp:148-219: chunks of 256 tokens, the first against
-    nothing, the others against the INT8 cache): per layer norm + activation quantization, q/k/v GEMM,
-    q/k norm + RoPE + cache append, attention (FP16 for chunk 0, INT8-cache hybrid after), o GEMM,
-    add + norm, gate/up GEMM, SiLU x up, down GEMM, add; after the last chunk the final norm, the
-    lm_head on the last token and the greedy sampler.  One HIP graph per chunk, replayed in order."""
-    Hd, Hq, Hkv, D, F, V = 1024, 16, 8, 128, 3072, 151936
-    mk = lambda N, K: make_weights(K, N, False, gen)
-    Ls = [dict(q=mk(Hq * D, Hd), k=mk(Hkv * D, Hd), v=mk(Hkv * D, Hd), o=mk(Hd, Hq * D), gate=mk(F, Hd),
-               up=mk(F, Hd), down=mk(Hd, F)) for _ in range(layers)]
-    head = mk(V, Hd)
-    nw = lambda n: (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
-    for L in Ls:
-        L.update(in_norm=nw(Hd), post_norm=nw(Hd), q_norm=nw(D), k_norm=nw(D))
-    final_norm = nw(Hd)
-    theta, eps = 1e6, 1e-6
-    H.rope_reserve(D, theta, tokens + 1)
-    half = lambda *shape: torch.empty(shape, dtype=torch.float16, device="cuda")
-    i8 = lambda *shape: torch.empty(shape, dtype=torch.int8, device="cuda")
-    f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device="cuda")
-    M = chunk
-    nchunks = tokens // chunk
-    toks = torch.randint(0, V, (nchunks, M), dtype=torch.int32, device="cuda", generator=gen)
-    kc, vc = i8(layers, 1, tokens, Hkv, D), i8(layers, 1, tokens, Hkv, D)
-    ksc, vsc = f32(layers, 1, tokens, Hkv, 1), f32(layers, 1, tokens, Hkv, 1)
-    h0, hid, h2, x = half(M, Hd), half(M, Hd), half(M, Hd), half(M, Hd)
-    qo, ko, vo, qr, kr = half(M, Hq * D), half(M, Hkv * D), half(M, Hkv * D), half(M, Hq * D), half(M, Hkv * D)
-    ao, oo, go, uo, do = half(1, M, Hq, D), half(M, Hd), half(M, F), half(M, F), half(M, Hd)
-    logits, tok = half(1, V), torch.empty((1,), dtype=torch.int32, device="cuda")
-    xq, xs, xq2, xs2, aq, asc, oq, os_ = (i8(M, Hd), f32(M), i8(M, Hd), f32(M), i8(M, F), f32(M), i8(M, Hq * D),
-                                          f32(M))
-    shared = [(H.MatmulShared([(L["q"][0], L["q"][1], qo), (L["k"][0], L["k"][1], ko), (L["v"][0], L["v"][1], vo)], 128),
-               H.MatmulShared([(L["gate"][0], L["gate"][1], go), (L["up"][0], L["up"][1], uo)], 128)) for L in Ls]
-    slots = [torch.full((1,), c * chunk, dtype=torch.int32, device="cuda") for c in range(nchunks)]
-
-    def run_chunk(c):
-        cache = c * chunk
-        H.embedding(head[0], toks[c], head[1], 128, out=h0, check=False)
-        H.add_rms_norm_quant(h0, None, Ls[0]["in_norm"], eps, out_q=xq, out_scales=xs)
-        res = h0
-        for li, L in enumerate(Ls):
-            shared[li][0].run(xq, xs)
-            q4, k4, v4 = qo.view(1, M, Hq, D), ko.view(1, M, Hkv, D), vo.view(1, M, Hkv, D)
-            H.qk_norm_rope_kv_append(q4, k4, v4, L["q_norm"], L["k_norm"], eps, theta, cache, kc[li], vc[li], ksc[li],
-                                     vsc[li], slots[c], 128, out_q=qr.view(1, M, Hq, D), out_k=kr.view(1, M, Hkv, D))
-            if cache == 0:
-                a = H.attention_f16(qr.view(1, M, Hq, D), kr.view(1, M, Hkv, D), v4, 0.0, out=ao)
-            else:
-                a = H.attention_hybrid(qr.view(1, M, Hq, D), kc[li, 0, :cache], vc[li, 0, :cache], ksc[li, 0, :cache],
-                                       vsc[li, 0, :cache], kr.view(1, M, Hkv, D), v4, 0.0, position_offset=cache, out=ao)
-            H.quantize_activations(a.view(M, Hq * D), out_q=oq, out_scales=os_)
-            H.matmul_int8(oq, os_, L["o"][0], L["o"][1], 128, out=oo)
-            H.add_rms_norm_quant(res, oo, L["post_norm"], eps, out_sum=h2, out_q=xq2, out_scales=xs2)
-            shared[li][1].run(xq2, xs2)
-            H.silu_multiply_quant(go, uo, out_q=aq, out_scales=asc)
-            H.matmul_int8(aq, asc, L["down"][0], L["down"][1], 128, out=do)
-            nxt = Ls[li + 1]["in_norm"] if li + 1 < layers else final_norm
-            last = li + 1 == layers and c + 1 == nchunks
-            H.add_rms_norm_quant(h2, do, nxt, eps, out_sum=hid, out_norm=x if last else None, out_q=xq, out_scales=xs)
-            res = hid
-        if c + 1 == nchunks:
-            H.matmul_f16act(x[M - 1:M], head[0], head[1], 128, out=logits)
-            H.sample_greedy(logits, out=tok)
-
+    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence (cactus_amd/steps.py: Qwen3Prefill),
+    one HIP graph per chunk, replayed in order."""
+    from cactus_amd import steps as ST
+    cfg = dict(ST.QWEN3_0P6B, layers=layers)
+    w = ST.qwen3_synthetic_weights(gen, cfg)
+    pf = ST.Qwen3Prefill(w, cfg, tokens, chunk)
+    pf.toks.copy_(torch.randint(0, cfg["vocab"], pf.toks.shape, dtype=torch.int32, device="cuda", generator=gen))
     graphs = []
-    for c in range(nchunks):
-        run_chunk(c)                      # sizes workspaces, builds RoPE rows
+    for c in range(pf.nchunks):
+        pf.run_chunk(c)                   # sizes workspaces, builds RoPE rows
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            run_chunk(c)
+            pf.run_chunk(c)
         graphs.append(g)
     for g in graphs:
         g.replay()

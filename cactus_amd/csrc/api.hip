@@ -695,6 +695,78 @@ int cactus_hip_qk_norm_rope_kv_append_f16_dev(const cactus_half_t* q, const cact
 }
 
 namespace {
+int check_window(const char* who, size_t window, size_t sink, size_t seq_len, size_t max_slots) {
+    if (window == 0) return CACTUS_HIP_OK;
+    char msg[160];
+    if (sink >= window || window > max_slots || seq_len > window - sink || window > 0x7FFFFFFFull) {
+        snprintf(msg, sizeof msg, "%s: needs sink < window <= max_slots and at most window - sink new tokens per call", who);
+        return fail(CACTUS_HIP_EINVAL, msg);
+    }
+    return CACTUS_HIP_OK;
+}
+}  // namespace
+
+int cactus_hip_qk_norm_rope_seq_f16_dev(const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v,
+                                        const cactus_half_t* q_weight, const cactus_half_t* k_weight,
+                                        cactus_half_t* q_output, cactus_half_t* k_output, int8_t* k_cache,
+                                        int8_t* v_cache, float* k_scales, float* v_scales, const int32_t* positions,
+                                        size_t max_position, size_t batch_size, size_t seq_len, size_t num_q_heads,
+                                        size_t num_kv_heads, size_t head_dim, float eps, float theta, size_t group_size,
+                                        size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+                                        size_t window, size_t sink, void* stream) {
+    if (batch_size * seq_len * head_dim == 0 || num_q_heads + num_kv_heads == 0) return CACTUS_HIP_OK;
+    if (!q || !k || !q_weight || !k_weight || !q_output || !k_output || !positions)
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_seq: null operand");
+    if (v && (!k_cache || !v_cache || !k_scales || !v_scales))
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_seq: v given without the cache to append to");
+    if (group_size == 0 || group_size > (size_t(1) << 20)) return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_seq: bad group_size");
+    if ((head_dim & 1) || head_dim > 2048) return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_seq: head_dim must be even and <= 2048");
+    if (seq_len > (size_t(1) << 30) || num_q_heads > (size_t(1) << 20) || num_kv_heads > (size_t(1) << 20) ||
+        max_position >= (size_t(1) << 30))
+        return fail(CACTUS_HIP_EINVAL, "qk_norm_rope_seq: dimension too large");
+    if (v) {
+        int rc = check_window("qk_norm_rope_seq", window, sink, seq_len, max_slots);
+        if (rc != CACTUS_HIP_OK) return rc;
+    }
+    const uint16_t *c, *s;
+    int rc = rope_rows(head_dim, theta, 0, max_position + 1, &c, &s);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_qk_norm_rope_seq(q, k, v, q_weight, k_weight, q_output, k_output, c, s, k_cache, v_cache, k_scales,
+                                           v_scales, positions, max_position, batch_size, seq_len, num_q_heads,
+                                           num_kv_heads, head_dim, eps, group_size, cache_batch_stride, scale_batch_stride,
+                                           max_slots, window, sink, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "qk_norm_rope_seq launch", e);
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_kv_append_windowed_dev(const cactus_half_t* k_new, const cactus_half_t* v_new, int8_t* k_cache,
+                                      int8_t* v_cache, float* k_scales, float* v_scales, const int32_t* positions,
+                                      size_t batch_size, size_t seq_len, size_t kv_heads, size_t head_dim,
+                                      size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride,
+                                      size_t max_slots, size_t window, size_t sink, void* stream) {
+    if (batch_size * seq_len * kv_heads * head_dim == 0) return CACTUS_HIP_OK;
+    if (!k_new || !v_new || !k_cache || !v_cache || !k_scales || !v_scales || !positions || group_size == 0)
+        return fail(CACTUS_HIP_EINVAL, "kv_append_windowed: bad operand");
+    int rc = check_window("kv_append_windowed", window, sink, seq_len, max_slots);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_kv_append_windowed(k_new, k_cache, k_scales, v_new, v_cache, v_scales, positions, batch_size,
+                                             seq_len, kv_heads, head_dim, group_size, cache_batch_stride,
+                                             scale_batch_stride, max_slots, window, sink, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "kv_append_windowed launch", e);
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_kv_positions_advance_dev(int32_t* positions, int32_t* cache_lens, size_t batch_size, size_t advance,
+                                        size_t window, void* stream) {
+    if (batch_size == 0) return CACTUS_HIP_OK;
+    if (!positions) return fail(CACTUS_HIP_EINVAL, "kv_positions_advance: null positions");
+    if (advance > 0x7FFFFFFFull || window > 0x7FFFFFFFull) return fail(CACTUS_HIP_EINVAL, "kv_positions_advance: too large");
+    hipError_t e = launch_kv_positions_advance(positions, cache_lens, batch_size, advance, window, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "kv_positions_advance launch", e);
+    return CACTUS_HIP_OK;
+}
+
+namespace {
 int unary_dev(int op, const char* name, const cactus_half_t* in, cactus_half_t* out, size_t n, void* stream) {
     if (n == 0) return CACTUS_HIP_OK;
     if (!in || !out) return fail(CACTUS_HIP_EINVAL, name);

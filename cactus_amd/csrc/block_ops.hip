@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) void rope_kernel(const uint16_t* __restrict__ 
 // (engine_cache.cpp:234-267): the rotated k row and the v row (rows [tokens*(Hq+Hkv),
 // tokens*(Hq+2*Hkv)) of the launch) are quantized per group of `gs` dims with the arithmetic of
 // kv_quant_kernel and stored at slot slots[b] + s of sequence b (slots == nullptr: row for row).
+// With `ap.positions` set, sequence b's tokens have absolute positions positions[b] + s: RoPE reads
+// the table row of that position (cos_t / sin_t then start at position 0 and hold rows up to
+// max_position) and an appended row goes to ring_slot(position, window, sink).
 struct KvAppendArgs {
     const uint16_t* v = nullptr;
     int8_t* kc = nullptr;
@@ -190,8 +193,10 @@ struct KvAppendArgs {
     float* ks = nullptr;
     float* vs = nullptr;
     const int32_t* slots = nullptr;
+    const int32_t* positions = nullptr;
     size_t cache_batch_stride = 0, scale_batch_stride = 0, max_slots = 0;
     int gs = 128;
+    int window = 0, sink = 0, max_position = 0;
 };
 
 // one row of D halves in LDS -> int8 + one scale per group, by the 16 lanes of a group; lane l
@@ -239,10 +244,11 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
     // where a k / v row goes in the cache
     size_t doff = hr * D, soff = hr * (size_t)((D + ap.gs - 1) / ap.gs);
     bool place = live && ap.v != nullptr && !is_q;
-    if (place && ap.slots != nullptr) {
+    if (place && (ap.slots != nullptr || ap.positions != nullptr)) {
         const size_t b = token / seq_len, sq = token % seq_len, h = hr - token * Hkv;
-        const long sl = (long)ap.slots[b] + (long)sq;
-        place = ap.slots[b] >= 0 && (size_t)sl < ap.max_slots;
+        const long first = ap.positions ? ap.positions[b] : ap.slots[b];
+        const long sl = ap.positions ? ring_slot(first + (long)sq, ap.window, ap.sink) : first + (long)sq;
+        place = first >= 0 && (size_t)sl < ap.max_slots;
         const size_t slot = place ? (size_t)sl : 0;
         doff = b * ap.cache_batch_stride + (slot * Hkv + h) * D;
         soff = b * ap.scale_batch_stride + (slot * Hkv + h) * (size_t)((D + ap.gs - 1) / ap.gs);
@@ -288,7 +294,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
         if (place) quant_row_groups(nrm, D, ap.gs, ap.vc + doff, ap.vs + soff, l);
         return;
     }
-    const int half_dim = D / 2, s = (int)(token % seq_len);
+    const int half_dim = D / 2;
+    int s = (int)(token % seq_len);
+    if (ap.positions) s = max(0, min(ap.positions[token / seq_len] + s, ap.max_position));
     for (int i = l; i < half_dim; i += 16) {
         const uint16_t cb = cos_t[(size_t)s * half_dim + i], sb = sin_t[(size_t)s * half_dim + i];
         const uint16_t x1b = nrm[i], x2b = nrm[half_dim + i];
@@ -745,6 +753,23 @@ hipError_t launch_qk_norm_rope_append(const uint16_t* q, const uint16_t* k, cons
     ap.v = v; ap.kc = kc; ap.vc = vc; ap.ks = ks; ap.vs = vs; ap.slots = slots;
     ap.cache_batch_stride = cache_batch_stride; ap.scale_batch_stride = scale_batch_stride; ap.max_slots = max_slots;
     ap.gs = (int)gs;
+    qk_norm_rope_kernel<<<dim3((unsigned)((total + 15) / 16)), dim3(256), 16 * D * sizeof(uint16_t), st>>>(
+        q, k, qw, kw, q_out, k_out, cos_t, sin_t, tokens, (int)Hq, (int)Hkv, (int)D, (int)seq_len, eps, ap);
+    return hipGetLastError();
+}
+
+hipError_t launch_qk_norm_rope_seq(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* qw,
+                                   const uint16_t* kw, uint16_t* q_out, uint16_t* k_out, const uint16_t* cos_t,
+                                   const uint16_t* sin_t, int8_t* kc, int8_t* vc, float* ks, float* vs,
+                                   const int32_t* positions, size_t max_position, size_t batch, size_t seq_len,
+                                   size_t Hq, size_t Hkv, size_t D, float eps, size_t gs, size_t cache_batch_stride,
+                                   size_t scale_batch_stride, size_t max_slots, size_t window, size_t sink,
+                                   hipStream_t st) {
+    const size_t tokens = batch * seq_len, total = tokens * (Hq + (v ? 2 : 1) * Hkv);
+    KvAppendArgs ap;
+    ap.v = v; ap.kc = kc; ap.vc = vc; ap.ks = ks; ap.vs = vs; ap.positions = positions;
+    ap.cache_batch_stride = cache_batch_stride; ap.scale_batch_stride = scale_batch_stride; ap.max_slots = max_slots;
+    ap.gs = (int)gs; ap.window = (int)window; ap.sink = (int)sink; ap.max_position = (int)max_position;
     qk_norm_rope_kernel<<<dim3((unsigned)((total + 15) / 16)), dim3(256), 16 * D * sizeof(uint16_t), st>>>(
         q, k, qw, kw, q_out, k_out, cos_t, sin_t, tokens, (int)Hq, (int)Hkv, (int)D, (int)seq_len, eps, ap);
     return hipGetLastError();

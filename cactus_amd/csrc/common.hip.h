@@ -53,6 +53,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Slot of the token with absolute index `abs` in a cache of `window` slots whose first `sink` slots
+// keep the first tokens (KVCache, engine_cache.cpp:268-329: first `sink` tokens + the most recent
+// `window - sink`): tokens fill slots 0..window-1 in order, then each new token overwrites the oldest
+// of the recent ones, which is the slot its index maps to going round the recent region.  The cache
+// then holds the tokens the reference's sliding window holds, rotated.  window == 0: no window.
+__host__ __device__ __forceinline__ long ring_slot(long abs, long window, long sink) {
+    if (window <= 0 || abs < window) return abs;
+    return sink + (abs - window) % (window - sink);
+}
+
 // Round to nearest, ties to even (NEON vcvtnq_s32_f32), as an int.
 __device__ __forceinline__ int rne_i32(float v) { return (int)rintf(v); }
 

@@ -25,6 +25,15 @@ hipError_t launch_kv_append(const uint16_t* k_src, int8_t* k_cache, float* k_sca
                             int8_t* v_cache, float* v_scales, size_t batch, size_t heads, size_t D, size_t gs,
                             const int32_t* slots, size_t cache_batch_stride, size_t scale_batch_stride,
                             size_t max_slots, hipStream_t st);
+// seq_len new tokens per sequence at absolute positions positions[b] + s, each stored at
+// ring_slot(position, window, sink) of its sequence's cache (window 0: slot = position)
+hipError_t launch_kv_append_windowed(const uint16_t* k_src, int8_t* k_cache, float* k_scales, const uint16_t* v_src,
+                                     int8_t* v_cache, float* v_scales, const int32_t* positions, size_t batch,
+                                     size_t seq_len, size_t heads, size_t D, size_t gs, size_t cache_batch_stride,
+                                     size_t scale_batch_stride, size_t max_slots, size_t window, size_t sink,
+                                     hipStream_t st);
+hipError_t launch_kv_positions_advance(int32_t* positions, int32_t* cache_lens, size_t batch, size_t advance,
+                                       size_t window, hipStream_t st);
 hipError_t launch_unpack_int4(const uint8_t* packed, int8_t* unpacked, size_t count, hipStream_t st);
 
 // matmul_skinny.hip: M <= 16, group_size == 128.  B is int8[N,K] or packed uint8[N,K/2].
@@ -161,6 +170,15 @@ hipError_t launch_qk_norm_rope_append(const uint16_t* q, const uint16_t* k, cons
                                       const int32_t* slots, size_t batch, size_t seq_len, size_t Hq, size_t Hkv,
                                       size_t D, float eps, size_t gs, size_t cache_batch_stride,
                                       size_t scale_batch_stride, size_t max_slots, hipStream_t st);
+// per-sequence positions (device int32 [batch]); cos_t / sin_t start at position 0 and hold rows up to
+// max_position; v == nullptr: no cache append
+hipError_t launch_qk_norm_rope_seq(const uint16_t* q, const uint16_t* k, const uint16_t* v, const uint16_t* qw,
+                                   const uint16_t* kw, uint16_t* q_out, uint16_t* k_out, const uint16_t* cos_t,
+                                   const uint16_t* sin_t, int8_t* kc, int8_t* vc, float* ks, float* vs,
+                                   const int32_t* positions, size_t max_position, size_t batch, size_t seq_len,
+                                   size_t Hq, size_t Hkv, size_t D, float eps, size_t gs, size_t cache_batch_stride,
+                                   size_t scale_batch_stride, size_t max_slots, size_t window, size_t sink,
+                                   hipStream_t st);
 hipError_t launch_row_quant(int mode, const uint16_t* a, const uint16_t* b, const uint16_t* w, uint16_t* sum_out,
                             uint16_t* y_out, int8_t* q_out, float* scales_out, size_t rows, size_t dims, float eps,
                             hipStream_t st);

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void kv_quant_kernel(
     const uint16_t* __restrict__ src0, int8_t* __restrict__ dst0, float* __restrict__ scales0,
     const uint16_t* __restrict__ src1, int8_t* __restrict__ dst1, float* __restrict__ scales1,
     size_t rows, size_t D, size_t gs, size_t G, const int32_t* __restrict__ slots, size_t heads,
-    size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots) {
+    size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+    const int32_t* __restrict__ positions = nullptr, size_t seq_len = 1, int window = 0, int sink = 0) {
     const uint16_t* __restrict__ src = blockIdx.y ? src1 : src0;
     int8_t* __restrict__ dst = blockIdx.y ? dst1 : dst0;
     float* __restrict__ scales = blockIdx.y ? scales1 : scales0;
@@ -120,14 +121,17 @@ __global__ __launch_bounds__(256) void kv_quant_kernel(
     const size_t cnt = live ? ((D - start < gs) ? D - start : gs) : 0;
     const size_t cnt8 = (cnt / 8) * 8;
     const uint16_t* s = src + row * D + start;
-    // Destination: row for row, or (append form) source row (b, h) -> slot slots[b] of sequence
-    // b's cache; a slot outside [0, max_slots) stores nothing.
+    // Destination: row for row, or (append form) into the slots of each sequence's cache; a slot
+    // outside [0, max_slots) stores nothing.
     size_t doff = row * D + start, soff = row * G;
     bool place = true;
-    if (slots != nullptr && live) {
-        const size_t b = row / heads, h = row - b * heads;
-        const long sl = slots[b];
-        place = sl >= 0 && (size_t)sl < max_slots;
+    if ((slots != nullptr || positions != nullptr) && live) {
+        // source row ((b, s), h): token s of sequence b goes to slot slots[b] + s, or to the ring slot
+        // of its absolute position positions[b] + s
+        const size_t tok = row / heads, h = row - tok * heads, b = tok / seq_len, sq = tok - b * seq_len;
+        const long first = positions ? positions[b] : slots[b];
+        const long sl = positions ? ring_slot(first + (long)sq, window, sink) : first + (long)sq;
+        place = first >= 0 && (size_t)sl < max_slots;
         const size_t slot = place ? (size_t)sl : 0;
         doff = b * cache_batch_stride + (slot * heads + h) * D + start;
         soff = b * scale_batch_stride + (slot * heads + h) * G;
@@ -256,6 +260,40 @@ hipError_t launch_kv_append(const uint16_t* k_src, int8_t* k_cache, float* k_sca
     kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(
         k_src, k_cache, k_scales, v_src, v_cache, v_scales, rows, D, gs, G, slots, heads, cache_batch_stride,
         scale_batch_stride, max_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_kv_append_windowed(const uint16_t* k_src, int8_t* k_cache, float* k_scales, const uint16_t* v_src,
+                                     int8_t* v_cache, float* v_scales, const int32_t* positions, size_t batch,
+                                     size_t seq_len, size_t heads, size_t D, size_t gs, size_t cache_batch_stride,
+                                     size_t scale_batch_stride, size_t max_slots, size_t window, size_t sink,
+                                     hipStream_t st) {
+    const size_t rows = batch * seq_len * heads;
+    if (rows == 0 || D == 0) return hipSuccess;
+    const size_t G = (D + gs - 1) / gs;
+    const size_t items = rows * G;
+    kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(
+        k_src, k_cache, k_scales, v_src, v_cache, v_scales, rows, D, gs, G, nullptr, heads, cache_batch_stride,
+        scale_batch_stride, max_slots, positions, seq_len, (int)window, (int)sink);
+    return hipGetLastError();
+}
+
+// positions[b] += advance; cache_lens[b] = tokens the cache of sequence b holds = min(position, window)
+__global__ __launch_bounds__(256) void kv_positions_advance_kernel(int32_t* __restrict__ positions,
+                                                                  int32_t* __restrict__ cache_lens, size_t batch,
+                                                                  int advance, int window) {
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= batch) return;
+    const int p = positions[b] + advance;
+    positions[b] = p;
+    if (cache_lens) cache_lens[b] = (window > 0 && p > window) ? window : p;
+}
+
+hipError_t launch_kv_positions_advance(int32_t* positions, int32_t* cache_lens, size_t batch, size_t advance,
+                                       size_t window, hipStream_t st) {
+    if (batch == 0) return hipSuccess;
+    kv_positions_advance_kernel<<<dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, st>>>(
+        positions, cache_lens, batch, (int)advance, (int)window);
     return hipGetLastError();
 }
 

@@ -375,6 +375,21 @@ class KVCache:
     def get_value_scales(self, layer):
         return lib.cactus_hip_kvcache_value_scales(self._c, layer)
 
+    def upload_rows(self, layer, first, keys, key_scales, values, value_scales):
+        """Overwrite slots [first, first + n) of one layer with host rows (keys / values int8 [n, Hkv, D], scales
+        fp32 [n, Hkv, G]): lets a test continue a device cache from a state computed elsewhere."""
+        G = (self.head_dim + 127) // 128
+        n = keys.shape[0]
+        assert first + n <= self.get_effective_seq_len()
+        for ptr, a, row_bytes in ((self.get_keys_int8(layer), keys, self.num_kv_heads * self.head_dim),
+                                  (self.get_key_scales(layer), key_scales, self.num_kv_heads * G * 4),
+                                  (self.get_values_int8(layer), values, self.num_kv_heads * self.head_dim),
+                                  (self.get_value_scales(layer), value_scales, self.num_kv_heads * G * 4)):
+            a = np.ascontiguousarray(a)
+            assert a.nbytes == n * row_bytes
+            _ok(lib.cactus_hip_memcpy_h2d(C.c_void_p(ptr + first * row_bytes), a.ctypes.data_as(C.c_void_p), a.nbytes, None))
+        _ok(lib.cactus_hip_synchronize(None))
+
     def download(self, layer):
         """(keys int8 [len,Hkv,D], key scales, values, value scales) of one layer as numpy."""
         L = self.get_effective_seq_len()

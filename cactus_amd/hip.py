@@ -100,6 +100,9 @@ SIGNATURES = {
     "cactus_hip_sample_max_survivors": (_sz, []),
     "cactus_hip_sample_uniform": (_f, [C.c_uint32]),
     "cactus_hip_logits_entropy_f16_dev": (_i, [_vp, _vp, _sz, _sz, _vp]),
+    "cactus_hip_qk_norm_rope_seq_f16_dev": (_i, [_vp] * 12 + [_sz] * 6 + [_f, _f] + [_sz] * 6 + [_vp]),
+    "cactus_hip_kv_append_windowed_dev": (_i, [_vp] * 7 + [_sz] * 10 + [_vp]),
+    "cactus_hip_kv_positions_advance_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _vp]),
     "cactus_hip_kv_append_batched_dev": (_i, [_vp] * 6 + [_sz] * 4 + [_vp, _sz, _sz, _sz, _vp]),
     "cactus_hip_indices_to_int32_dev": (_i, [_vp, _i, _vp, _sz, _vp]),
     "cactus_hip_embedding_int8_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
@@ -482,6 +485,43 @@ def kv_append_batched(k_new, v_new, k_cache, v_cache, k_scales, v_scales, slots,
                                                 k_scales.stride(0), k_cache.shape[1], _stream()))
 
 
+def qk_norm_rope_seq(q, k, v, q_weight, k_weight, eps, theta, positions, max_position, k_cache=None, v_cache=None,
+                     k_scales=None, v_scales=None, window=0, sink=0, group_size=128, out_q=None, out_k=None):
+    """qk_norm_rope for independent sequences at positions int32 [B] (tokens seen so far); with v (and the
+    caches [B, slots, Hkv, D] / scales [B, slots, Hkv, G]) the rotated k and v rows are also quantized into the
+    ring slot of their position.  v None: no append (append after the attention with kv_append_windowed)."""
+    _dev(q, torch.float16); _dev(k, torch.float16); _dev(positions, torch.int32)
+    B, S, Hq, D = q.shape
+    Hkv = k.shape[2]
+    oq = out_q if out_q is not None else torch.empty_like(q)
+    ok = out_k if out_k is not None else torch.empty_like(k)
+    cbs = sbs = ms = 0
+    if v is not None:
+        _dev(v, torch.float16)
+        cbs, sbs, ms = k_cache.stride(0), k_scales.stride(0), k_cache.shape[1]
+    _check(lib.cactus_hip_qk_norm_rope_seq_f16_dev(
+        _p(q), _p(k), _p(v), _p(q_weight), _p(k_weight), _p(oq), _p(ok), _p(k_cache if v is not None else None),
+        _p(v_cache if v is not None else None), _p(k_scales if v is not None else None),
+        _p(v_scales if v is not None else None), _p(positions), max_position, B, S, Hq, Hkv, D, float(eps), float(theta),
+        group_size, cbs, sbs, ms, window, sink, _stream()))
+    return oq, ok
+
+
+def kv_append_windowed(k_new, v_new, k_cache, v_cache, k_scales, v_scales, positions, window=0, sink=0, group_size=128):
+    """k_new / v_new fp16 [B, S, Hkv, D] quantized into the ring slots of positions[b] + s."""
+    _dev(k_new, torch.float16); _dev(v_new, torch.float16); _dev(positions, torch.int32)
+    B, S, Hh, D = k_new.shape
+    _check(lib.cactus_hip_kv_append_windowed_dev(_p(k_new), _p(v_new), _p(k_cache), _p(v_cache), _p(k_scales),
+                                                 _p(v_scales), _p(positions), B, S, Hh, D, group_size, k_cache.stride(0),
+                                                 k_scales.stride(0), k_cache.shape[1], window, sink, _stream()))
+
+
+def kv_positions_advance(positions, cache_lens, advance, window=0):
+    _dev(positions, torch.int32)
+    _check(lib.cactus_hip_kv_positions_advance_dev(_p(positions), _p(cache_lens), positions.numel(), advance, window,
+                                                   _stream()))
+
+
 def rope(x, theta, start_pos=0, out=None):
     """Half-split rotary embedding on fp16 [batch, seq, heads, head_dim]."""
     _dev(x, torch.float16)
@@ -656,14 +696,14 @@ def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, sc
 
 
 def attention_hybrid_batched(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale, cache_lens,
-                             position_offsets, group_size=128):
+                             position_offsets, group_size=128, out=None):
     """k_cached/v_cached int8 [B, max_cache, Hkv, D]; scales fp32 [B, max_cache, Hkv, G];
     cache_lens / position_offsets int32 [B]."""
     B, S, Hq, D = q.shape
     new_len, Hkv = k_new.shape[1], k_new.shape[2]
     max_cache = k_cached.shape[1]
     G = k_scales.shape[-1]
-    out = torch.empty_like(q)
+    out = out if out is not None else torch.empty_like(q)
     _check(lib.cactus_hip_attention_hybrid_int8_fp16_batched_dev(
         _p(q), _p(k_cached), _p(v_cached), _p(k_scales), _p(v_scales), _p(k_new), _p(v_new), _p(out),
         B, S, _p(cache_lens), new_len, Hq, Hkv, D, float(scale), _p(position_offsets), group_size,

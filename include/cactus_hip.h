@@ -473,6 +473,45 @@ int cactus_hip_kv_append_batched_dev(const cactus_half_t* k_new, const cactus_ha
                                      size_t cache_batch_stride, size_t scale_batch_stride,
                                      size_t max_slots, void* stream);
 
+/* Independent sequences at different positions, with the reference's sliding window (engine_cache.cpp:
+ * 268-329: the first `sink` tokens and the most recent `window - sink` are kept; window = min(context, 512),
+ * sink 4 in engine_model.cpp:136-146) held as a ring: the token with absolute index p of a sequence lives in
+ * slot p while p < window and in slot sink + (p - window) % (window - sink) afterwards, i.e. a new token
+ * overwrites the oldest recent one instead of every layer's window being moved down by one per token.  The
+ * cache then holds exactly the tokens the reference's holds, rotated; the hybrid attention sees every cached
+ * key, so only the order of its sums changes.  No counterpart in the reference, whose cache is batch-1.
+ *
+ * positions: device int32 [batch], tokens each sequence has seen so far (its RoPE position offset and
+ * attention position_offset; KVCache::total_seq_len).  window == 0: no window (slot = position).
+ *
+ *   cactus_hip_qk_norm_rope_seq_f16_dev   cactus_hip_qk_norm_rope_kv_append_f16_dev with per-sequence
+ *       positions: token s of sequence b is rotated for position positions[b] + s (clamped to max_position, which
+ *       bounds the cos/sin table the call builds) and, when v != NULL, k (rotated) and v are quantized into
+ *       that token's slot.  Appending in this launch is only equivalent to the reference while no
+ *       sequence's window is full (the attention of the step must still see the token a full window is
+ *       about to drop): pass v == NULL then and append after the attention with
+ *   cactus_hip_kv_append_windowed_dev     k_new / v_new half[batch, seq_len, Hkv, D] (k already rotated)
+ *       quantized into the slots of their positions.
+ *   cactus_hip_kv_positions_advance_dev   positions[b] += advance and, when cache_lens != NULL,
+ *       cache_lens[b] = min(positions[b], window) (window 0: positions[b]): the two arrays the batched
+ *       attention takes, kept on the device between steps.
+ * At most window - sink new tokens per sequence and call. */
+int cactus_hip_qk_norm_rope_seq_f16_dev(const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v,
+                                        const cactus_half_t* q_weight, const cactus_half_t* k_weight,
+                                        cactus_half_t* q_output, cactus_half_t* k_output, int8_t* k_cache,
+                                        int8_t* v_cache, float* k_scales, float* v_scales, const int32_t* positions,
+                                        size_t max_position, size_t batch_size, size_t seq_len, size_t num_q_heads,
+                                        size_t num_kv_heads, size_t head_dim, float eps, float theta, size_t group_size,
+                                        size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+                                        size_t window, size_t sink, void* stream);
+int cactus_hip_kv_append_windowed_dev(const cactus_half_t* k_new, const cactus_half_t* v_new, int8_t* k_cache,
+                                      int8_t* v_cache, float* k_scales, float* v_scales, const int32_t* positions,
+                                      size_t batch_size, size_t seq_len, size_t kv_heads, size_t head_dim,
+                                      size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride,
+                                      size_t max_slots, size_t window, size_t sink, void* stream);
+int cactus_hip_kv_positions_advance_dev(int32_t* positions, int32_t* cache_lens, size_t batch_size, size_t advance,
+                                        size_t window, void* stream);
+
 /* ------------------------------------------------ host-pointer drop-in family
  * Same argument lists as cactus/kernel/kernel.h, host memory in and out.      */
 

@@ -1,0 +1,402 @@
+"""The whole-step wiring that bench.py times (cactus_amd/steps.py: batched decode steps of the Qwen3 and
+LFM2 op sequences, the chunked Qwen3 prefill) against the CPU oracle, sequence by sequence: every
+sequence of a batch must produce the logits (fp16 tolerance: attention sums in another order on the
+device) and the greedy token that the oracle produces for that sequence run alone, step after step.
+Cut-down models (a few blocks, a small vocabulary) with the real widths; synthetic weights.
+
+Covered: batches of at most 4 (streaming launches with produced activations) and above (tile kernel,
+shared launches); sequences of different lengths in one batch; the converter's MIXED INT4 / INT8
+policy; the sliding window with sink held as a ring once sequences outgrow it; a three-chunk prefill."""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests.helpers import rand_weights_int8, rand_weights_int4
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+HID, HQ, HKV, D, FF = 1024, 16, 8, 128, 3072
+EPS, THETA = 1e-6, 1e6
+
+
+@pytest.fixture(scope="module")
+def ST():
+    import cactus_amd.hip as hip
+    hip.init(0)
+    from cactus_amd import steps
+    return steps
+
+
+def make_model(rng, layers, vocab, gain, mixed):
+    from cactus_amd.steps import mixed_policy_int4
+
+    def mat(n, k, int4=False):
+        B, Bs = (rand_weights_int4 if int4 else rand_weights_int8)(rng, n, k)
+        # nibbles span [-8, 7] where bytes span [-127, 127]: larger group scales keep the weights' magnitude
+        return B, (Bs.astype(np.float32) * gain * (16.0 if int4 else 1.0)).astype(np.float16)
+    Ls = []
+    for li in range(layers):
+        L = {name: mat(n, k, mixed and mixed_policy_int4(name, li, layers))
+             for name, (n, k) in {"q": (HQ * D, HID), "k": (HKV * D, HID), "v": (HKV * D, HID), "o": (HID, HQ * D),
+                                  "gate": (FF, HID), "up": (FF, HID), "down": (HID, FF)}.items()}
+        for name, n in {"in_norm": HID, "post_norm": HID, "q_norm": D, "k_norm": D}.items():
+            L[name] = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float16)
+        Ls.append(L)
+    B, Bs = rand_weights_int8(rng, vocab, HID)
+    return {"layers": Ls, "emb": (B, Bs), "final_norm": (1.0 + 0.1 * rng.standard_normal(HID)).astype(np.float16)}
+
+
+def omm(x_bits, wt):
+    q, s = O.quantize_activations(x_bits)
+    fn = O.matmul_int4 if wt[0].dtype == np.uint8 else O.matmul_int8
+    return fn(q, s, wt[0], wt[1].view(np.uint16), 128)
+
+
+def trim(cache, window, sink):
+    """The reference's sliding window (engine_cache.cpp:268-329): first `sink` tokens + the most recent ones."""
+    if not window or cache[0].shape[0] <= window:
+        return cache
+    return [np.concatenate([a[:sink], a[a.shape[0] - (window - sink):]]) for a in cache]
+
+
+def oracle_forward(m, tokens, pos, caches, window=0, sink=0):
+    """Logits bits of the last of `tokens` for ONE sequence; caches: per block [kq, ks, vq, vs] or None."""
+    S = len(tokens)
+    h = O.embedding(m["emb"][0], np.asarray(tokens, np.int32), m["emb"][1].view(np.uint16), 128)
+    for li, L in enumerate(m["layers"]):
+        n1 = O.rms_norm(h, L["in_norm"], EPS)
+        q = O.rms_norm(omm(n1, L["q"]).reshape(S * HQ, D), L["q_norm"], EPS).reshape(1, S, HQ, D)
+        k = O.rms_norm(omm(n1, L["k"]).reshape(S * HKV, D), L["k_norm"], EPS).reshape(1, S, HKV, D)
+        v = omm(n1, L["v"]).reshape(1, S, HKV, D)
+        q, k = O.rope(q, THETA, pos), O.rope(k, THETA, pos)
+        if caches[li] is None:
+            attn = O.attention_f16(q, k, v, 0.0, position_offset=pos)
+        else:
+            kq, ks, vq, vs = caches[li]
+            attn = O.attention_hybrid(q, kq[None], vq[None], ks[None], vs[None], k, v, 0.0, position_offset=pos)
+        new = O.quantize_kv(k.reshape(S, HKV, D)) + O.quantize_kv(v.reshape(S, HKV, D))
+        new = [new[0], new[1], new[2], new[3]]
+        caches[li] = new if caches[li] is None else [np.concatenate([a, b]) for a, b in zip(caches[li], new)]
+        caches[li] = trim(caches[li], window, sink)
+        h = O.binary("add", h, omm(attn.reshape(S, HQ * D), L["o"]))
+        n2 = O.rms_norm(h, L["post_norm"], EPS)
+        act = O.binary("multiply", O.silu(omm(n2, L["gate"])), omm(n2, L["up"]))
+        h = O.binary("add", h, omm(act, L["down"]))
+    last = O.rms_norm(h[S - 1:S], m["final_norm"], EPS)
+    return omm(last, m["emb"])[0]
+
+
+def ring_slot(i, window, sink):
+    return i if not window or i < window else sink + (i - window) % (window - sink)
+
+
+def cache_token_indices(total, window, sink):
+    """Absolute token index of every row of the oracle's (sliding-window) cache after `total` tokens."""
+    if not window or total <= window:
+        return list(range(total))
+    return list(range(sink)) + list(range(total - (window - sink), total))
+
+
+def load_caches(kvstate, index, b, caches, total, window=0, sink=0):
+    """Oracle caches of one sequence -> the device caches of batch row b: the row of token i goes to the slot
+    the device keeps token i in (slot i, or its ring slot once the window is full)."""
+    slots = torch.tensor([ring_slot(i, window, sink) for i in cache_token_indices(total, window, sink)]).cuda()
+    for li, ai in index.items():
+        kq, ks, vq, vs = caches[li]
+        assert kq.shape[0] == slots.numel()
+        kvstate.kc[ai, b, slots] = torch.from_numpy(kq).cuda()
+        kvstate.vc[ai, b, slots] = torch.from_numpy(vq).cuda()
+        kvstate.ksc[ai, b, slots] = torch.from_numpy(ks).cuda()
+        kvstate.vsc[ai, b, slots] = torch.from_numpy(vs).cuda()
+
+
+class StepChecker:
+    """Per (step, sequence) comparison of a device decode step that started from the oracle's state.
+    All ops but attention reproduce the oracle bit for bit, and attention differs by fp32 summation order,
+    so a step is bit-exact unless an fp16 ulp of some attention output flips a value of the next INT8
+    activation quantization; in a synthetic model with random weights such a flip grows through the
+    remaining blocks to a few per cent of the largest logit.  Bars: bit-exact, or |diff| <= 2e-2 + 6e-2 *
+    max|logit|; the greedy token equals the oracle's unless the oracle itself separates the two candidates
+    by less than twice that difference."""
+
+    def __init__(self):
+        self.pairs = self.exact = self.near_ties = 0
+        self.seen = set()
+
+    def check(self, lg_dev, tok_dev, lg_ref_bits, where):
+        ref = lg_ref_bits.view(np.float16).astype(np.float64)
+        self.pairs += 1
+        to = int(O.sample_greedy(lg_ref_bits.view(np.float16)[None])[0])
+        self.seen.add(to)
+        if np.array_equal(lg_dev.view(np.uint16), lg_ref_bits):
+            self.exact += 1
+            assert tok_dev == to, where
+            return to, True
+        err = np.abs(lg_dev.astype(np.float64) - ref).max()
+        assert err <= 2e-2 + 6e-2 * np.abs(ref).max(), (where, err, np.abs(ref).max())
+        if tok_dev != to:
+            assert ref[to] - ref[tok_dev] <= 2 * err, (where, tok_dev, to, ref[to], ref[tok_dev], err)
+            self.near_ties += 1
+        return to, False
+
+
+@pytest.mark.parametrize("lens,mixed,window", [
+    ((5, 17, 40), False, 0),                     # at most 4 sequences: streaming launches, produced activations
+    ((9, 3, 28), True, 0),                       # MIXED policy on the streaming path (q/k INT8, v INT4 launches)
+    ((3, 9, 16, 31, 33, 40), False, 0),          # above 4: tile kernel, shared q/k/v and gate/up launches
+    ((4, 12, 17, 25, 36), True, 0),              # MIXED policy on the tile path
+    ((10, 20, 23), False, 24),                   # sliding window 24 with sink 4: sequences outgrow it at different steps
+    ((6, 14, 19, 22, 23, 23), False, 24),
+])
+def test_qwen3_batched_decode_matches_oracle_per_sequence(ST, lens, mixed, window):
+    layers, vocab, steps, sink = 6, 8192, 8, 4
+    rng = np.random.default_rng(sum(lens) + mixed + window)
+    m = make_model(rng, layers, vocab, 0.02, mixed)
+    cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
+    batch = len(lens)
+    dec = ST.Qwen3Decode(ST.weights_to_device(m), cfg, batch, 64, window=window, sink=sink, max_position=128)
+    index = {li: li for li in range(layers)}
+    caches, toks = [], []
+    for b, n in enumerate(lens):        # oracle prefill of each sequence alone; its cache seeds the device's
+        cb = [None] * layers
+        prompt = rng.integers(0, vocab, n).tolist()
+        lg = oracle_forward(m, prompt, 0, cb, window, sink)
+        toks.append(int(O.sample_greedy(lg.view(np.float16)[None])[0]))
+        caches.append(cb)
+        load_caches(dec.kv, index, b, cb, n, window, sink)
+    dec.kv.set_positions(lens)
+    pos = list(lens)
+    ck = StepChecker()
+    exact_rows = total_rows = 0
+    for step in range(steps):
+        dec.kv.tok.copy_(torch.tensor(toks, dtype=torch.int32))
+        dec.step()
+        torch.cuda.synchronize()
+        lg_d = dec.logits.cpu().numpy()
+        tok_d = dec.kv.tok.cpu().tolist()
+        kc_d, ksc_d = dec.kv.kc.cpu().numpy(), dec.kv.ksc.cpu().numpy()
+        for b in range(batch):
+            lg_o = oracle_forward(m, [toks[b]], pos[b], caches[b], window, sink)
+            toks[b], exact = ck.check(lg_d[b], tok_d[b], lg_o, (step, b))
+            # the token this step appended: the rows the device quantized into its slot against the oracle's
+            slot = ring_slot(pos[b], window, sink)
+            for li in range(layers):
+                same = np.array_equal(kc_d[li, b, slot], caches[b][li][0][-1]) and \
+                    np.array_equal(ksc_d[li, b, slot], caches[b][li][1][-1])
+                total_rows += 1
+                exact_rows += same
+                if exact or li == 0:     # block 0's keys do not sit behind any attention
+                    assert same, (step, b, li)
+            pos[b] += 1
+            load_caches(dec.kv, index, b, caches[b], pos[b], window, sink)    # next step starts from the oracle's state
+    assert dec.kv.positions.cpu().tolist() == pos
+    assert dec.kv.cache_lens.cpu().tolist() == [min(p, window) if window else p for p in pos]
+    assert len(ck.seen) > 1 and ck.near_ties <= 2
+    if not window:     # a ring holds the window's tokens rotated: its attention sums in another order every step
+        assert ck.exact >= 0.7 * ck.pairs, (ck.exact, ck.pairs)
+        assert exact_rows >= 0.9 * total_rows
+
+
+def test_qwen3_chunked_prefill_matches_oracle(ST):
+    """Three chunks of 64 tokens: chunk 0 against nothing (FP16 attention), the others against the INT8 cache;
+    the last token's logits and greedy choice, and the quantized K cache the chunks leave behind."""
+    layers, vocab, tokens, chunk = 4, 8192, 192, 64
+    rng = np.random.default_rng(77)
+    m = make_model(rng, layers, vocab, 0.02, False)
+    cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
+    pf = ST.Qwen3Prefill(ST.weights_to_device(m), cfg, tokens, chunk)
+    prompt = rng.integers(0, vocab, tokens)
+    pf.toks.copy_(torch.from_numpy(prompt.reshape(-1, chunk).astype(np.int32)))
+    caches = [None] * layers
+    for ci in range(tokens // chunk):
+        pf.run_chunk(ci)
+        lg_o = oracle_forward(m, prompt[ci * chunk:(ci + 1) * chunk].tolist(), ci * chunk, caches)
+    torch.cuda.synchronize()
+    StepChecker().check(pf.logits.cpu().numpy()[0], int(pf.tok.cpu()[0]), lg_o, "prefill")
+    # block 0's keys depend on nothing but the embedding, the input norm and the k projection: bit-exact
+    assert np.array_equal(pf.kc[0, 0].cpu().numpy(), caches[0][0])
+    assert np.array_equal(pf.ksc[0, 0].cpu().numpy(), caches[0][1])
+    # Later blocks sit behind attention outputs, which differ in fp16 ulps: a token whose INT8 activations
+    # flipped anywhere has a different row in every block after it, and over 192 tokens times 4 blocks that
+    # happens to a share of the tokens.  Block 1 (one attention upstream): nearly all values agree.
+    frac = [(np.abs(pf.kc[li, 0].cpu().numpy().astype(np.int32) - caches[li][0].astype(np.int32)) <= 1).mean()
+            for li in range(layers)]
+    assert frac[1] > 0.9 and min(frac) > 0.5, frac
+
+
+def conv_rows(cc):
+    """The oracle's circular ConvCache rows of one block in temporal order, zeros for rows not held yet."""
+    W, Cc = cc.W, cc.rows.shape[1]
+    held, h = cc.count.value, cc.head.value
+    rows = cc.rows[:held] if held < W else np.concatenate([cc.rows[h:], cc.rows[:h]])
+    st = np.zeros((W, Cc), np.uint16)
+    st[W - held:] = rows
+    return torch.from_numpy(st.view(np.float16)).cuda()
+
+
+def test_lfm2_batched_decode_matches_oracle_per_sequence(ST):
+    """A cut-down LFM2 (conv, conv, attention, conv, attention; hidden 2048, ffn 2048, vocabulary 4096) for 5
+    sequences of different lengths: conv state rows and INT8 caches per sequence on the device."""
+    from tests import test_gpu_greedy_decode as GD
+    c = GD.LFM
+    rng = np.random.default_rng(5)
+    types, vocab, ffn, steps = "ccaca", 4096, 2048, 6
+
+    def mat(n, k, g):
+        B, Bs = rand_weights_int8(rng, n, k)
+        return B, (Bs.astype(np.float32) * g).astype(np.float16)
+    Ls = []
+    for t in types:
+        L = {"gate": mat(ffn, c["HID"], 0.01), "up": mat(ffn, c["HID"], 0.01), "down": mat(c["HID"], ffn, 0.01),
+             "in_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16),
+             "post_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
+        if t == "a":
+            L.update(q=mat(c["HQ"] * c["D"], c["HID"], 0.01), k=mat(c["HKV"] * c["D"], c["HID"], 0.01),
+                     v=mat(c["HKV"] * c["D"], c["HID"], 0.01), o=mat(c["HID"], c["HQ"] * c["D"], 0.01),
+                     q_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16),
+                     k_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16))
+        else:
+            L.update(in_proj=mat(3 * c["HID"], c["HID"], 0.01), out_proj=mat(c["HID"], c["HID"], 0.01),
+                     conv_w=(rng.standard_normal((c["HID"], 1, c["K"])) * 0.5).astype(np.float16))
+        Ls.append(L)
+    m = {"layers": Ls, "emb": mat(vocab, c["HID"], 1.0),
+         "final_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
+    attn_at = tuple(i for i, t in enumerate(types) if t == "a")
+    cfg = dict(ST.LFM2_1P2B, layers=len(types), vocab=vocab, ffn=ffn, attention_layers=attn_at)
+    dm = ST.weights_to_device(m)
+    for L in dm["layers"]:
+        if "conv_w" in L:
+            L["conv_w"] = L["conv_w"].reshape(c["HID"], c["K"]).contiguous()
+    lens = (4, 9, 2, 13, 7)
+    batch = len(lens)
+    dec = ST.Lfm2Decode(dm, cfg, batch, 64, max_position=128)
+    kvs, convs, toks = [], [], []
+    for b, n in enumerate(lens):
+        kv = [None] * len(types)
+        conv = [O.Lfm2ConvState(c["W"], c["HID"]) for _ in types]
+        prompt = rng.integers(0, vocab, n).tolist()
+        lg = GD.lfm2_oracle_forward(m, prompt, 0, kv, conv)
+        toks.append(int(O.sample_greedy(lg.view(np.float16)[None])[0]))
+        kvs.append(kv); convs.append(conv)
+        load_caches(dec.kv, dec.attn_index, b, kv, n)
+        for li in dec.state:
+            dec.state[li][b] = conv_rows(conv[li])
+    dec.kv.set_positions(lens)
+    pos = list(lens)
+    ck = StepChecker()
+    for step in range(steps):
+        dec.kv.tok.copy_(torch.tensor(toks, dtype=torch.int32))
+        dec.step()
+        torch.cuda.synchronize()
+        lg_d = dec.logits.cpu().numpy()
+        tok_d = dec.kv.tok.cpu().tolist()
+        for b in range(batch):
+            lg_o = GD.lfm2_oracle_forward(m, [toks[b]], pos[b], kvs[b], convs[b])
+            toks[b], _ = ck.check(lg_d[b], tok_d[b], lg_o, (step, b))
+            pos[b] += 1
+            load_caches(dec.kv, dec.attn_index, b, kvs[b], pos[b])
+            for li in dec.state:
+                dec.state[li][b] = conv_rows(convs[b][li])
+    assert ck.near_ties <= 2 and ck.exact >= 0.7 * ck.pairs, (ck.exact, ck.pairs)
+
+
+# ------------------------------------------------------------------ per-sequence positions and the ring window
+def test_qk_norm_rope_at_per_sequence_positions_bit_exact(ST):
+    """cactus_hip_qk_norm_rope_seq_f16_dev: every sequence rotated for its own position (model_qwen.cpp:63-81
+    applied per sequence), and with v given the rotated k / v rows quantized into the slot of that position."""
+    import cactus_amd.hip as H
+    rng = np.random.default_rng(3)
+    B, S, Hq, Hkv, Dh, slots = 4, 3, 4, 2, 128, 48
+    q = rng.standard_normal((B, S, Hq, Dh)).astype(np.float16)
+    k = rng.standard_normal((B, S, Hkv, Dh)).astype(np.float16)
+    v = rng.standard_normal((B, S, Hkv, Dh)).astype(np.float16)
+    qw = (1.0 + 0.1 * rng.standard_normal(Dh)).astype(np.float16)
+    kw = (1.0 + 0.1 * rng.standard_normal(Dh)).astype(np.float16)
+    positions = np.array([0, 7, 30, 41], np.int32)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    kc = torch.zeros((B, slots, Hkv, Dh), dtype=torch.int8, device="cuda"); vc = torch.zeros_like(kc)
+    ks = torch.ones((B, slots, Hkv, 1), dtype=torch.float32, device="cuda"); vs = torch.ones_like(ks)
+    oq, ok = H.qk_norm_rope_seq(dev(q), dev(k), dev(v), dev(qw), dev(kw), 1e-6, 1e6, dev(positions), 64, kc, vc, ks, vs)
+    torch.cuda.synchronize()
+    bits = lambda t: t.cpu().view(torch.int16).numpy().view(np.uint16)
+    for b in range(B):
+        p = int(positions[b])
+        wq = O.rope(O.rms_norm(q[b].reshape(S * Hq, Dh), qw, 1e-6).reshape(1, S, Hq, Dh), 1e6, p)
+        wk = O.rope(O.rms_norm(k[b].reshape(S * Hkv, Dh), kw, 1e-6).reshape(1, S, Hkv, Dh), 1e6, p)
+        assert np.array_equal(bits(oq[b:b + 1]), wq) and np.array_equal(bits(ok[b:b + 1]), wk), b
+        kq_o, ks_o = O.quantize_kv(wk.reshape(S, Hkv, Dh).view(np.float16))
+        vq_o, vs_o = O.quantize_kv(v[b])
+        assert np.array_equal(kc[b, p:p + S].cpu().numpy(), kq_o) and np.array_equal(ks[b, p:p + S].cpu().numpy(), ks_o)
+        assert np.array_equal(vc[b, p:p + S].cpu().numpy(), vq_o) and np.array_equal(vs[b, p:p + S].cpu().numpy(), vs_o)
+        untouched = np.ones(slots, bool); untouched[p:p + S] = False
+        assert not kc[b].cpu().numpy()[untouched].any()
+
+
+@pytest.mark.parametrize("new_per_call", [1, 3])
+def test_windowed_batched_append_holds_the_sliding_windows_tokens(ST, new_per_call):
+    """Sequences at different positions appended to together, `new_per_call` tokens each, far past a window of 16
+    with sink 4 (engine_cache.cpp:268-329 per sequence): after every call the device's ring, un-rotated, holds
+    bit for bit the rows of the reference's sliding cache, the device-kept positions / cache lengths are
+    right, and the batched attention over the ring equals the oracle's attention over the sliding cache
+    (|diff| <= 2e-3 + 4e-3 |ref|: the ring only permutes the sums)."""
+    import cactus_amd.hip as H
+    rng = np.random.default_rng(40 + new_per_call)
+    B, Hq, Hkv, Dh, window, sink, slots = 4, 4, 2, 128, 16, 4, 20
+    S = new_per_call
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    kc = torch.zeros((B, slots, Hkv, Dh), dtype=torch.int8, device="cuda"); vc = torch.zeros_like(kc)
+    ks = torch.ones((B, slots, Hkv, 1), dtype=torch.float32, device="cuda"); vs = torch.ones_like(ks)
+    start = [0, 5, 11, 15]
+    ocache = []
+    for b in range(B):                      # sequences begin with different numbers of tokens (below the window)
+        k0 = rng.uniform(-2, 2, (1, start[b], Hkv, Dh)).astype(np.float16)
+        v0 = rng.uniform(-2, 2, (1, start[b], Hkv, Dh)).astype(np.float16)
+        if start[b]:
+            H.kv_append_windowed(dev(k0), dev(v0), kc[b:b + 1], vc[b:b + 1], ks[b:b + 1], vs[b:b + 1],
+                                 torch.zeros((1,), dtype=torch.int32, device="cuda"))     # below the window: slot = position
+        ocache.append(list(O.quantize_kv(k0[0])) + list(O.quantize_kv(v0[0])))
+    positions = dev(np.array(start, np.int32))
+    lens = dev(np.array(start, np.int32))
+    pos = list(start)
+    for call in range(12):
+        kn = rng.uniform(-2, 2, (B, S, Hkv, Dh)).astype(np.float16)
+        vn = rng.uniform(-2, 2, (B, S, Hkv, Dh)).astype(np.float16)
+        qh = rng.uniform(-1, 1, (B, S, Hq, Dh)).astype(np.float16)
+        # the step's attention sees the cache as it is plus the new tokens, then the cache takes them
+        got = H.attention_hybrid_batched(dev(qh), kc, vc, ks, vs, dev(kn), dev(vn), 0.0, lens, positions)
+        H.kv_append_windowed(dev(kn), dev(vn), kc, vc, ks, vs, positions, window, sink)
+        H.kv_positions_advance(positions, lens, S, window)
+        torch.cuda.synchronize()
+        got = got.cpu().view(torch.int16).numpy().view(np.uint16)
+        for b in range(B):
+            kq, ksc, vq, vsc = ocache[b]
+            want = O.attention_hybrid(qh[b:b + 1], kq[None], vq[None], ksc[None], vsc[None], kn[b:b + 1], vn[b:b + 1], 0.0,
+                                      position_offset=pos[b], cache_len=kq.shape[0])
+            g, w = got[b:b + 1].view(np.float16).astype(np.float64), want.view(np.float16).astype(np.float64)
+            assert (np.abs(g - w) <= 2e-3 + 4e-3 * np.abs(w)).all(), (call, b)
+            new = list(O.quantize_kv(kn[b])) + list(O.quantize_kv(vn[b]))
+            ocache[b] = trim([np.concatenate([a, n]) for a, n in zip(ocache[b], new)], window, sink)
+            pos[b] += S
+            idx = [ring_slot(i, window, sink) for i in cache_token_indices(pos[b], window, sink)]
+            assert np.array_equal(kc[b].cpu().numpy()[idx], ocache[b][0]), (call, b)
+            assert np.array_equal(ks[b].cpu().numpy()[idx], ocache[b][1]), (call, b)
+            assert np.array_equal(vc[b].cpu().numpy()[idx], ocache[b][2]), (call, b)
+            assert np.array_equal(vs[b].cpu().numpy()[idx], ocache[b][3]), (call, b)
+        assert positions.cpu().tolist() == pos and lens.cpu().tolist() == [min(p, window) for p in pos]
+
+
+def test_windowed_append_argument_errors(ST):
+    import cactus_amd.hip as H
+    z16 = torch.zeros((1, 1, 1, 128), dtype=torch.float16, device="cuda")
+    kc = torch.zeros((1, 8, 1, 128), dtype=torch.int8, device="cuda")
+    sc = torch.ones((1, 8, 1, 1), dtype=torch.float32, device="cuda")
+    p = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    with pytest.raises(H.CactusHipError, match="sink < window"):
+        H.kv_append_windowed(z16, z16, kc, kc, sc, sc, p, window=4, sink=4)          # no recent region
+    with pytest.raises(H.CactusHipError, match="sink < window"):
+        H.kv_append_windowed(z16, z16, kc, kc, sc, sc, p, window=16, sink=4)         # window above the slots
+    five = torch.zeros((1, 5, 1, 128), dtype=torch.float16, device="cuda")
+    with pytest.raises(H.CactusHipError, match="sink < window"):
+        H.kv_append_windowed(five, five, kc, kc, sc, sc, p, window=8, sink=4)        # more new tokens than recent slots
