@@ -6,7 +6,7 @@ classes enqueue the same op sequence for `batch` independent sequences on the cu
 the back-to-back small ops going out as the library's one-launch sequences, and keep every piece
 of per-sequence state on the device (token ids, positions, INT8 KV caches, LFM2 conv rows), so a
 step can be captured into a HIP graph and replayed.  They are what bench.py times and what
-tests/test_gpu_steps.py compares with the CPU oracle, sequence by sequence.
+tests/test_gpu_steps.py checks sequence by sequence against a CPU restatement of the reference.
 
 Weights: dicts of device tensors.  A quantized matrix is a pair (B, B_scales): int8 [N, K] or packed
 uint8 [N, K/2] (INT4) with fp16 scales [N, K/128]; a norm weight is an fp16 vector.
