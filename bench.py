@@ -2,6 +2,7 @@
 """bench.py -- throughput of the quantized hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...      (starts N ranks itself, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): the synthetic INT8-weight x FP16-activation matmul sweep,
@@ -92,23 +93,16 @@ def time_graph(fn, n_calls, replays=6):
     return e0.elapsed_time(e1) / (replays * n_calls)
 
 
-def cpu_baseline(steps=5):
+def cpu_baseline(work, steps=5):
     """The oracle (CPU restatement of the reference kernel -- its NEON sources do not build on
-    x86) on the same M=1 sweep, with the reference's thread policy for M <= 1: 4 GEMM threads
-    (kernel_utils.h:450-455); 1 warm-up + `steps` timed passes (tests/test_threading.cpp:111-120)."""
+    x86) on the same M=1 sweep and the SAME buffers the GPU step reads (weight set 0 and the
+    activation rows, copied back to the host), with the reference's thread policy for M <= 1: 4 GEMM
+    threads (kernel_utils.h:450-455); 1 warm-up + `steps` timed passes (tests/test_threading.cpp:111-120).
+    work: [(x fp16 [1, K], B int8 [N, K], B_scales fp16 [N, K/128])] as numpy arrays."""
     from oracle import binding as O
-    rng = np.random.default_rng(42)
     threads = min(4, os.cpu_count() or 1)
     O.set_threads(threads)
-    work = []
-    total = 0
-    for K in SIZES:
-        x = rng.uniform(-1, 1, (1, K)).astype(np.float16)
-        for N in SIZES:
-            B = rng.integers(-127, 128, (N, K), dtype=np.int8)
-            Bs = (0.01 + np.abs(rng.uniform(-1, 1, (N, K // 128))) * 0.05).astype(np.float16)
-            work.append((x, B, Bs))
-            total += gemv_bytes(1, K, N)
+    total = sum(gemv_bytes(1, B.shape[1], B.shape[0]) for _, B, _ in work)
 
     def one_pass():
         for x, B, Bs in work:
@@ -122,10 +116,31 @@ def cpu_baseline(steps=5):
     dt = (time.perf_counter() - t0) / steps
     O.set_threads(1)
     return {"value": round(total / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
-            "sample": f"full M=1 INT8 sweep (16 shapes, {total / 1e6:.0f} MB/pass), 1 warm-up + {steps} "
-                      f"timed passes, {threads} threads = the reference's GEMM policy for M<=1; scalar C "
-                      "restatement compiled with gcc -O3 -march=x86-64-v3 (NEON reference is unbuildable on x86)",
+            "sample": f"full M=1 INT8 sweep on the GPU step's own buffers (16 shapes, {total / 1e6:.0f} MB/pass), "
+                      f"1 warm-up + {steps} timed passes, {threads} threads = the reference's GEMM policy for M<=1; "
+                      "scalar C restatement compiled with gcc -O3 -march=x86-64-v3 (NEON reference is unbuildable on x86)",
             "ms_per_pass": round(dt * 1e3, 2)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this file with torch.distributed.run as
+    a child process (one rank per GPU, rendezvous on 127.0.0.1), pass its output through (rank 0 prints the one
+    JSON line) and return its exit code -- non-zero if any rank failed.  The parent makes no GPU call."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_extra:
+        cmd.append("--no-extra")
+    if args.no_cpu:
+        cmd.append("--no-cpu")
+    print("[bench] launching " + " ".join(cmd[1:]), file=sys.stderr, flush=True)
+    return subprocess.run(cmd).returncode
 
 
 def main():
@@ -137,9 +152,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: this process becomes the launcher of N ranks and never touches a GPU
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        print(f"[bench] rank {rank}/{world} (local rank {local_rank}, pid {os.getpid()}) starting", file=sys.stderr, flush=True)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -262,13 +282,15 @@ def main():
         extra = dict(extra, single_launch_8192=single)
     if world > 1 and not args.no_extra:
         sd = sharded_decode(H, gen, world)
+        ns = nsplit_8b(H, world, rank)
         if rank == 0:
-            extra = dict(extra, sharded_decode=sd)
+            extra = dict(extra, sharded_decode=sd, nsplit_8b=ns)
 
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu:
-            cpu = cpu_baseline()
+            cpu = cpu_baseline([(acts[K].cpu().numpy(), sets[0][(K, N)][0].cpu().numpy(), sets[0][(K, N)][1].cpu().numpy())
+                                for K, N in order])
         line = {
             "metric": "quant_gemv_hbm_throughput", "value": round(value, 1), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -322,6 +344,80 @@ def sharded_decode(H, gen, world):
     if l_ms < 1e29:
         out["lfm2_1p2b_1024_sequences_c512"] = {"ms_per_step": round(l_ms, 4), "sequences_per_gpu": per_rank,
                                                  "tokens_per_s": round(per_rank * world / (l_ms * 1e-3), 1)}
+    return out
+
+
+def nsplit_8b(H, world, rank, cache=32768):
+    """BASELINE configs[4]: the matmuls of an 8B-shape model (hidden 4096, ffn 12288) with packed INT4 group-128
+    weights, N-split over the ranks -- rank r runs the HIP kernel on rows row_shard(N, world, r) of the weight
+    and its scales, one all_gather_into_tensor (RCCL) reassembles [M, N] on every rank -- and decode attention
+    over a 32k-token INT8 cache sharded by kv head with the same gather.  Every rank draws the same full
+    weights (one seed), rank 0 also runs the unsplit problem: the N-split result must equal it bit for bit
+    (no output element's sum is split), the attention within the attention tolerance (the split count, and so
+    the summation order, follows the number of heads a rank holds).  Times are per call, local kernel +
+    gather, events on the launching stream, the slowest rank's."""
+    import torch.distributed as dist
+    from cactus_amd import sharding as S
+    gen = torch.Generator(device="cuda").manual_seed(4242)       # identical on every rank
+    out = {"ranks": world, "matmul_int4": {}, "note": "rows split by row_shard, HIP kernel per rank, one all-gather; "
+           "per call = local kernel + gather, max over ranks"}
+    ok_all = True
+    for (N, K) in ((12288, 4096), (4096, 12288), (4096, 4096)):
+        B, Bs = make_weights(K, N, True, gen)
+        for M in (1, 512):
+            x = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
+            q, sc = H.quantize_activations(x)
+            local = lambda b, bs: H.matmul_int4(q, sc, b, bs, 128)
+            got = S.matmul_nsplit(local, B, Bs, N)
+            same = True
+            if rank == 0:
+                same = bool(torch.equal(got.view(torch.int16), H.matmul_int4(q, sc, B, Bs, 128).view(torch.int16)))
+            ms = time_events(lambda i: S.matmul_nsplit(local, B, Bs, N), 10, warm=2)
+            start, end = S.row_shard(N, world, rank)
+            ms_local = time_events(lambda i: local(B[start:end], Bs[start:end]), 10, warm=2)
+            tt = torch.tensor([ms, ms_local, 0.0 if same else 1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms, ms_local, bad = (float(v) for v in tt.tolist())
+            ok_all = ok_all and bad == 0.0
+            row = {"us": round(ms * 1e3, 2), "us_local_kernel": round(ms_local * 1e3, 2), "bit_identical_to_unsplit": bad == 0.0}
+            if M == 1:
+                row["GBps"] = round(gemv_bytes(M, K, N, True, fused_quant=False) / (ms * 1e-3) / 1e9, 1)
+            else:
+                row["TOPS"] = round(2.0 * M * N * K / (ms * 1e-3) / 1e12, 1)
+            out["matmul_int4"][f"M{M}_K{K}_N{N}"] = row
+        del B, Bs
+    # 32k-context decode attention, 8B heads, sharded by kv head
+    Hq, Hkv, D = 32, 8, 128
+    if Hkv % world == 0:
+        kq = torch.randint(-127, 128, (cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+        vq = torch.randint(-127, 128, (cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+        ks = torch.rand((cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+        vs = torch.rand((cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+        qh = (torch.rand((1, 1, Hq, D), device="cuda", generator=gen) * 2 - 1).half()
+        kn = (torch.rand((1, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+        vn = (torch.rand((1, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
+        k0, k1, q0, q1 = S.kv_head_shard(Hkv, Hq, world, rank)
+        lk, lv = kq[:, k0:k1].contiguous(), vq[:, k0:k1].contiguous()         # the rank's own cache
+        lks, lvs = ks[:, k0:k1].contiguous(), vs[:, k0:k1].contiguous()
+        lq, lkn, lvn = qh[:, :, q0:q1].contiguous(), kn[:, :, k0:k1].contiguous(), vn[:, :, k0:k1].contiguous()
+
+        def sharded(i=0):
+            part = H.attention_hybrid(lq, lk, lv, lks, lvs, lkn, lvn, 0.0, position_offset=cache)
+            return S.all_gather_columns(part.view(1, -1), Hq * D, multiple=(q1 - q0) * D)
+        got = sharded()
+        diff = 0.0
+        if rank == 0:
+            full = H.attention_hybrid(qh, kq, vq, ks, vs, kn, vn, 0.0, position_offset=cache)
+            diff = float((got.view(-1).float() - full.view(-1).float()).abs().max())
+        ms = time_events(sharded, 10, warm=2)
+        tt = torch.tensor([ms, diff], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ms, diff = (float(v) for v in tt.tolist())
+        byts = 2 * cache * Hkv * (D + 4) + 2 * Hkv * D * 2 + 2 * Hq * D * 2
+        ok_all = ok_all and diff <= 2e-3
+        out["attn_decode_int8kv_c32768_kv_head_shard"] = {"us": round(ms * 1e3, 2), "GBps": round(byts / (ms * 1e-3) / 1e9, 1),
+                                                          "max_abs_diff_vs_unsplit": diff}
+    out["all_checks_passed"] = ok_all
     return out
 
 

@@ -106,3 +106,19 @@ def test_row_shard_alignment():
         assert edges[0][0] == 0 and max(e[1] for e in edges) == N
         for (a, b) in edges:
             assert a <= b and (a == b or a % 16 == 0)
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it must become the launcher: two ranks start (each
+    announces itself before touching a GPU) and, with no GPU in this container, fail -- which the parent
+    reports with a non-zero exit code instead of measuring one GPU and calling it two."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extra", "--no-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert "[bench] launching" in r.stderr
+    assert "rank 0/2" in r.stderr and "rank 1/2" in r.stderr, r.stderr[-2000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
