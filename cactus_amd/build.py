@@ -9,7 +9,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libcactus_hip.so")
 
 SOURCES = ["quant_kernels.hip", "matmul_skinny.hip", "matmul_gemm.hip", "matmul_generic.hip",
-           "matmul_f16.hip", "attention.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "api.hip", "graph.cpp"]
+           "matmul_f16.hip", "attention.hip", "attention_decode.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "api.hip", "graph.cpp"]
 HEADERS = ["common.hip.h", "block_math.hip.h", "kernels.h", "graph.h", os.path.join("..", "..", "include", "cactus_hip.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), so the
@@ -18,7 +18,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function"]
 # Per-file additions.  The GEMM's fp32 rescale runs beside MFMAs, where a packed v_pk_fma_f32
 # costs more than the two v_fma_f32 it replaces: keep the SLP vectorizer from packing them.
-EXTRA_FLAGS = {"matmul_gemm.hip": ["-fno-slp-vectorize"]}
+# The decode attention rescales its MFMA accumulators with VALU code: keep them in VGPRs (the default puts
+# them in AGPRs and copies them back and forth around every use).
+EXTRA_FLAGS = {"matmul_gemm.hip": ["-fno-slp-vectorize"],
+               "attention_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(target, deps):

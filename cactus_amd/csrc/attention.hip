@@ -574,10 +574,12 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnParams p) {
 // other workgroups' K/V streams, 2-3.5x slower at every split shape.)
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ ws,
                                                         uint16_t* __restrict__ out, int nsplit, int D) {
-    // one workgroup per output row; the per-split factors exp(m_s - M) go through LDS once,
-    // then each thread sums its dims over the splits with independent (pipelined) loads
+    // one workgroup per output row; the per-split factors exp(m_s - M) go through LDS once, then the
+    // splits are summed by 256 / (D / 2) thread groups at a time (a thread holds two dims of every
+    // G-th split, independent loads), and the groups' partial sums meet in LDS
     __shared__ float s_f[256];
     __shared__ float s_red[8];
+    __shared__ float s_acc[512];
     const size_t row = blockIdx.x;
     const float* base = ws + row * nsplit * (size_t)(D + 2);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -593,10 +595,24 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
     if (lane == 0) s_red[4 + wv] = L;
     __syncthreads();
     L = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    const int tpr = D / 2;              // threads per record
+    const int G = 256 / tpr;            // groups of splits summed side by side
+    const int g = tid / tpr, dd = (tid - g * tpr) * 2;
+    if (g < G) {
+        float ox = 0.0f, oy = 0.0f;
+#pragma unroll 8
+        for (int s = g; s < nsplit; s += G) {
+            const float2 v = *reinterpret_cast<const float2*>(base + (size_t)s * (D + 2) + 2 + dd);
+            ox = fmaf(v.x, s_f[s], ox);
+            oy = fmaf(v.y, s_f[s], oy);
+        }
+        s_acc[g * D + dd] = ox;
+        s_acc[g * D + dd + 1] = oy;
+    }
+    __syncthreads();
     for (int d = tid; d < D; d += 256) {
         float O = 0.0f;
-#pragma unroll 8
-        for (int s = 0; s < nsplit; s++) O = fmaf(base[(size_t)s * (D + 2) + 2 + d], s_f[s], O);
+        for (int gg = 0; gg < G; gg++) O += s_acc[gg * D + d];
         out[row * D + d] = (L > 0.0f) ? f2h_mul(O, 1.0f / L) : (uint16_t)0;
     }
 }
@@ -606,6 +622,7 @@ namespace {
 struct Plan {
     int dpl, nq, nsplit;
     size_t items;
+    bool mfma = false;   // the matrix-core decode kernel (attention_decode.hip)
 };
 
 bool tiled_ok(const AttnArgs& a) {
@@ -626,12 +643,20 @@ Plan make_plan(const AttnArgs& a) {
     for (int cand = maxnq; cand >= 1; cand >>= 1)
         if (gq % cand == 0) { pl.nq = cand; break; }
     pl.items = a.B * a.Hkv * (size_t)(gq / pl.nq) * a.S;
+    if (attn_decode_mfma_ok(a)) {   // every query head of a kv head in one wave
+        pl.mfma = true;
+        pl.nq = gq;
+        pl.items = a.B * a.Hkv;
+    }
     const size_t kvmax = (a.f16_mode ? 0 : a.cache_len) + a.new_len;
     const size_t maxblk = (kvmax + AT_BLOCK - 1) / AT_BLOCK;
-    // enough workgroups to fill the chip (about 2048 of 4 waves), but at least one 32-key block
-    // per wave; at most 256 splits (the merge kernel keeps one factor per split in LDS)
-    size_t ns = pl.items ? (2048 + pl.items - 1) / pl.items : 1;
-    const size_t cap = maxblk / AT_WAVES ? maxblk / AT_WAVES : 1;
+    // enough workgroups to fill the chip (about 2048 of 4 waves), but at least one 32-key block per wave;
+    // at most 256 splits (the merge kernel keeps one factor per split in LDS).  The matrix-core kernel's
+    // units are single waves: about 1024 of them (one per SIMD) stream fastest, each with two blocks or more.
+    const size_t target = pl.mfma ? 1024 : 2048;
+    size_t ns = pl.items ? (target + pl.items - 1) / pl.items : 1;
+    const size_t per_unit = pl.mfma ? 2 : AT_WAVES;     // blocks a unit should at least have
+    const size_t cap = maxblk / per_unit ? maxblk / per_unit : 1;
     if (ns > cap) ns = cap;
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
@@ -689,6 +714,14 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) 
         else
             attn_generic_kernel<false><<<dim3((unsigned)pl.items), dim3(64), lds, st>>>(p);
         return hipGetLastError();
+    }
+    if (pl.mfma) {
+        hipError_t em = launch_attention_decode_mfma(a, p.ws, pl.nsplit, st);
+        if (em == hipSuccess && pl.nsplit > 1) {
+            attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(p.ws, a.out, pl.nsplit, (int)a.D);
+            em = hipGetLastError();
+        }
+        return em;
     }
     const dim3 grid((unsigned)pl.items, (unsigned)pl.nsplit);
     switch (pl.dpl * 10 + pl.nq) {

@@ -1,0 +1,489 @@
+// Decode attention over the INT8 KV cache on the matrix cores
+// (cactus_attention_hybrid_int8_fp16, kernel_attention.cpp:257-482, for one query position per
+// sequence: Model::decode, and the batched form of it).
+//
+// Roofline: HBM.  Algorithmic bytes per sequence = 2*cache_len*Hkv*(D + 4) + new K/V + q + out.
+//
+// One wave per (sequence, kv head, key range): it streams the range's 32-key blocks and finishes its
+// output (or its split record) from registers, so a workgroup is just 4 (or 8) neighbouring items - the kv
+// heads of one sequence, whose rows are adjacent in memory - with no barrier and no LDS exchange.  Every
+// query head of the kv head (GQA, up to 16) rides in the same MFMAs, so a cached byte is fetched and
+// converted once whatever the group size, and the per-byte VALU work does not grow with it: one v_xor
+// per 4 values and one v_perm per 2.
+//
+// Everything is computed transposed, so that a lane owns a query head (lane % 16):
+//   S^T = K * Q^T   v_mfma_f32_16x16x32_f16, A = 16 keys x 32 dims, B = Q^T (columns = heads).  A lane
+//                   loads 16 contiguous bytes of one key row straight from global memory (a wave
+//                   instruction covers 16 rows x 64 bytes); the MFMA's contraction order is free as
+//                   long as both operands use it, so Q is laid out to match and K needs no staging.
+//   O^T = V^T * P^T A = 16 dims x 32 keys needs, per lane, 8 keys of one dim: the transpose of what
+//                   memory holds.  The raw INT8 rows go global -> LDS by LDS-DMA (no registers), and
+//                   ds_read_b64_tr_b16 reads them back transposed, two adjacent dims at a time (a
+//                   pair of bytes is its 16-bit element); B = P^T is the lane's own weights, in the
+//                   key order the first MFMA left them in (no shuffle).
+// INT8 -> binary16 is exact and costs no arithmetic: byte ^ 0x80 under the high byte 0x64 is the half
+// 1152 + value.  The constant is not subtracted per element: sum_d q[d] (1152 + k[d]) = 1152 sum(q) +
+// q.k, so the score subtracts 1152 * sum(q) once, and O subtracts 1152 * (sum of the weights fed to
+// the MFMA, summed by an MFMA from the same operand) block by block.  Weights enter as hi + lo binary16
+// parts (about 22 bits).
+// Per-key scales multiply the score column (K) and the weight (V), as the reference's dequantization
+// does per element.  Softmax is the online form with expf; key ranges (splits) leave (max, sum, O)
+// records that attn_merge_kernel reduces.
+#include "common.hip.h"
+#include "kernels.h"
+
+#include <math.h>
+
+#include <type_traits>
+
+namespace cactus_hip {
+
+namespace {
+
+constexpr int DC_BLOCK = 32;     // keys per block
+constexpr int DC_STAGES = 2;     // LDS stages and K register sets per wave: DC_STAGES - 1 blocks in flight
+constexpr int DC_MAX_NEW = 8;    // FP16 tokens of the step itself (decode: 1)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef __fp16 v2h __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_t;
+
+__device__ __forceinline__ v8h as_v8h(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const v4i v = {(int)a, (int)b, (int)c, (int)d};
+    return __builtin_bit_cast(v8h, v);
+}
+// two INT8 (already ^ 0x80) -> two halves 1152 + value
+__device__ __forceinline__ uint32_t pair_lo(uint32_t x) { return __builtin_amdgcn_perm(0x64646464u, x, 0x04010400u); }   // bytes 0, 1
+__device__ __forceinline__ uint32_t pair_hi(uint32_t x) { return __builtin_amdgcn_perm(0x64646464u, x, 0x04030402u); }   // bytes 2, 3
+__device__ __forceinline__ uint32_t pair_even(uint32_t x) { return __builtin_amdgcn_perm(0x64646464u, x, 0x04020400u); } // bytes 0, 2
+__device__ __forceinline__ uint32_t pair_odd(uint32_t x) { return __builtin_amdgcn_perm(0x64646464u, x, 0x04030401u); }  // bytes 1, 3
+
+// LDS byte address of a pointer into a __shared__ array
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// LDS reads the compiler does not see (see compute_block); the caller waits with s_waitcnt lgkmcnt
+__device__ __forceinline__ v4f lds_read_b128(uint32_t addr) {
+    v4f r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr) {
+    uint2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+    return r;
+}
+
+__device__ __forceinline__ float xor_lanes(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
+struct DecodeParams {
+    AttnArgs a;
+    int nsplit;
+    int n_items;  // batch * kv heads
+    int gq;       // query heads per kv head (<= 16)
+    float* ws;
+};
+
+// chunk swizzle of the V image: 16-byte chunk c of key row r sits at chunk c ^ swz(r), which keeps the
+// transposed reads of a 32-lane half (8 rows x 32 bytes) on 64 distinct banks
+template <int D>
+__device__ __forceinline__ int v_swz(int row) {
+    return D == 128 ? ((row >> 1) & 3) << 1 : ((row >> 2) & 1) << 1;
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
+    constexpr int ROWB = D;                         // bytes per key row
+    constexpr int VBYTES = DC_BLOCK * ROWB;         // V image of one block
+    constexpr int STAGE = VBYTES + 512;             // + 32 K scales, 128 B the request's idle lanes clear, 32 V scales, 128 B
+    constexpr int KL = D / 64;                      // 16-byte loads per lane and 16-key group (D = 64: 1)
+    constexpr int NC = D / 32;                      // 32-dim column blocks
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NW * DC_STAGES * STAGE];
+
+    const AttnArgs& a = p.a;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hd = lane & 15, q = lane >> 4;         // hd: query head (B / D column) or key / dim row (A operand)
+    const int Hkv = (int)a.Hkv, Hq = (int)a.Hq, gq = p.gq;
+    const int split = blockIdx.y;
+    const int item = (int)blockIdx.x * NW + w;
+    if (item >= p.n_items) return;                  // wave-uniform; the kernel has no barrier
+    const int kvh = item % Hkv, b = item / Hkv;
+    const int h0 = kvh * gq;
+
+    const int cl = a.cache_lens ? a.cache_lens[b] : (int)a.cache_len;
+    const int new_len = (int)a.new_len;
+    const int KV = cl + new_len;
+    const long long qabs = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset);
+    long long kv_end = KV;
+    if (a.is_causal) kv_end = min(kv_end, qabs + 1);          // kernel_attention.cpp:331-332
+    const int c_cnt = (int)min((long long)cl, kv_end);        // visible cached keys
+    const int nbc = (c_cnt + DC_BLOCK - 1) / DC_BLOCK;
+    const int bps = (nbc + p.nsplit - 1) / p.nsplit;
+    const int blk_first = split * bps, blk_last = min(nbc, blk_first + bps);
+
+    float scale = a.scale;
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);        // :278-280
+
+    const int8_t* Kc = a.k_cached + (size_t)b * a.cache_batch_stride;
+    const int8_t* Vc = a.v_cached + (size_t)b * a.cache_batch_stride;
+    const float* Ks = a.k_scales + (size_t)b * a.scale_batch_stride;
+    const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride;
+    const size_t row_stride = (size_t)Hkv * D;
+
+    // Q^T operand: lane (head, q) holds, for MFMA step (ld, half), Q[head][64 ld + 16 q + 8 half .. + 8)
+    v8h qreg[KL * 2];
+    float qsum = 0.0f;
+    {
+        const uint16_t* qrow = a.q + ((size_t)b * Hq + h0 + min(hd, gq - 1)) * D;
+#pragma unroll
+        for (int s = 0; s < KL * 2; s++) {
+            v4i raw = *reinterpret_cast<const v4i*>(qrow + 64 * (s >> 1) + 16 * q + 8 * (s & 1));
+            if (hd >= gq) raw = v4i{0, 0, 0, 0};
+            qreg[s] = __builtin_bit_cast(v8h, raw);
+#pragma unroll
+            for (int e = 0; e < 8; e++) qsum += (float)qreg[s][e];
+        }
+        qsum += xor_lanes(qsum, 16);
+        qsum += xor_lanes(qsum, 32);
+    }
+    const float nqsum = -1152.0f * qsum;
+    const float scale2 = scale * 1.44269504f;     // scores are kept times log2(e)
+
+    uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
+    // per-lane pieces of the addresses
+    const int dma_row = D == 128 ? lane >> 3 : lane >> 2;            // row inside one DMA instruction
+    const int dma_chunk = D == 128 ? lane & 7 : lane & 3;
+    constexpr int DMA_ROWS = D == 128 ? 8 : 16;
+    constexpr int NDMA = DC_BLOCK / DMA_ROWS;
+
+    // K, V and the scales come through buffer descriptors that end with the last visible cached row: rows
+    // past it (the tail of a range's last block, and whole blocks past this wave's share, whose offsets are
+    // pushed out of range) read as zeros and cost no memory traffic.  Requests are therefore made
+    // unconditionally and the block loop has no branch around a memory operation (a branch there turns
+    // every counted wait into a wait for everything).
+    const unsigned valid_bytes = (unsigned)c_cnt * (unsigned)row_stride;
+    const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Kc), 0, (int)valid_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Vc), 0, (int)valid_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ksrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ks), 0, c_cnt * Hkv * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vsrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, c_cnt * Hkv * 4, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned k_lane_off[2], v_lane_off[NDMA];
+#pragma unroll
+    for (int g = 0; g < 2; g++) k_lane_off[g] = (unsigned)(16 * g + hd) * (unsigned)row_stride + kvh * D + 16 * q;
+#pragma unroll
+    for (int i = 0; i < NDMA; i++) {
+        const int row = i * DMA_ROWS + dma_row;
+        v_lane_off[i] = (unsigned)row * (unsigned)row_stride + kvh * D + ((dma_chunk ^ v_swz<D>(row)) << 4);
+    }
+    // one scale per lane and request: lanes 0..31 the block's 32 keys, lanes 32..63 nothing
+    const unsigned s_lane_off = lane < 32 ? (unsigned)(lane * Hkv + kvh) * 4u : OOB;
+
+    struct KRegs { v4i k[2][KL]; };
+    // K: 16 keys x 64 bytes per wave instruction, straight to registers
+    auto issue_k = [&](int blk, KRegs& kr) __attribute__((always_inline)) {
+        const unsigned base = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)row_stride : OOB;
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int ld = 0; ld < KL; ld++)
+                kr.k[g][ld] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(krsrc, (int)(base + k_lane_off[g]) + 64 * ld, 0, 0));
+    };
+    // V: raw rows into the LDS image (lane-linear per instruction, swizzled through the source address), and
+    // the scales: each request writes its 32 scales and, from its idle lanes, 128 bytes of zeros behind them
+    auto issue_v = [&](int blk, int stage) __attribute__((always_inline)) {
+        const unsigned base = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)row_stride : OOB;
+        const unsigned sbase = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)Hkv * 4u : OOB;
+        uint8_t* st = my_lds + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NDMA; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lptr_t)(st + i * 1024), 16, (int)(base + v_lane_off[i]), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrsrc, (lptr_t)(st + VBYTES), 4, (int)(sbase + s_lane_off), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrsrc, (lptr_t)(st + VBYTES + 256), 4, (int)(sbase + s_lane_off), 0, 0, 0);
+    };
+
+    // m_run is the running maximum minus 6 (scores are base-2 logarithms): weights are 2^(s - m_run) <= 64, which
+    // keeps the binary16 parts of small weights out of the subnormal range; numerator and denominator carry
+    // the same factor.  pend: 1152 * (sum of the last block's weights as the MFMA saw them), still inside oacc.
+    float m_run = -INFINITY, l_part = 0.0f, pend = 0.0f;
+    v4f oacc[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) oacc[c][e] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // transposed-read addresses: lane i of group q supplies row 4q + (i >> 2), columns 4 (i & 3) .. + 4 of the block
+    // (rows 16 .. 31 are the same lanes' addresses plus 16 rows: the swizzle has period 16 or less)
+    uint32_t tr_off[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int row = 4 * q + (hd >> 2), pp = hd & 3;
+        const int chunk = (2 * c + (pp >> 1)) ^ v_swz<D>(row);
+        tr_off[c] = row * ROWB + chunk * 16 + 8 * (pp & 1);
+    }
+
+    // full: all 32 keys of the block are valid (every block but a range's last), so nothing is masked
+    auto compute_block = [&](auto full_tag, int blk, int stage, KRegs& kr) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const uint8_t* st = my_lds + stage * STAGE;
+        const int kb = blk * DC_BLOCK;
+        const int nv = min(DC_BLOCK, c_cnt - kb);            // valid keys of the block (wave-uniform)
+        // Every LDS read of the loop is issued here, by hand: the compiler orders an LDS read it can see behind
+        // ALL outstanding LDS-DMA requests (a wait for the next block's prefetch as well), which would take
+        // the overlap of loads and arithmetic away.  The stage's requests are complete (the caller waited).
+        const uint32_t sa = lds_addr(st);
+        v4f ksv[2], vsv[2];
+        uint2 tv[2][NC];
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            ksv[g] = lds_read_b128(sa + VBYTES + 64 * g + 16 * q);
+            vsv[g] = lds_read_b128(sa + VBYTES + 256 + 64 * g + 16 * q);
+        }
+        // ---- scores: S^T[key][head]; the two key groups' accumulation chains alternate.  The chains start
+        // at -1152 * sum(q), which takes the conversion's constant out again.
+        v4f acc[2] = {v4f{nqsum, nqsum, nqsum, nqsum}, v4f{nqsum, nqsum, nqsum, nqsum}};
+#pragma unroll
+        for (int ld = 0; ld < KL; ld++)
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const uint32_t x0 = (uint32_t)kr.k[g][ld][2 * hf] ^ 0x80808080u;
+                    const uint32_t x1 = (uint32_t)kr.k[g][ld][2 * hf + 1] ^ 0x80808080u;
+                    const v8h ka = as_v8h(pair_lo(x0), pair_hi(x0), pair_lo(x1), pair_hi(x1));
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qreg[2 * ld + hf], acc[g], 0, 0, 0);
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ksv[0]), "+v"(ksv[1]), "+v"(vsv[0]), "+v"(vsv[1]));
+        // scores in the base-2 domain: s * log2(e), so that the weights are one v_exp_f32 each
+        float sc[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sc[g][j] = acc[g][j] * (ksv[g][j] * scale2);
+                if (!FULL && 16 * g + 4 * q + j >= nv) sc[g][j] = -INFINITY;
+            }
+        // ---- online softmax, per head (lane % 16); a head's 32 keys sit in its 4 lanes (q = 0..3)
+        float bm = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                         fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+        bm = fmaxf(bm, xor_lanes(bm, 16));
+        bm = fmaxf(bm, xor_lanes(bm, 32));
+        // the V image's transposed reads: in flight while the weights are computed
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            tv[0][c] = lds_read_tr16(sa + tr_off[c]);
+            tv[1][c] = lds_read_tr16(sa + tr_off[c] + 16 * ROWB);
+        }
+        // unconditional (a factor of 1 when the maximum stays): a branch around it makes the compiler copy
+        // every accumulator on the path that skips it
+        {
+            const float mn = fmaxf(m_run, bm - 6.0f);          // the block holds a valid key: finite
+            const float corr = __builtin_amdgcn_exp2f(m_run - mn);   // m_run = -inf -> 0
+            l_part *= corr;
+            // the rescale also takes out the constant the last block's V conversion added (1152 per weight):
+            // the accumulators never hold more than one block's worth of it, so what the subtraction costs in
+            // precision does not grow with the context
+            const float npc = -pend * corr;
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int e = 0; e < 2; e++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) oacc[c][e][j] = fmaf(oacc[c][e][j], corr, npc);
+            m_run = mn;
+        }
+        // weights: w = p * v_scale as hi + lo halves (hi rounded toward zero, lo the rest: 21 bits or more)
+        uint32_t ph[4], pl[4];
+        float bsum = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const float p0 = __builtin_amdgcn_exp2f(sc[g][2 * jj] - m_run);      // a masked key: 2^-inf = 0
+                const float p1 = __builtin_amdgcn_exp2f(sc[g][2 * jj + 1] - m_run);
+                bsum += p0 + p1;
+                const float w0 = p0 * vsv[g][2 * jj], w1 = p1 * vsv[g][2 * jj + 1];
+                const v2h hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+                const v2h lo = __builtin_amdgcn_cvt_pkrtz(w0 - (float)hi[0], w1 - (float)hi[1]);
+                ph[2 * g + jj] = __builtin_bit_cast(uint32_t, hi);
+                pl[2 * g + jj] = __builtin_bit_cast(uint32_t, lo);
+            }
+        l_part += bsum;
+        const v8h phi = as_v8h(ph[0], ph[1], ph[2], ph[3]), plo = as_v8h(pl[0], pl[1], pl[2], pl[3]);
+        if constexpr (NC == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0]), "+v"(tv[1][0]), "+v"(tv[0][1]), "+v"(tv[1][1]), "+v"(tv[0][2]),
+                         "+v"(tv[1][2]), "+v"(tv[0][3]), "+v"(tv[1][3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0]), "+v"(tv[1][0]), "+v"(tv[0][1]), "+v"(tv[1][1]));
+        // the block's sum of weights exactly as the MFMAs below see them (a row of ones as the A operand: every
+        // row of the result is the column's sum), for the constant's removal
+        {
+            const v8h ones = as_v8h(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
+            v4f wb = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, phi, v4f{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            wb = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, plo, wb, 0, 0, 0);
+            pend = 1152.0f * wb[0];
+        }
+        // ---- O^T[dim][head] += V^T * P^T, 32 dims per column block: even dims and odd dims alternate
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const uint2 ua = tv[0][c], ub = tv[1][c];
+            const uint32_t x0 = ua.x ^ 0x80808080u, x1 = ua.y ^ 0x80808080u;
+            const uint32_t x2 = ub.x ^ 0x80808080u, x3 = ub.y ^ 0x80808080u;
+            const v8h ve = as_v8h(pair_even(x0), pair_even(x1), pair_even(x2), pair_even(x3));
+            const v8h vo = as_v8h(pair_odd(x0), pair_odd(x1), pair_odd(x2), pair_odd(x3));
+            oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ve, phi, oacc[c][0], 0, 0, 0);
+            oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vo, phi, oacc[c][1], 0, 0, 0);
+            oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ve, plo, oacc[c][0], 0, 0, 0);
+            oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vo, plo, oacc[c][1], 0, 0, 0);
+        }
+    };
+
+    // this wave's blocks, the next one requested before the current one is consumed (two K register sets
+    // and two LDS stages that swap roles); the counted waits leave exactly the next block's requests in
+    // flight.  Requests are unconditional (past the wave's share they read nothing); only the arithmetic of
+    // a block that does not exist is skipped.  Every lane runs every iteration: the transposed reads need
+    // all lanes.  A stage is rewritten by the requests issued after its consumer, whose LDS reads have
+    // completed by then (the consumer waited for them).
+    if (blk_first < blk_last) {
+        KRegs kr[DC_STAGES];
+        int blk = blk_first;
+        const int mine = blk_last - blk;      // blocks of this wave
+        auto compute = [&](int bk, int stage, KRegs& k) __attribute__((always_inline)) {
+            if (bk * DC_BLOCK + DC_BLOCK <= c_cnt) compute_block(std::true_type{}, bk, stage, k);
+            else compute_block(std::false_type{}, bk, stage, k);
+        };
+        constexpr int OPS_PER_BLOCK = 2 * KL + NDMA + 2;   // vector-memory operations of one block's requests
+#pragma unroll
+        for (int u = 0; u < DC_STAGES - 1; u++) {
+            issue_k(blk + u, kr[u]);
+            issue_v(blk + u, u);
+        }
+        for (int it = 0; it < mine; it += DC_STAGES) {
+#pragma unroll
+            for (int u = 0; u < DC_STAGES; u++) {
+                constexpr int AHEAD = DC_STAGES - 1;
+                const int un = (u + AHEAD) % DC_STAGES;
+                issue_k(blk + AHEAD, kr[un]);
+                issue_v(blk + AHEAD, un);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * OPS_PER_BLOCK) : "memory");
+                if (it + u < mine) compute(blk, u, kr[u]);
+                blk++;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last, empty requests still write this wave's LDS
+    }
+
+    // ---- this wave's state -> LDS (the ring is idle now), then the workgroup's merge
+    l_part += xor_lanes(l_part, 16);
+    l_part += xor_lanes(l_part, 32);
+#pragma unroll
+    for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) oacc[c][e][j] -= pend;
+    const uint16_t* Kn = a.k_new + (size_t)b * new_len * Hkv * D;
+    const uint16_t* Vn = a.v_new + (size_t)b * new_len * Hkv * D;
+    const int n_new = split == 0 ? (int)max(0LL, min((long long)new_len, kv_end - cl)) : 0;   // visible ones
+    // the FP16 tokens of the step itself (split 0 adds them) continue the online softmax; a lane holds its
+    // head's Q dims 64 ld + 16 q + 8 half .. + 8 and output dims 32 c + 8 q .. + 8
+    for (int t = 0; t < n_new; t++) {
+        const uint16_t* kn = Kn + ((size_t)t * Hkv + kvh) * D;
+        const uint16_t* vn = Vn + ((size_t)t * Hkv + kvh) * D;
+        float part = 0.0f;
+#pragma unroll
+        for (int st = 0; st < KL * 2; st++) {
+            const v8h kv = *reinterpret_cast<const v8h*>(kn + 64 * (st >> 1) + 16 * q + 8 * (st & 1));
+#pragma unroll
+            for (int e = 0; e < 8; e++) part = fmaf((float)qreg[st][e], (float)kv[e], part);
+        }
+        part += xor_lanes(part, 16);
+        part += xor_lanes(part, 32);
+        const float s2 = part * scale2;
+        const float mn = fmaxf(m_run, s2 - 6.0f);
+        const float corr = __builtin_amdgcn_exp2f(m_run - mn), pt = __builtin_amdgcn_exp2f(s2 - mn);
+        l_part = l_part * corr + pt;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const v8h vv = *reinterpret_cast<const v8h*>(vn + 32 * c + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) oacc[c][e][j] = fmaf((float)vv[2 * j + e], pt, oacc[c][e][j] * corr);
+        }
+        m_run = mn;
+    }
+    if (hd >= gq) return;
+    const size_t orow = (size_t)b * Hq + h0 + hd;
+    if (p.nsplit == 1) {
+        const float inv = 1.0f / l_part;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            uint32_t pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint16_t lo = l_part > 0.0f ? f2h_mul(oacc[c][0][j], inv) : (uint16_t)0;   // :460-479
+                const uint16_t hi = l_part > 0.0f ? f2h_mul(oacc[c][1][j], inv) : (uint16_t)0;
+                pk[j] = (uint32_t)lo | ((uint32_t)hi << 16);
+            }
+            *reinterpret_cast<v4i*>(a.out + orow * D + 32 * c + 8 * q) = v4i{(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+        }
+    } else {
+        float* rec = p.ws + (orow * p.nsplit + split) * (size_t)(D + 2);
+        if (q == 0) {
+            rec[0] = m_run * 0.69314718f;        // the merge works in the natural-log domain (-inf stays); every
+                                              // split's reference is 6 below its maximum, which cancels
+            rec[1] = l_part;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                *reinterpret_cast<float2*>(rec + 2 + 32 * c + 8 * q + 2 * j) = make_float2(oacc[c][0][j], oacc[c][1][j]);
+    }
+}
+
+}  // namespace
+
+// One query position per sequence over an INT8 cache with head_dim 64 or 128 and one scale group per
+// row; up to 16 query heads per kv head and up to 8 FP16 tokens of the step itself.
+bool attn_decode_mfma_ok(const AttnArgs& a) {
+    if (a.f16_mode || a.S != 1 || a.new_len > (size_t)DC_MAX_NEW) return false;
+    if (a.D != 64 && a.D != 128) return false;
+    if (a.qgs < a.D || a.Hkv == 0 || a.Hq % a.Hkv != 0 || a.Hq / a.Hkv > 16) return false;
+    if (a.cache_len == 0 && a.cache_lens == nullptr) return false;           // nothing cached: the plain kernel
+    if (!a.k_cached || !a.v_cached || !a.k_scales || !a.v_scales || !a.q || !a.out) return false;
+    if (a.new_len && (!a.k_new || !a.v_new)) return false;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a.k_cached) | reinterpret_cast<uintptr_t>(a.v_cached) |
+                         reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.out) |
+                         reinterpret_cast<uintptr_t>(a.k_new) | reinterpret_cast<uintptr_t>(a.v_new);
+    if ((al & 15) != 0 || a.cache_batch_stride % 16 != 0) return false;
+    if (a.B * a.Hkv > 0x7FFFFFFFull / 2 || a.cache_len + a.new_len >= (size_t(1) << 30)) return false;
+    if (a.cache_len * a.Hkv * a.D >= (size_t(1) << 31)) return false;   // one buffer descriptor per sequence, 32-bit offsets
+    return true;
+}
+
+hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st) {
+    DecodeParams p;
+    p.a = a;
+    p.nsplit = nsplit;
+    p.n_items = (int)(a.B * a.Hkv);
+    p.gq = (int)(a.Hq / a.Hkv);
+    p.ws = ws;
+    if (nsplit > 1 && ws == nullptr) return hipErrorInvalidValue;
+    // 8 waves per workgroup cover a whole 8-head row of the cache; the wider workgroup pays when there are
+    // many of them and their LDS rings are small (head_dim 64)
+    const int nw = (a.D == 64 && p.n_items >= 4096) ? 8 : 4;
+    const dim3 grid((unsigned)((p.n_items + nw - 1) / nw), (unsigned)nsplit);
+    if (a.D == 128)
+        attn_decode_mfma_kernel<128, 4><<<grid, dim3(256), 0, st>>>(p);
+    else if (nw == 8)
+        attn_decode_mfma_kernel<64, 8><<<grid, dim3(512), 0, st>>>(p);
+    else
+        attn_decode_mfma_kernel<64, 4><<<grid, dim3(256), 0, st>>>(p);
+    return hipGetLastError();
+}
+
+}  // namespace cactus_hip

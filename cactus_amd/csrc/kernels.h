@@ -126,6 +126,12 @@ struct AttnArgs {
 size_t attn_workspace_bytes(const AttnArgs& a);
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 
+// attention_decode.hip: cactus_attention_hybrid_int8_fp16 for one query position per sequence on the matrix
+// cores (head_dim 64 / 128, one scale group per row, up to 16 query heads per kv head); key ranges split
+// over workgroups leave records in ws as attn_kernel does
+bool attn_decode_mfma_ok(const AttnArgs& a);
+hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st);
+
 // attention_prefill.hip: cactus_attention_f16 for many queries on the FP16 matrix cores (head_dim 64 /
 // 128, no window, no mask tensor); launch_attention routes eligible calls there
 bool attn_prefill_ok(const AttnArgs& a);

@@ -35,11 +35,17 @@ def make_model(rng, LAYERS, VOCAB, gain):
     def mat(n, k, gain):
         B, Bs = rand_weights_int8(rng, n, k)
         return B, (Bs.astype(np.float32) * gain).astype(np.float16)
+    # The branches are kept small against the residual stream (embedding rows have standard deviation 2.6;
+    # an attention or MLP branch adds about a tenth of that), as in a trained network: v / o / down take a
+    # tenth of `gain`, gate / up a fifth.  With every matrix at the same gain each block multiplies the
+    # stream by 25 or more, the stream forgets its past, and the model is a chaotic map whose logits move
+    # by several per cent when one INT8 value anywhere flips - a test of nothing.
+    rel = {"q": 1.0, "k": 1.0, "v": 0.1, "o": 0.1, "gate": 0.2, "up": 0.2, "down": 0.1}
     layers = []
     for _ in range(LAYERS):
-        L = {name: mat(n, k, gain) for name, (n, k) in {"q": (HQ * D, HID), "k": (HKV * D, HID), "v": (HKV * D, HID),
-                                                         "o": (HID, HQ * D), "gate": (FF, HID), "up": (FF, HID),
-                                                         "down": (HID, FF)}.items()}
+        L = {name: mat(n, k, gain * rel[name]) for name, (n, k) in {"q": (HQ * D, HID), "k": (HKV * D, HID), "v": (HKV * D, HID),
+                                                                    "o": (HID, HQ * D), "gate": (FF, HID), "up": (FF, HID),
+                                                                    "down": (HID, FF)}.items()}
         for name, n in {"in_norm": HID, "post_norm": HID, "q_norm": D, "k_norm": D}.items():
             L[name] = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float16)
         layers.append(L)
@@ -135,21 +141,21 @@ def graph_forward(G, g, wn, tokens, pos, cache):
 
 
 @pytest.mark.parametrize("seed,prompt_len,steps,LAYERS,VOCAB,gain", [(3, 11, 14, 4, 8192, 0.05), (8, 1, 10, 4, 8192, 0.05),
-                                                                      (5, 9, 64, 28, 151936, 0.02)])
+                                                                      (5, 9, 64, 28, 151936, 0.05)])
 def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain):
-    """Every op but attention reproduces the oracle bit for bit and attention differs by fp32 summation
-    order, so a step is bit-exact unless one fp16 ulp of an attention output flips a value of the next
-    INT8 activation quantization; a synthetic model with random weights then amplifies the flip through
-    the remaining blocks to several per cent of the largest logit (and, left alone, the two KV caches drift
-    apart from there: 3 % after the first flip, 8 % fifty steps later in this 28-block model).  To judge
-    every step on its own, each step starts from the oracle's state: after a step the rows the device
-    appended to its cache are compared with the oracle's and replaced by them.
-    Bars per step: logits bit-exact, or within 2e-2 + 1e-1 * max|logit| (a flip in an early block of 28 reached
-    8 % in one step); the greedy token identical, or
-    (at most twice in a run) different only where the oracle itself separates the two candidates by less
-    than twice the difference between the rows.  Most steps must be bit-exact.  A synthetic model soon
-    repeats one token: when the chosen token has been produced before, the run continues from a fresh
-    seeded token instead."""
+    """Every op but attention reproduces the oracle bit for bit.  Decode attention runs on the matrix
+    cores (fp16 products, fp32 sums in the MFMA's order, exp2): its outputs agree with the oracle's to
+    within an fp16 ulp, not bit for bit, so about one value in a thousand rounds the other way and the
+    following INT8 activation quantization now and then turns that into a different quantized value.
+    To judge every step on its own, each step starts from the oracle's state: after a step the rows the
+    device appended to its cache are compared with the oracle's and replaced by them.
+    Bars per step: logits within 2e-2 + rel * max|logit|, rel = 5e-3 for 4 blocks and 1.5e-2 for 28
+    (observed: 0.27 % and 0.87 %); the greedy token identical, or (at most twice in a run) different only
+    where the oracle itself separates the two candidates by less than twice the difference between the
+    rows.  The first step (prompt, FP16 attention in the oracle's summation order) and every step's
+    first-block K/V rows (computed before any attention) must be bit-exact.  A synthetic model soon repeats
+    one token: when the chosen token has been produced before, the run continues from a fresh seeded
+    token instead."""
     import cactus_amd.hip as H
     rng = np.random.default_rng(seed)
     m = make_model(rng, LAYERS, VOCAB, gain)
@@ -159,7 +165,7 @@ def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain
     cache = G.KVCache(LAYERS, 2048, HKV, D)
     ocaches = [None] * LAYERS
 
-    tokens, near_ties, exact_steps, exact_rows, rows = [], 0, 0, 0, 0
+    tokens, near_ties = [], 0
     feed, pos = prompt, 0
     for step in range(steps):
         lg_d = graph_forward(G, g, wn, feed, pos, cache)
@@ -167,8 +173,8 @@ def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain
         ref = lg_o.astype(np.float64)
         err = np.abs(lg_d.astype(np.float64) - ref).max()
         exact = np.array_equal(lg_d.view(np.uint16), lg_o.view(np.uint16))
-        exact_steps += int(exact)
-        assert err <= 2e-2 + 1e-1 * np.abs(ref).max(), (step, err, np.abs(ref).max())
+        assert err <= 2e-2 + (5e-3 if LAYERS <= 4 else 1.5e-2) * np.abs(ref).max(), (step, err, np.abs(ref).max())
+        assert exact or step > 0
         td = int(H.sample_greedy(torch.from_numpy(lg_d[None].copy()).cuda()).cpu()[0])
         to = int(O.sample_greedy(lg_o[None])[0])
         tokens.append(to)
@@ -182,15 +188,12 @@ def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain
             ok_, oks, ov, ovs = (a[pos:pos + n] for a in ocaches[li])
             same = np.array_equal(dk[pos:], ok_) and np.array_equal(dks[pos:], oks) and \
                 np.array_equal(dv[pos:], ov) and np.array_equal(dvs[pos:], ovs)
-            rows += 1
-            exact_rows += int(same)
-            assert same or not exact or li > 0, (step, li)
+            assert same or li > 0, (step, li)
             if not same:
                 cache.upload_rows(li, pos, ok_, oks, ov, ovs)
         pos += n
         feed = [to] if tokens.count(to) <= 1 else [int(rng.integers(0, VOCAB))]
     assert near_ties <= 2 and cache.get_total_seq_len() == prompt_len + steps - 1
-    assert exact_steps >= 0.6 * steps and exact_rows >= 0.8 * rows, (exact_steps, steps, exact_rows, rows)
     assert len(set(tokens)) > 1           # not a degenerate stream
     g.close()
     cache.close()
@@ -357,17 +360,18 @@ def lfm2_model(rng, gain):
         B, Bs = rand_weights_int8(rng, n, k)
         return B, (Bs.astype(np.float32) * g).astype(np.float16)
     layers = []
+    lo = 0.3 * gain     # the matrices that write to the residual stream (and v): small branches, see make_model
     for t in c["TYPES"]:
-        L = {"gate": mat(c["FF"], c["HID"], gain), "up": mat(c["FF"], c["HID"], gain), "down": mat(c["HID"], c["FF"], gain),
+        L = {"gate": mat(c["FF"], c["HID"], gain), "up": mat(c["FF"], c["HID"], gain), "down": mat(c["HID"], c["FF"], lo),
              "in_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16),
              "post_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
         if t == "a":
             L.update(q=mat(c["HQ"] * c["D"], c["HID"], gain), k=mat(c["HKV"] * c["D"], c["HID"], gain),
-                     v=mat(c["HKV"] * c["D"], c["HID"], gain), o=mat(c["HID"], c["HQ"] * c["D"], gain),
+                     v=mat(c["HKV"] * c["D"], c["HID"], lo), o=mat(c["HID"], c["HQ"] * c["D"], lo),
                      q_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16),
                      k_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16))
         else:
-            L.update(in_proj=mat(3 * c["HID"], c["HID"], gain), out_proj=mat(c["HID"], c["HID"], gain),
+            L.update(in_proj=mat(3 * c["HID"], c["HID"], gain), out_proj=mat(c["HID"], c["HID"], lo),
                      conv_w=(rng.standard_normal((c["HID"], 1, c["K"])) * 0.5).astype(np.float16))
         layers.append(L)
     return {"layers": layers, "emb": mat(c["VOCAB"], c["HID"], 1.0),
@@ -480,7 +484,7 @@ def test_lfm2_shape_greedy_tokens(G):
         lg_o = lfm2_oracle_forward(m, feed, pos, kv, conv).view(np.float16)
         ref = lg_o.astype(np.float64)
         err = np.abs(lg_d.astype(np.float64) - ref).max()
-        assert err <= 2e-2 + 2e-2 * np.abs(ref).max(), (step, err, np.abs(ref).max())
+        assert err <= 2e-2 + 1e-2 * np.abs(ref).max(), (step, err, np.abs(ref).max())    # observed: 0.55 %
         td = int(H.sample_greedy(torch.from_numpy(lg_d[None].copy()).cuda()).cpu()[0])
         to = int(O.sample_greedy(lg_o[None])[0])
         assert td == to, (step, toks, td, to, np.sort(ref)[-2:])

@@ -32,13 +32,18 @@ def ST():
 def make_model(rng, layers, vocab, gain, mixed):
     from cactus_amd.steps import mixed_policy_int4
 
-    def mat(n, k, int4=False):
+    def mat(n, k, g, int4=False):
         B, Bs = (rand_weights_int4 if int4 else rand_weights_int8)(rng, n, k)
         # nibbles span [-8, 7] where bytes span [-127, 127]: larger group scales keep the weights' magnitude
-        return B, (Bs.astype(np.float32) * gain * (16.0 if int4 else 1.0)).astype(np.float16)
+        return B, (Bs.astype(np.float32) * g * (16.0 if int4 else 1.0)).astype(np.float16)
+    # Branches small against the residual stream (embedding rows: standard deviation 2.6; a branch adds about a
+    # tenth of that), as in a trained network.  With every matrix at one gain each block multiplies the
+    # stream many times over and the model is a chaotic map: one flipped INT8 value anywhere moves the logits
+    # by several per cent, and a comparison of logits says nothing.
+    rel = {"q": 1.0, "k": 1.0, "v": 0.1, "o": 0.1, "gate": 0.2, "up": 0.2, "down": 0.1}
     Ls = []
     for li in range(layers):
-        L = {name: mat(n, k, mixed and mixed_policy_int4(name, li, layers))
+        L = {name: mat(n, k, gain * rel[name], mixed and mixed_policy_int4(name, li, layers))
              for name, (n, k) in {"q": (HQ * D, HID), "k": (HKV * D, HID), "v": (HKV * D, HID), "o": (HID, HQ * D),
                                   "gate": (FF, HID), "up": (FF, HID), "down": (HID, FF)}.items()}
         for name, n in {"in_norm": HID, "post_norm": HID, "q_norm": D, "k_norm": D}.items():
@@ -114,15 +119,15 @@ def load_caches(kvstate, index, b, caches, total, window=0, sink=0):
 
 class StepChecker:
     """Per (step, sequence) comparison of a device decode step that started from the oracle's state.
-    All ops but attention reproduce the oracle bit for bit, and attention differs by fp32 summation order,
-    so a step is bit-exact unless an fp16 ulp of some attention output flips a value of the next INT8
-    activation quantization; in a synthetic model with random weights such a flip grows through the
-    remaining blocks to a few per cent of the largest logit.  Bars: bit-exact, or |diff| <= 2e-2 + 6e-2 *
-    max|logit|; the greedy token equals the oracle's unless the oracle itself separates the two candidates
-    by less than twice that difference."""
+    All ops but attention reproduce the oracle bit for bit; decode attention runs on the matrix cores and
+    agrees with the oracle to within an fp16 ulp per output (about one value in a thousand rounds the other
+    way), which the next INT8 activation quantization now and then turns into a different quantized value.
+    Bars: |diff| <= 2e-2 + 1e-2 * max|logit|; the greedy token equals the oracle's unless the oracle itself
+    separates the two candidates by less than twice that difference."""
 
     def __init__(self):
         self.pairs = self.exact = self.near_ties = 0
+        self.worst = 0.0
         self.seen = set()
 
     def check(self, lg_dev, tok_dev, lg_ref_bits, where):
@@ -135,7 +140,8 @@ class StepChecker:
             assert tok_dev == to, where
             return to, True
         err = np.abs(lg_dev.astype(np.float64) - ref).max()
-        assert err <= 2e-2 + 6e-2 * np.abs(ref).max(), (where, err, np.abs(ref).max())
+        self.worst = max(self.worst, err / np.abs(ref).max())
+        assert err <= 2e-2 + 1e-2 * np.abs(ref).max(), (where, err, np.abs(ref).max())
         if tok_dev != to:
             assert ref[to] - ref[tok_dev] <= 2 * err, (where, tok_dev, to, ref[to], ref[tok_dev], err)
             self.near_ties += 1
@@ -153,7 +159,7 @@ class StepChecker:
 def test_qwen3_batched_decode_matches_oracle_per_sequence(ST, lens, mixed, window):
     layers, vocab, steps, sink = 6, 8192, 8, 4
     rng = np.random.default_rng(sum(lens) + mixed + window)
-    m = make_model(rng, layers, vocab, 0.02, mixed)
+    m = make_model(rng, layers, vocab, 0.05, mixed)
     cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
     batch = len(lens)
     dec = ST.Qwen3Decode(ST.weights_to_device(m), cfg, batch, 64, window=window, sink=sink, max_position=128)
@@ -194,9 +200,6 @@ def test_qwen3_batched_decode_matches_oracle_per_sequence(ST, lens, mixed, windo
     assert dec.kv.positions.cpu().tolist() == pos
     assert dec.kv.cache_lens.cpu().tolist() == [min(p, window) if window else p for p in pos]
     assert len(ck.seen) > 1 and ck.near_ties <= 2
-    if not window:     # a ring holds the window's tokens rotated: its attention sums in another order every step
-        assert ck.exact >= 0.7 * ck.pairs, (ck.exact, ck.pairs)
-        assert exact_rows >= 0.9 * total_rows
 
 
 def test_qwen3_chunked_prefill_matches_oracle(ST):
@@ -204,7 +207,7 @@ def test_qwen3_chunked_prefill_matches_oracle(ST):
     the last token's logits and greedy choice, and the quantized K cache the chunks leave behind."""
     layers, vocab, tokens, chunk = 4, 8192, 192, 64
     rng = np.random.default_rng(77)
-    m = make_model(rng, layers, vocab, 0.02, False)
+    m = make_model(rng, layers, vocab, 0.05, False)
     cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
     pf = ST.Qwen3Prefill(ST.weights_to_device(m), cfg, tokens, chunk)
     prompt = rng.integers(0, vocab, tokens)
@@ -249,16 +252,16 @@ def test_lfm2_batched_decode_matches_oracle_per_sequence(ST):
         return B, (Bs.astype(np.float32) * g).astype(np.float16)
     Ls = []
     for t in types:
-        L = {"gate": mat(ffn, c["HID"], 0.01), "up": mat(ffn, c["HID"], 0.01), "down": mat(c["HID"], ffn, 0.01),
+        L = {"gate": mat(ffn, c["HID"], 0.01), "up": mat(ffn, c["HID"], 0.01), "down": mat(c["HID"], ffn, 0.003),
              "in_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16),
              "post_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
         if t == "a":
             L.update(q=mat(c["HQ"] * c["D"], c["HID"], 0.01), k=mat(c["HKV"] * c["D"], c["HID"], 0.01),
-                     v=mat(c["HKV"] * c["D"], c["HID"], 0.01), o=mat(c["HID"], c["HQ"] * c["D"], 0.01),
+                     v=mat(c["HKV"] * c["D"], c["HID"], 0.003), o=mat(c["HID"], c["HQ"] * c["D"], 0.003),
                      q_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16),
                      k_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16))
         else:
-            L.update(in_proj=mat(3 * c["HID"], c["HID"], 0.01), out_proj=mat(c["HID"], c["HID"], 0.01),
+            L.update(in_proj=mat(3 * c["HID"], c["HID"], 0.01), out_proj=mat(c["HID"], c["HID"], 0.003),
                      conv_w=(rng.standard_normal((c["HID"], 1, c["K"])) * 0.5).astype(np.float16))
         Ls.append(L)
     m = {"layers": Ls, "emb": mat(vocab, c["HID"], 1.0),
@@ -299,7 +302,7 @@ def test_lfm2_batched_decode_matches_oracle_per_sequence(ST):
             load_caches(dec.kv, dec.attn_index, b, kvs[b], pos[b])
             for li in dec.state:
                 dec.state[li][b] = conv_rows(convs[b][li])
-    assert ck.near_ties <= 2 and ck.exact >= 0.7 * ck.pairs, (ck.exact, ck.pairs)
+    assert ck.near_ties <= 2
 
 
 # ------------------------------------------------------------------ per-sequence positions and the ring window
