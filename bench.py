@@ -460,6 +460,54 @@ def qwen3_decode_step(H, gen, batch, cache_len, layers=28, mixed=False):
                     + ("; MIXED precision policy (INT4 attn_v / attn_output / MLP in blocks 2..25)" if mixed else "")}
 
 
+def qwen3_decode_via_graph(H, gen, cache_len=512, tokens=24):
+    """The same Qwen3-0.6B decode step driven through the graph surface, the way the reference's engine does it
+    (cactus_amd/steps.py: Qwen3GraphModel): every token rebuilds the forward pass on a CactusGraph node by node,
+    executes it, reads the sampled token back, feeds the KV cache from the k / v nodes and soft-resets.
+    Wall-clock per token, host work included; `execute_ms` is the part inside execute() + the token read-back.
+    Reported with execute()'s fused launches on and off."""
+    import time
+    import numpy as np
+    from cactus_amd import steps as ST
+    cfg = ST.QWEN3_0P6B
+    w = ST.qwen3_synthetic_weights(gen, cfg)
+    host = {"layers": [{k: (tuple(t.cpu().numpy() for t in v) if isinstance(v, tuple) else v.cpu().numpy())
+                        for k, v in L.items()} for L in w["layers"]],
+            "emb": tuple(t.cpu().numpy() for t in w["emb"]), "final_norm": w["final_norm"].cpu().numpy()}
+    del w
+    torch.cuda.empty_cache()
+    out = {}
+    for fusion in (True, False):
+        m = ST.Qwen3GraphModel(host, cfg, max_seq=cache_len + tokens + 8, fusion=fusion)
+        rng = np.random.default_rng(3)
+        tok = m.step(rng.integers(0, cfg["vocab"], cache_len).tolist())      # prefill fills the cache
+        for _ in range(4):
+            tok = m.step([tok])
+        torch.cuda.synchronize()
+        ex_s = 0.0
+        orig_execute = m.g.execute
+
+        def timed_execute():
+            nonlocal ex_s
+            t = time.perf_counter()
+            orig_execute()
+            torch.cuda.synchronize()
+            ex_s += time.perf_counter() - t
+        m.g.execute = timed_execute
+        t0 = time.perf_counter()
+        for _ in range(tokens):
+            tok = m.step([tok])
+        dt = time.perf_counter() - t0
+        out["fused" if fusion else "node_by_node"] = {
+            "ms_per_token": round(dt / tokens * 1e3, 3), "tokens_per_s": round(tokens / dt, 1),
+            "execute_ms": round(ex_s / tokens * 1e3, 3), "fused_launches_per_token": m.g.fused_launches() // (tokens + 5),
+            "pool_allocations": m.g.pool_allocations()}
+        m.close()
+    out["note"] = ("one sequence, cache_len %d, %d tokens: graph rebuilt per token through the Python binding of the C ABI "
+                   "(about 700 node calls), synchronous token read-back" % (cache_len, tokens))
+    return out
+
+
 def lfm2_decode_step(H, gen, batch, cache_len):
     """One decode step of the LFM2-1.2B op sequence for `batch` independent sequences on one GPU
     (cactus_amd/steps.py: Lfm2Decode; 10 blocks with the short convolution, 6 with attention; dimensions from
@@ -650,6 +698,8 @@ def extra_table(H, gen, big):
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512),
                                        "b256_c512_mixed_int4": qwen3_decode_step(H, gen, 256, 512, mixed=True)}
+    torch.cuda.empty_cache()
+    ex["qwen3_decode_step_via_graph"] = qwen3_decode_via_graph(H, gen, 512)
     torch.cuda.empty_cache()
     # config 4 (1024 independent LFM2-1.2B sequences sharded over the GPUs of a node): what one GPU
     # runs at 8 GPUs (128 sequences) and at 1 GPU (1024)

@@ -888,6 +888,154 @@ bool CactusGraph::batchable_matmul(const GraphNode& n, bool* int4) const {
     return true;
 }
 
+// A matmul node that can take its FP16 rows from a producer fused into its launch: grouped INT8 or packed
+// INT4 weights (group 128), pretransposed, left operand = node `lhs_id`, weights resident.
+bool CactusGraph::fusable_matmul(const GraphNode& n, size_t lhs_id, bool* int4) const {
+    if (n.op_type != OpType::MATMUL || n.params.backend == ComputeBackend::NPU || !n.params.pretransposed_rhs)
+        return false;
+    if (n.input_ids[0] != lhs_id || n.input_ids[1] == lhs_id) return false;
+    const BufferDesc& rhs = node(n.input_ids[1]).output_buffer;
+    if (!rhs.device_valid) return false;
+    if (!rhs.is_packed_int4() && !rhs.is_grouped_int8()) return false;
+    if (rhs.group_size != 128 || rhs.scales_device == nullptr) return false;
+    *int4 = rhs.is_packed_int4();
+    return true;
+}
+
+// Every reader of node `producer_idx` is a fusable matmul (and there is at least one): their indices by precision.
+bool CactusGraph::consumer_matmuls(size_t producer_idx, std::vector<size_t>* int8_idx, std::vector<size_t>* int4_idx) const {
+    const std::vector<size_t>& cons = consumers_[producer_idx];
+    if (cons.empty()) return false;
+    const size_t id = nodes_[producer_idx]->id;
+    for (size_t c : cons) {
+        bool i4 = false;
+        if (!fusable_matmul(*nodes_[c], id, &i4)) return false;
+        (i4 ? int4_idx : int8_idx)->push_back(c);
+    }
+    return int8_idx->size() <= 16 && int4_idx->size() <= 16;
+}
+
+void CactusGraph::launch_produced(int kind, bool int4, const std::vector<size_t>& mm, const void* x, const void* x2,
+                                  const void* w, void* sum_out, float eps, size_t M, size_t K) {
+    std::vector<cactus_hip_matmul_weights> wt;
+    for (size_t c : mm) {
+        GraphNode& m = *nodes_[c];
+        const BufferDesc& rhs = node(m.input_ids[1]).output_buffer;
+        ensure_device(m.output_buffer);
+        cactus_hip_matmul_weights e;
+        e.B = int4 ? rhs.packed_int4_device : rhs.device_data;
+        e.B_scales = static_cast<const cactus_half_t*>(rhs.scales_device);
+        e.C = static_cast<cactus_half_t*>(m.output_buffer.device_data);
+        e.N = rhs.shape[0];
+        wt.push_back(e);
+    }
+    const auto* hx = static_cast<const cactus_half_t*>(x);
+    const auto* hx2 = static_cast<const cactus_half_t*>(x2);
+    int rc;
+    if (kind == 1) {
+        auto fn = int4 ? cactus_hip_matmul_int4_norm_f16act_dev : cactus_hip_matmul_int8_norm_f16act_dev;
+        rc = fn(hx, hx2, static_cast<const cactus_half_t*>(w), static_cast<cactus_half_t*>(sum_out), eps, wt.data(),
+                wt.size(), M, K, 128, nullptr);
+    } else if (kind == 2) {
+        auto fn = int4 ? cactus_hip_matmul_int4_silu_f16act_dev : cactus_hip_matmul_int8_silu_f16act_dev;
+        rc = fn(hx, hx2, wt.data(), wt.size(), M, K, 128, nullptr);
+    } else {
+        auto fn = int4 ? cactus_hip_matmul_int4_gelu_f16act_dev : cactus_hip_matmul_int8_gelu_f16act_dev;
+        rc = fn(hx, hx2, wt.data(), wt.size(), M, K, 128, nullptr);
+    }
+    abi_check(rc);
+    fused_launches_++;
+}
+
+// nodes_[norm_idx] is an RMS_NORM whose readers are all fusable matmuls: one launch per weight precision
+// computes them from the norm's input; when that input is a plain ADD of two computed nodes that has not
+// run yet, the add goes into the same launch (its sum is written out: the residual stream reads it later).
+bool CactusGraph::try_fuse_norm(size_t norm_idx, std::vector<char>& done) {
+    GraphNode& r = *nodes_[norm_idx];
+    if (r.op_type != OpType::RMS_NORM) return false;
+    const size_t src_idx = node_index_map_.at(r.input_ids[0]);
+    GraphNode& src = *nodes_[src_idx];
+    const BufferDesc& w = node(r.input_ids[1]).output_buffer;
+    const BufferDesc& shape_of = src.output_buffer;
+    if (shape_of.shape.size() != 2 || shape_of.precision != Precision::FP16 || !w.device_valid) return false;
+    const size_t M = shape_of.shape[0], K = shape_of.shape[1];
+    if (M == 0 || K == 0 || K % 128 != 0 || K > 16384 || w.total_size < K || w.precision != Precision::FP16) return false;
+    std::vector<size_t> m8, m4;
+    if (!consumer_matmuls(norm_idx, &m8, &m4)) return false;
+    const void *x = nullptr, *x2 = nullptr;
+    void* sum_out = nullptr;
+    bool with_add = false;
+    if (!done[src_idx]) {
+        // the add in front, not yet computed: same shapes on both sides (no broadcast), operands computed
+        if (src.op_type != OpType::ADD || src.input_ids.size() != 2) return false;
+        const BufferDesc& a = node(src.input_ids[0]).output_buffer;
+        const BufferDesc& b = node(src.input_ids[1]).output_buffer;
+        if (!a.device_valid || !b.device_valid || a.precision != Precision::FP16 || b.precision != Precision::FP16 ||
+            a.total_size != shape_of.total_size || b.total_size != shape_of.total_size)
+            return false;
+        ensure_device(src.output_buffer);
+        if (src.output_buffer.device_data == a.device_data || src.output_buffer.device_data == b.device_data) return false;
+        x = a.device_data; x2 = b.device_data; sum_out = src.output_buffer.device_data;
+        with_add = true;
+    } else {
+        if (!src.output_buffer.device_valid) return false;
+        x = src.output_buffer.device_data;
+    }
+    if (!m8.empty()) launch_produced(1, false, m8, x, x2, w.device_data, sum_out, r.params.epsilon, M, K);
+    if (!m4.empty()) launch_produced(1, true, m4, x, x2, w.device_data, sum_out, r.params.epsilon, M, K);
+    if (with_add) { src.output_buffer.device_valid = true; done[src_idx] = 1; }
+    done[norm_idx] = 1;      // never materialized: get_output() computes it on demand
+    for (size_t c : m8) { nodes_[c]->output_buffer.device_valid = true; done[c] = 1; }
+    for (size_t c : m4) { nodes_[c]->output_buffer.device_valid = true; done[c] = 1; }
+    return true;
+}
+
+// nodes_[mul_idx] is MULTIPLY(act(gate), up) with act = SILU or GELU read by nothing else, and every reader
+// of the product is a fusable matmul.
+bool CactusGraph::try_fuse_activation(size_t mul_idx, std::vector<char>& done) {
+    GraphNode& m = *nodes_[mul_idx];
+    if (m.op_type != OpType::MULTIPLY || m.input_ids.size() != 2) return false;
+    const size_t act_idx = node_index_map_.at(m.input_ids[0]);
+    GraphNode& act = *nodes_[act_idx];
+    if (act.op_type != OpType::SILU && act.op_type != OpType::GELU) return false;
+    if (done[act_idx] || consumers_[act_idx].size() != 1) return false;
+    const BufferDesc& gate = node(act.input_ids[0]).output_buffer;
+    const BufferDesc& up = node(m.input_ids[1]).output_buffer;
+    if (!gate.device_valid || !up.device_valid || gate.precision != Precision::FP16 || up.precision != Precision::FP16)
+        return false;
+    if (gate.shape.size() != 2 || gate.total_size != up.total_size || m.output_buffer.total_size != gate.total_size) return false;
+    const size_t M = gate.shape[0], K = gate.shape[1];
+    if (M == 0 || K == 0 || K % 128 != 0 || K > 16384) return false;
+    std::vector<size_t> m8, m4;
+    if (!consumer_matmuls(mul_idx, &m8, &m4)) return false;
+    const int kind = act.op_type == OpType::SILU ? 2 : 3;
+    if (!m8.empty()) launch_produced(kind, false, m8, gate.device_data, up.device_data, nullptr, nullptr, 0.0f, M, K);
+    if (!m4.empty()) launch_produced(kind, true, m4, gate.device_data, up.device_data, nullptr, nullptr, 0.0f, M, K);
+    done[act_idx] = 1;
+    done[mul_idx] = 1;
+    for (size_t c : m8) { nodes_[c]->output_buffer.device_valid = true; done[c] = 1; }
+    for (size_t c : m4) { nodes_[c]->output_buffer.device_valid = true; done[c] = 1; }
+    return true;
+}
+
+// A node a fused launch skipped (RMS_NORM, SILU / GELU, MULTIPLY), computed now from its inputs.
+void CactusGraph::materialize(size_t idx) {
+    GraphNode& n = *nodes_[idx];
+    if (n.output_buffer.device_valid) return;
+    if (n.op_type != OpType::RMS_NORM && n.op_type != OpType::SILU && n.op_type != OpType::GELU &&
+        n.op_type != OpType::MULTIPLY)
+        return;
+    for (size_t in : n.input_ids) {
+        materialize(node_index_map_.at(in));
+        if (!node(in).output_buffer.device_valid) return;
+    }
+    ensure_device(n.output_buffer);
+    if (n.op_type == OpType::RMS_NORM) compute_rms_norm_node(n);
+    else if (n.op_type == OpType::MULTIPLY) compute_binary_node(n);
+    else compute_activation_node(n);
+    n.output_buffer.device_valid = true;
+}
+
 void CactusGraph::execute() {
     for (auto& kv : quant_cache_) {
         if (kv.second.q) { pool_.release(kv.second.q); pool_.release(kv.second.scales); }
@@ -897,12 +1045,49 @@ void CactusGraph::execute() {
     // set_input without a reset, and "is this input valid yet" is what orders the batched matmul runs.
     for (auto& up : nodes_)
         if (up->op_type != OpType::INPUT) up->output_buffer.device_valid = false;
+    std::vector<char> done(nodes_.size(), 0);
+    consumers_.assign(nodes_.size(), {});
+    for (size_t idx = 0; idx < nodes_.size(); idx++)
+        for (size_t in : nodes_[idx]->input_ids) {
+            auto it = node_index_map_.find(in);
+            if (it != node_index_map_.end()) consumers_[it->second].push_back(idx);
+        }
     for (size_t idx = 0; idx < nodes_.size(); idx++) {
         GraphNode& n = *nodes_[idx];
+        if (done[idx]) continue;       // taken by a fused launch further up
         if (n.op_type == OpType::INPUT) {
             if (!n.output_buffer.device_valid)
                 throw std::runtime_error("Input node " + std::to_string(n.id) + " has no data");
+            done[idx] = 1;
             continue;
+        }
+        if (fusion_) {
+            // an ADD read by a norm whose rows only feed matmuls: add + norm + matmuls in one launch
+            if (n.op_type == OpType::ADD) {
+                bool taken = false;
+                for (size_t c : consumers_[idx])
+                    if (nodes_[c]->op_type == OpType::RMS_NORM && nodes_[c]->input_ids[0] == n.id && !done[c] &&
+                        try_fuse_norm(c, done)) {
+                        taken = true;
+                        break;
+                    }
+                if (taken) continue;
+            }
+            if (n.op_type == OpType::RMS_NORM && node(n.input_ids[0]).output_buffer.device_valid && try_fuse_norm(idx, done))
+                continue;
+            // an activation read only by a multiply: wait for the multiply, which may take both into its readers' launch
+            if ((n.op_type == OpType::SILU || n.op_type == OpType::GELU) && consumers_[idx].size() == 1 &&
+                nodes_[consumers_[idx][0]]->op_type == OpType::MULTIPLY && nodes_[consumers_[idx][0]]->input_ids[0] == n.id &&
+                node(n.input_ids[0]).output_buffer.device_valid)
+                continue;               // not done: the multiply decides
+            if (n.op_type == OpType::MULTIPLY) {
+                const size_t a_idx = node_index_map_.at(n.input_ids[0]);
+                if (!done[a_idx]) {     // the activation deferred above
+                    if (node(n.input_ids[1]).output_buffer.device_valid && try_fuse_activation(idx, done)) continue;
+                    materialize(a_idx);
+                    done[a_idx] = 1;
+                }
+            }
         }
         for (size_t in : n.input_ids)
             if (!node(in).output_buffer.device_valid)
@@ -917,7 +1102,7 @@ void CactusGraph::execute() {
             for (size_t j = idx; j < nodes_.size() && run.size() < 16; j++) {
                 GraphNode& m = *nodes_[j];
                 bool m4 = false;
-                if (!batchable_matmul(m, &m4) || m4 != int4) break;
+                if (done[j] || !batchable_matmul(m, &m4) || m4 != int4) break;
                 BufferDesc& lhs = node(m.input_ids[0]).output_buffer;
                 BufferDesc& rhs = node(m.input_ids[1]).output_buffer;
                 ensure_device(m.output_buffer);
@@ -935,7 +1120,7 @@ void CactusGraph::execute() {
             if (run.size() > 1) {
                 abi_check(int4 ? cactus_hip_matmul_int4_f16act_batch_dev(run.data(), run.size(), 128, nullptr)
                                : cactus_hip_matmul_int8_f16act_batch_dev(run.data(), run.size(), 128, nullptr));
-                for (size_t j = idx; j <= last; j++) nodes_[j]->output_buffer.device_valid = true;
+                for (size_t j = idx; j <= last; j++) { nodes_[j]->output_buffer.device_valid = true; done[j] = 1; }
                 idx = last;
                 continue;
             }
@@ -983,13 +1168,19 @@ void CactusGraph::execute() {
             default: break;
         }
         n.output_buffer.device_valid = true;
+        done[idx] = 1;
     }
 }
 
-void* CactusGraph::get_device_output(size_t node_id) { return node(node_id).output_buffer.device_data; }
+void* CactusGraph::get_device_output(size_t node_id) {
+    BufferDesc& b = node(node_id).output_buffer;
+    if (!b.device_valid) materialize(node_index_map_.at(node_id));   // a node a fused launch skipped
+    return b.device_data;
+}
 
 void* CactusGraph::get_output(size_t node_id) {   // graph_execute.cpp:223-229; synchronises
     BufferDesc& b = node(node_id).output_buffer;
+    if (!b.device_valid) materialize(node_index_map_.at(node_id));   // a node a fused launch skipped
     if (!b.device_valid || b.device_data == nullptr) return nullptr;
     b.host_copy.resize(b.byte_size);
     hip_check(hipMemcpy(b.host_copy.data(), b.device_data, b.byte_size, hipMemcpyDeviceToHost), "hipMemcpy D2H");
@@ -1477,6 +1668,8 @@ int cactus_hip_graph_hard_reset(void* g) {
 }
 size_t cactus_hip_graph_node_count(void* g) { return G_(g)->get_node_count(); }
 size_t cactus_hip_graph_pool_allocations(void* g) { return G_(g)->pool_device_allocations(); }
+void cactus_hip_graph_set_fusion(void* g, int on) { G_(g)->set_fusion(on != 0); }
+size_t cactus_hip_graph_fused_launches(void* g) { return G_(g)->fused_launches(); }
 
 void* cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim) {
     auto* c = new KVCache();

@@ -189,6 +189,13 @@ public:
     size_t pool_device_allocations() const { return pool_.device_allocations(); }
     void hard_reset();
     void soft_reset();   // drops every node that is not a weight (external) input
+    // execute() hands runs of nodes to the fused launches of the C ABI (on by default):
+    //   [add ->] rms_norm -> matmuls that read the normalized rows   (one launch for up to 4 rows)
+    //   silu / gelu -> multiply -> matmuls that read the product
+    // with the results of the separate nodes, bit for bit.  A node that a fused launch never materializes
+    // (the norm's rows, the activation and its product) is computed when get_output() asks for it.
+    void set_fusion(bool on) { fusion_ = on; }
+    size_t fused_launches() const { return fused_launches_; }   // fused runs taken by execute() so far
 
     size_t add_node(OpType op_type, const std::vector<size_t>& inputs,
                     const std::vector<size_t>& output_shape, const OpParams& params = {});
@@ -216,6 +223,13 @@ private:
     void ensure_device(BufferDesc& b);
     void* resident_copy(const void* host, size_t bytes);
     bool batchable_matmul(const GraphNode& n, bool* int4) const;
+    bool fusable_matmul(const GraphNode& n, size_t lhs_id, bool* int4) const;
+    bool consumer_matmuls(size_t producer_idx, std::vector<size_t>* int8_idx, std::vector<size_t>* int4_idx) const;
+    bool try_fuse_norm(size_t norm_idx, std::vector<char>& done);
+    bool try_fuse_activation(size_t mul_idx, std::vector<char>& done);
+    void launch_produced(int kind, bool int4, const std::vector<size_t>& mm, const void* x, const void* x2,
+                         const void* w, void* sum_out, float eps, size_t M, size_t K);
+    void materialize(size_t idx);
     void compute_matmul_node(GraphNode& n);
     void compute_attention_node(GraphNode& n);
     void compute_attention_int8_hybrid_node(GraphNode& n);
@@ -235,6 +249,9 @@ private:
 
     DevicePool pool_;
     std::vector<void*> retired_;   // resident copies replaced under the same host address
+    bool fusion_ = true;
+    size_t fused_launches_ = 0;
+    std::vector<std::vector<size_t>> consumers_;   // per node index: indices of the nodes that read it (this execute())
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;

@@ -51,6 +51,8 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_hard_reset": (_i, [_vp]),
     "cactus_hip_graph_node_count": (_sz, [_vp]),
     "cactus_hip_graph_pool_allocations": (_sz, [_vp]),
+    "cactus_hip_graph_set_fusion": (None, [_vp, _i]),
+    "cactus_hip_graph_fused_launches": (_sz, [_vp]),
     "cactus_hip_kvcache_create": (_vp, [_sz, _sz, _sz, _sz]),
     "cactus_hip_kvcache_destroy": (None, [_vp]),
     "cactus_hip_kvcache_set_window": (_i, [_vp, _sz, _sz]),
@@ -287,6 +289,14 @@ class CactusGraph:
 
     def pool_allocations(self):
         return lib.cactus_hip_graph_pool_allocations(self._g)
+
+    def set_fusion(self, on):
+        """Whether execute() hands [add ->] rms_norm -> matmuls and silu/gelu -> multiply -> matmuls runs to the
+        fused launches (default on; same results bit for bit)."""
+        lib.cactus_hip_graph_set_fusion(self._g, 1 if on else 0)
+
+    def fused_launches(self):
+        return lib.cactus_hip_graph_fused_launches(self._g)
 
 
 def parse_cact_header(data):

@@ -417,3 +417,89 @@ class Lfm2Decode:
         H.sample_greedy(self.logits, out=kv.tok)
         if advance:
             kv.advance(1)
+
+
+class Qwen3GraphModel:
+    """One sequence driven node by node through the graph surface, as the reference's engine does:
+    the Qwen forward pass (models/model_qwen.cpp:51-172) rebuilt on a CactusGraph every step, the INT8
+    KVCache fed from the k / v nodes (engine_cache.cpp:186-266), greedy sampling as a SAMPLE node, soft
+    reset between steps (Model::prefill / Model::decode, engine_model.cpp:170-253).
+
+    weights: the host model (numpy arrays, the dict layout of this module); they are bound once as
+    external inputs and stay resident on the device across soft resets."""
+
+    def __init__(self, weights, cfg, max_seq=2048, fusion=True):
+        from . import graph as G
+        import numpy as np
+        self.G, self.np, self.cfg = G, np, cfg
+        self.g = G.CactusGraph()
+        self.g.set_fusion(fusion)
+        self.cache = G.KVCache(cfg["layers"], max_seq, cfg["kv_heads"], cfg["head_dim"])
+        self.pos = 0
+
+        def weight(pair):
+            B, Bs = pair
+            K = B.shape[1] * (2 if B.dtype == np.uint8 else 1)
+            n = self.g.input((B.shape[0], K), G.INT8)
+            if B.dtype == np.uint8:
+                self.g.set_packed_int4(n, B)
+            else:
+                self.g.set_external_input(n, B)
+            self.g.set_grouped_scales(n, 128, K // 128, Bs)
+            return n
+
+        def vec(a):
+            n = self.g.input(a.shape, G.FP16)
+            self.g.set_external_input(n, a)
+            return n
+        self.wn = {"emb": weight(weights["emb"]), "final_norm": vec(weights["final_norm"]),
+                   "layers": [{k: (weight(v) if isinstance(v, tuple) else vec(v)) for k, v in L.items()}
+                              for L in weights["layers"]]}
+
+    def forward(self, tokens):
+        """Adds the nodes of one forward pass over `tokens` at the current position; returns (logits node,
+        k nodes, v nodes).  Nothing runs until execute()."""
+        g, G, c, np = self.g, self.G, self.cfg, self.np
+        S, Hq, Hkv, D, Hd = len(tokens), c["q_heads"], c["kv_heads"], c["head_dim"], c["hidden"]
+        idx = g.input((S,), G.FP32)
+        g.set_input(idx, np.asarray(tokens, np.float32))
+        h = g.embedding(self.wn["emb"], idx)
+        ks, vs = [], []
+        scale = 1.0 / float(np.sqrt(D))
+        for li, L in enumerate(self.wn["layers"]):
+            n1 = g.rms_norm(h, L["in_norm"], c["eps"])
+            q, k, v = (g.matmul(n1, L[name], True) for name in ("q", "k", "v"))
+            q = g.reshape(g.rms_norm(g.reshape(q, (S * Hq, D)), L["q_norm"], c["eps"]), (1, S, Hq, D))
+            k = g.reshape(g.rms_norm(g.reshape(k, (S * Hkv, D)), L["k_norm"], c["eps"]), (1, S, Hkv, D))
+            v = g.reshape(v, (1, S, Hkv, D))
+            q, k = g.rope(q, c["theta"], self.pos), g.rope(k, c["theta"], self.pos)
+            ks.append(k)
+            vs.append(v)
+            if self.cache.is_empty():
+                attn = g.attention(q, k, v, scale, self.pos)
+            else:
+                attn = g.attention_int8_hybrid(q, k, v, scale, self.pos, self.cache.get_keys_int8(li),
+                                               self.cache.get_values_int8(li), self.cache.get_key_scales(li),
+                                               self.cache.get_value_scales(li), self.cache.get_effective_seq_len(),
+                                               Hkv, D)
+            h = g.add(h, g.matmul(g.reshape(attn, (S, Hq * D)), L["o"], True))
+            n2 = g.rms_norm(h, L["post_norm"], c["eps"])
+            act = g.multiply(g.silu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
+            h = g.add(h, g.matmul(act, L["down"], True))
+        last = g.reshape(g.index(g.rms_norm(h, self.wn["final_norm"], c["eps"]), S - 1, 0), (1, Hd))   # engine_model.cpp:241-246
+        return g.matmul(last, self.wn["emb"], True), ks, vs
+
+    def step(self, tokens):
+        """Prefill (several tokens) or decode (one): runs the pass, appends to the cache, returns the greedy token."""
+        logits, ks, vs = self.forward(tokens)
+        tok = self.g.sample(logits, 0.0, 0.0, 0)          # temperature 0, no top-p / top-k: greedy (kernel_nn.cpp:451)
+        self.g.execute()
+        out = int(self.g.get_output(tok).view(self.np.uint32)[0])
+        self.cache.update_from_graph(self.g, ks, vs, len(tokens))
+        self.g.soft_reset()
+        self.pos += len(tokens)
+        return out
+
+    def close(self):
+        self.g.close()
+        self.cache.close()

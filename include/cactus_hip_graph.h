@@ -112,6 +112,16 @@ size_t cactus_hip_graph_node_count(void* graph);
  * buffers in a pool across execute() and soft_reset() (the reference's BufferPool,
  * graph_execute.cpp:640-675), so the count stops growing once a step has run. */
 size_t cactus_hip_graph_pool_allocations(void* graph);
+/* execute() recognizes the runs a decoder block is made of and hands each to one fused launch of
+ * cactus_hip.h, with the separate nodes' results bit for bit (on by default; the reference executes node
+ * by node, graph_execute.cpp:480-560, and fuses nothing):
+ *   [add ->] rms_norm -> the matmuls reading the normalized rows   (model_qwen.cpp:51-57, 109-113)
+ *   silu / gelu -> multiply -> the matmuls reading the product     (model_qwen.cpp:114-116)
+ * The run must be closed: every reader of the norm (of the product) is a grouped INT8 / INT4 matmul with
+ * it as the left operand.  A node such a launch never writes (the norm's rows, the activation, the
+ * product) is computed when its output is asked for.  fused_launches: fused launches issued so far. */
+void   cactus_hip_graph_set_fusion(void* graph, int on);
+size_t cactus_hip_graph_fused_launches(void* graph);
 
 void*  cactus_hip_kvcache_create(size_t layers, size_t max_seq, size_t kv_heads, size_t head_dim);
 void   cactus_hip_kvcache_destroy(void* cache);

@@ -680,3 +680,97 @@ def test_buffer_pool_survives_soft_reset(G):
         assert g.get_node_count() == 1     # the weight survives
     assert counts[0] > 0 and counts[1] == counts[0] and counts[3] == counts[0], counts
     g.close()
+
+
+# ---------------------------------------------------------------------------- fused runs
+def _decoder_mlp_block(G, g, rng, M, HID, FF, mixed, act):
+    """h2 = h + o;  n = rms_norm(h2);  out = h2 + down(act(gate(n)) * up(n))  plus a second norm without an add
+    in front -- the node order a model builds (gate, activation, up, multiply)."""
+    def weight(n, k, int4):
+        node = g.input((n, k), G.INT8)
+        if int4:
+            Bp, Bs = rand_weights_int4(rng, n, k)
+            g.set_packed_int4(node, Bp)
+        else:
+            B, Bs = rand_weights_int8(rng, n, k)
+            g.set_external_input(node, B)
+        g.set_grouped_scales(node, 128, k // 128, (Bs.astype(np.float32) * 0.05).astype(np.float16))
+        return node
+    h = g.input((M, HID), G.FP16)
+    o = g.input((M, HID), G.FP16)
+    g.set_input(h, rand_act_f16(rng, M, HID))
+    g.set_input(o, rand_act_f16(rng, M, HID))
+    nw1, nw2 = g.input((HID,), G.FP16), g.input((HID,), G.FP16)
+    g.set_input(nw1, (1.0 + 0.1 * rng.standard_normal(HID)).astype(np.float16))
+    g.set_input(nw2, (1.0 + 0.1 * rng.standard_normal(HID)).astype(np.float16))
+    wg, wu, wd = weight(FF, HID, False), weight(FF, HID, mixed), weight(HID, FF, mixed)
+    wq = weight(HID, HID, False)
+    h2 = g.add(h, o)
+    n = g.rms_norm(h2, nw1, 1e-6)
+    gate = g.matmul(n, wg, True)
+    a = g.silu(gate) if act == "silu" else g.gelu(gate)
+    up = g.matmul(n, wu, True)
+    prod = g.multiply(a, up)
+    out = g.add(h2, g.matmul(prod, wd, True))
+    n2 = g.rms_norm(out, nw2, 1e-6)        # no add in front that has not run: norm + matmul only
+    q = g.matmul(n2, wq, True)
+    return dict(h2=h2, n=n, gate=gate, a=a, up=up, prod=prod, out=out, n2=n2, q=q)
+
+
+@pytest.mark.parametrize("M,mixed,act", [(1, False, "silu"), (3, True, "silu"), (2, False, "gelu"), (24, False, "silu"),
+                                         (24, True, "gelu")])
+def test_fused_runs_equal_node_by_node_execution(G, M, mixed, act):
+    """execute() with the fused launches against execute() node by node: every node's output identical, the
+    ones a fused launch never wrote included (computed on request)."""
+    HID, FF = 1024, 3072
+    outs = {}
+    for fusion in (False, True):
+        rng = np.random.default_rng(M + mixed)
+        g = G.CactusGraph()
+        g.set_fusion(fusion)
+        nodes = _decoder_mlp_block(G, g, rng, M, HID, FF, mixed, act)
+        g.execute()
+        if fusion:
+            # add+norm+(gate, up): one launch per weight precision; act+multiply+down: one; norm+q: one
+            assert g.fused_launches() == (4 if mixed else 3)
+        else:
+            assert g.fused_launches() == 0
+        outs[fusion] = {k: u16(g.get_output(v)).copy() for k, v in nodes.items()}
+        g.close()
+    for k in outs[True]:
+        assert np.array_equal(outs[True][k], outs[False][k]), k
+
+
+def test_fusion_leaves_open_runs_alone(G):
+    """A norm that something other than a matmul reads, and an activation read twice, are computed as nodes."""
+    rng = np.random.default_rng(4)
+    g = G.CactusGraph()
+    HID = 512
+    x = g.input((2, HID), G.FP16)
+    g.set_input(x, rand_act_f16(rng, 2, HID))
+    nw = g.input((HID,), G.FP16)
+    g.set_input(nw, np.ones(HID, np.float16))
+    w = g.input((256, HID), G.INT8)
+    B, Bs = rand_weights_int8(rng, 256, HID)
+    g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, HID // 128, Bs)
+    n = g.rms_norm(x, nw, 1e-6)
+    y = g.matmul(n, w, True)
+    z = g.add(n, x)                      # a second reader of the norm
+    a = g.silu(x)
+    p = g.multiply(a, x)
+    p2 = g.multiply(a, p)                # the activation read twice
+    y2 = g.matmul(p2, w, True)           # multiply(a, p) is not act * up of a closed run; p2's first operand is `a` though
+    g.execute()
+    xs = u16(rand_act_f16(np.random.default_rng(4), 2, HID))
+    want_n = O.rms_norm(xs, np.ones(HID, np.float16), 1e-6)
+    assert np.array_equal(u16(g.get_output(n)), want_n)
+    q, s = O.quantize_activations(want_n)
+    assert np.array_equal(u16(g.get_output(y)), O.matmul_int8(q, s, B, u16(Bs), 128))
+    assert np.array_equal(u16(g.get_output(z)), O.binary("add", want_n, xs))
+    sa = O.silu(xs)
+    want_p2 = O.binary("multiply", sa, O.binary("multiply", sa, xs))
+    assert np.array_equal(u16(g.get_output(p2)), want_p2)
+    q, s = O.quantize_activations(want_p2)
+    assert np.array_equal(u16(g.get_output(y2)), O.matmul_int8(q, s, B, u16(Bs), 128))
+    g.close()
