@@ -381,7 +381,13 @@ __device__ __forceinline__ v4i act_mul8_bits(v4i g, v4i u) {
     return o;
 }
 
-template <bool INT4, int W, int P, int CT, int PRO = 0>
+// WT (wave tiles): the W waves share the activation rows but each streams a 16-row tile of its own (tile
+// tl * W + w) over the whole of K and runs the fp32 chain in registers as the group sums come out of the
+// MFMAs - no LDS hand-over, no barrier after the prologue.  For thousands of tiles with short rows (the
+// vocabulary projection: 9496 tiles of 1024 bytes per row): each wave then has its whole tile in flight at
+// once.  Rows of several ring rounds stream faster split over the waves (the default), whose reads of one
+// row are adjacent.  Needs K % 1024 == 0 (a round is 8 groups = one 16-byte chunk of scales).
+template <bool INT4, int W, int P, int CT, int PRO = 0, bool WT = false>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
                                         uint16_t* __restrict__ C, int M, int K, int N, int tl,
@@ -394,9 +400,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     const int SC = ((G + step - 1) / step) * step;
     const int SCP = SC + 4, GP = ((G + 3) & ~3) + 4;
     constexpr int TR = SK_TN * CT;   // weight rows per tile: CT MFMA column tiles share each activation fragment
+    static_assert(!WT || (CT == 1 && PRO == 0 && P * GPU_ == 8), "wave tiles: one column tile, 8 groups per ring round");
     float* gbuf = sk_lds;                                                        // [CT][M*16][SCP] group sums
-    float* scl = sk_lds + (size_t)CT * M * 16 * SCP;                             // [TR][GP] fp32 scales
-    int8_t* lds_a = reinterpret_cast<int8_t*>(scl + TR * GP);                    // [M][K]
+    float* scl = sk_lds + (WT ? 0 : (size_t)CT * M * 16 * SCP);                  // [TR][GP] fp32 scales
+    int8_t* lds_a = reinterpret_cast<int8_t*>(scl + (WT ? 0 : TR * GP));         // [M][K]
     float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4]
     float* s_inv = wmax + W * 4;                                                            // [4]      (PRO 1)
     uint16_t* lds_x = reinterpret_cast<uint16_t*>(s_inv + 4);                               // [M][K]   (PRO 1)
@@ -404,6 +411,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, q = lane >> 4;
+    const int wtile = WT ? tl * W + w : tl;       // the tile whose weights this wave reads
     const unsigned row_bytes = INT4 ? (unsigned)K / 2 : (unsigned)K;
     const __amdgpu_buffer_rsrc_t brsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
@@ -426,7 +434,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     Boff boff;   // a row past N is out of range and reads zeros
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
-        const int n = tl * TR + ct * SK_TN + r;
+        const int n = wtile * TR + ct * SK_TN + r;
         boff.o[ct] = (n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
     }
     auto load_unit = [&](int u, const Boff& bo, Unit& R) {
@@ -438,8 +446,16 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         }
     };
     // this thread's chunks of 8 scales of the tile (fast path: chunk t + j*W*64), else out of range
-    const int n0 = tl * TR;
+    const int n0 = wtile * TR;
     const bool fast = sc_fast_shape && n0 + TR <= N;
+    // wave tiles: the fp32 chains of rows m = 4 q + i, and the lane's row of scales, 8 groups (16 bytes) per
+    // ring round, requested one round ahead
+    float run[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    v4i sc_cur = zero4;
+    auto load_scale_chunk = [&](int chunk) {
+        const int n = n0 + r;
+        return buf_load<0>(srsrc, (n < N && chunk * 8 < G) ? (unsigned)(((size_t)n * G + (size_t)chunk * 8) * 2) : SK_OOB, 0);
+    };
     auto load_scales = [&]() {
         ScRegs sr;
 #pragma unroll
@@ -450,14 +466,22 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         }
         return sr;
     };
-    auto put_group = [&](int ct, int gl, v4i acc) {
+    auto put_group = [&](int ct, int gl, v4i acc, int j8) {
+        if constexpr (WT) {      // the chain step of this group; j8 = gl % 8 (a constant after unrolling) picks its scale
+            const uint32_t x = (uint32_t)sc_cur[j8 >> 1];
+            float sv = h2f((uint16_t)((j8 & 1) ? (x >> 16) : (x & 0xFFFFu)));
+            if (INT4) sv *= 0.0625f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) run[i] = fmaf((float)acc[i], sv, run[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int m = q * 4 + i;
             if (m < M && gl < G) gbuf[((ct * M + m) * 16 + r) * SCP + gl] = (float)acc[i];
         }
     };
-    auto compute_unit = [&](int u, const Unit& R) {
+    auto compute_unit = [&](int u, const Unit& R, int pslot) {
         if constexpr (INT4) {
             const int8_t* ap = aptr_lds + (size_t)min(u, nunits - 1) * 256;
             v4i a[4] = {ldg(ap), ldg(ap + 16), ldg(ap + 128), ldg(ap + 144)};
@@ -483,7 +507,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
                     v4i acc = zero4;
                     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ae, blo, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ao, bhi, acc, 0, 0, 0);
-                    put_group(ct, 2 * u + h, acc);
+                    put_group(ct, 2 * u + h, acc, 2 * pslot + h);
                 }
             }
         } else {
@@ -496,7 +520,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
                 v4i acc = zero4;
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, R.b[ct][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, R.b[ct][1], acc, 0, 0, 0);
-                put_group(ct, u, acc);
+                put_group(ct, u, acc, pslot);
             }
         }
     };
@@ -526,8 +550,9 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         if constexpr (PRO == 1) w_stage[j] = buf_load<0>(wrsrc, i16 < npieces ? (unsigned)wpiece(i16) * 16u : SK_OOB, 0);
     }
 #pragma unroll
-    for (int p = 0; p < P; p++) load_unit(w + p * W, boff, ring[p]);
-    const ScRegs sc_regs = load_scales();
+    for (int p = 0; p < P; p++) load_unit(WT ? p : w + p * W, boff, ring[p]);
+    const ScRegs sc_regs = WT ? ScRegs() : load_scales();
+    v4i sc_next = WT ? load_scale_chunk(0) : zero4;
     if constexpr (PRO == 2 || PRO == 3) {
 #pragma unroll
         for (int j = 0; j < AST; j++) a_stage[j] = act_mul8_bits<PRO == 2 ? OP_SILU : OP_GELU>(a_stage[j], b_stage[j]);
@@ -643,17 +668,49 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         asm volatile("" ::: "memory");
     }
 
+    if constexpr (WT) {
+        const int rounds = nunits / P;               // K % 1024 == 0: whole rounds of 8 groups
+        for (int rd = 0; rd + 1 < rounds; rd++) {
+            sc_cur = sc_next;
+            sc_next = load_scale_chunk(rd + 1);
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int ul = rd * P + p;
+                compute_unit(ul, ring[p], p);
+                load_unit(ul + P, boff, ring[p]);
+            }
+        }
+        sc_cur = sc_next;
+#pragma unroll
+        for (int p = 0; p < P; p++) compute_unit((rounds - 1) * P + p, ring[p], p);
+        // rows m = 4 q + i of the accumulator: the lanes of q = 0 hold the M <= 4 real ones
+        if (q == 0 && n0 + r < N) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i < M) {
+                    float rmax = wmax[i];
+#pragma unroll
+                    for (int ww = 1; ww < W; ww++) rmax = fmaxf(rmax, wmax[ww * 4 + i]);
+                    float as = rmax / 127.0f;
+                    if (as < 1e-10f) as = 1e-10f;
+                    if (scales_out != nullptr && wtile == 0 && r == 0) scales_out[i] = as;
+                    C[(size_t)i * N + n0 + r] = f2h_mul(run[i], as);
+                }
+            }
+        }
+        return;
+    }
     const int rounds = (nunits + W * P - 1) / (W * P);
     for (int rd = 0; rd + 1 < rounds; rd++) {    // no VMEM under a branch: counted waits
 #pragma unroll
         for (int p = 0; p < P; p++) {
             const int ul = w + (rd * P + p) * W;
-            compute_unit(ul, ring[p]);
+            compute_unit(ul, ring[p], p);
             load_unit(ul + P * W, boff, ring[p]);
         }
     }
 #pragma unroll
-    for (int p = 0; p < P; p++) compute_unit(w + ((rounds - 1) * P + p) * W, ring[p]);
+    for (int p = 0; p < P; p++) compute_unit(w + ((rounds - 1) * P + p) * W, ring[p], p);
 
     // the tile's scales -> LDS as fp32 (x 1/16 for INT4)
     if (fast) {
@@ -762,6 +819,20 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     fq_body<INT4, W, P, CT>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                         reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
                         bt.N[pi], tile, (int)threadIdx.x, fq_lds);
+}
+
+// The batched launch with wave tiles: a workgroup of 4 waves quantizes its problem's activation rows once
+// and every wave streams one of 4 neighbouring tiles.  tile_end counts workgroups (4 tiles each).
+template <bool INT4>
+__global__ __launch_bounds__(256) void skinny_batch_wave_kernel(const SkinnyBatch bt) {
+    const int blk = (int)blockIdx.x;
+    int pi = 0;
+    while (pi + 1 < bt.count && blk >= bt.tile_end[pi]) pi++;
+    const int tile4 = blk - (pi ? bt.tile_end[pi - 1] : 0);
+    extern __shared__ __attribute__((aligned(16))) float fq_lds[];
+    fq_body<INT4, 4, INT4 ? 4 : 8, 1, 0, true>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
+                                    reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi],
+                                    bt.K[pi], bt.N[pi], tile4, (int)threadIdx.x, fq_lds);
 }
 
 // The same launch with a workgroup of 4 waves split into 4 / wt wave groups, each on its own tile:
@@ -940,9 +1011,20 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
 }
 
 // FP16 activations in, quantized inside the kernel (M <= 4 and skinny_fused_quant_ok only).
+// One wave per tile pays for launches of 2048 tiles or more whose rows are at most 1024 (INT4: 2048) bytes:
+// measured on M = 1, N = 151936, K = 1024: 0.64 of 8 TB/s against 0.61 (INT4: 0.53 / 0.48); N = 32768, K = 4096
+// INT4: 0.52 / 0.45; K = 8192: 0.53 against 0.63 the other way round.
+static bool wave_tiles_pay(bool int4, size_t K, size_t tiles) {
+    return tiles >= 2048 && K % 1024 == 0 && (int4 ? K <= 4096 : K <= 1024);
+}
+
 hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
                                    const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
                                    hipStream_t st) {
+    if (scales_out == nullptr && wave_tiles_pay(int4, K, (N + SK_TN - 1) / SK_TN)) {
+        const SkinnyProblem one{X, B, B_scales, C, M, K, N};     // wave tiles (the batched launch decides)
+        return launch_matmul_skinny_fq_batch(int4, &one, 1, st);
+    }
     int W, ct;
     fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &ct);
     return launch_fq(int4, W, ct, X, scales_out, B, B_scales, C, M, K, N, st);
@@ -988,6 +1070,28 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
         bt.M[i] = (int)q.M; bt.K[i] = (int)q.K; bt.N[i] = (int)q.N;
     }
     if (tiles == 0) return hipSuccess;
+    // Thousands of tiles: one wave per tile, the fp32 chain in registers (no LDS hand-over, no tile barrier)
+    {
+        bool wave_tiles = true;
+        size_t blocks = 0, lds_w = 0;
+        for (size_t i = 0; wave_tiles && i < count; i++) {
+            const SkinnyProblem& q = pr[order[i]];
+            wave_tiles = wave_tiles_pay(int4, q.K, total_tiles) && (reinterpret_cast<uintptr_t>(q.Bs) & 15) == 0;
+            lds_w = std::max(lds_w, ((q.M * q.K + 15) & ~(size_t)15) + (4 * 4 + 4) * sizeof(float) + 16);
+            blocks += ((q.N + SK_TN - 1) / SK_TN + 3) / 4;
+            bt.tile_end[i] = (int)blocks;
+        }
+        if (wave_tiles && lds_w <= 64 * 1024) {
+            if (int4) skinny_batch_wave_kernel<true><<<dim3((unsigned)blocks), dim3(256), lds_w, st>>>(bt);
+            else skinny_batch_wave_kernel<false><<<dim3((unsigned)blocks), dim3(256), lds_w, st>>>(bt);
+            return hipGetLastError();
+        }
+        size_t tt = 0;       // not taken: back to one tile per workgroup
+        for (size_t i = 0; i < count; i++) {
+            tt += (pr[order[i]].N + SK_TN * ct - 1) / (SK_TN * ct);
+            bt.tile_end[i] = (int)tt;
+        }
+    }
     // Four waves per tile: the workgroup of 4 waves is cut into wave groups per problem, so that
     // short rows (few units) get fewer waves per tile and more tiles in flight.
 #ifndef SK_SUB_K1

@@ -65,6 +65,43 @@ def test_matmul_f16_activations_fused_quant_bit_exact(H, M, K, N, int4):
 
 
 @pytest.mark.parametrize("int4", [False, True])
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 151936), (3, 1024, 32768 + 40), (4, 1024, 40000), (2, 2048, 33000),
+                                   (1, 4096, 32768)])
+def test_matmul_f16_activations_many_short_rows_bit_exact(H, M, K, N, int4):
+    """2048 tiles or more of short rows: one wave per 16-row tile with the fp32 chain in registers (the
+    vocabulary projection's launch; INT8 up to K = 1024, INT4 up to 4096 - the other shapes here take the
+    split-row kernel at the same sizes).  Ragged N, several rows, rows of very different scales."""
+    rng = np.random.default_rng(M * 31 + K + N + int4)
+    x = rand_act_f16(rng, M, K)
+    if M > 1:
+        x[1] = 0
+    if M > 2:
+        x[2] *= 30.0
+    B, Bs = (rand_weights_int4 if int4 else rand_weights_int8)(rng, N, K)
+    q, s = O.quantize_activations(x)
+    want = (O.matmul_int4 if int4 else O.matmul_int8)(q, s, B, Bs, 128)
+    got = bits(H.matmul_f16act(dev(x), dev(B), dev(Bs), 128, int4=int4))
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("int4", [False, True])
+def test_matmul_f16_activations_batch_of_short_rows_bit_exact(H, int4):
+    """The batched launch over the wave-per-tile kernel: three vocabulary-sized problems with their own rows."""
+    rng = np.random.default_rng(5 + int4)
+    mk = rand_weights_int4 if int4 else rand_weights_int8
+    entries, wants = [], []
+    for (M, K, N) in [(1, 1024, 20000), (2, 1024, 17000 + 8), (4, 1024, 16384)]:
+        x = rand_act_f16(rng, M, K)
+        B, Bs = mk(rng, N, K)
+        q, s_ = O.quantize_activations(x)
+        wants.append((O.matmul_int4 if int4 else O.matmul_int8)(q, s_, B, Bs, 128))
+        entries.append((dev(x), dev(B), dev(Bs), torch.zeros((M, N), dtype=torch.float16, device="cuda")))
+    outs = H.MatmulBatch(entries, 128, int4=int4).run()
+    for o, w in zip(outs, wants):
+        assert (bits(o) == w).all()
+
+
+@pytest.mark.parametrize("int4", [False, True])
 def test_matmul_f16_activations_batch_equals_single_calls(H, int4):
     """One batched launch of mixed shapes (shared and distinct activation rows, ragged N, one
     entry that is not fusable and runs on its own) == one call per entry == the oracle."""
