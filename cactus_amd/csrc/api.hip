@@ -959,8 +959,15 @@ int cactus_hip_sample_f16_dev(const cactus_half_t* logits, uint32_t* output, siz
     if (!draws || !workspace) return fail(CACTUS_HIP_EINVAL, "sample: draws and workspace are required");
     if ((history == nullptr) != (history_counts == nullptr))
         return fail(CACTUS_HIP_EINVAL, "sample: history and history_counts go together");
+    // top_k = 0 (or above what the first kernel holds in LDS) can leave a row more survivors than that: those
+    // rows are finished by a second kernel that works in the library workspace
+    void* wide = nullptr;
+    if ((top_k == 0 || top_k > cactus_hip_sample_max_survivors()) && vocab_size > cactus_hip_sample_max_survivors()) {
+        int rc = ::workspace(sample_wide_scratch_bytes(rows), &wide);
+        if (rc != CACTUS_HIP_OK) return rc;
+    }
     hipError_t e = launch_sample(logits, workspace, output, status, rows, vocab_size, temperature, top_p, top_k, draws,
-                                 history, history_counts, S(stream));
+                                 history, history_counts, wide, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "sample launch", e);
     return CACTUS_HIP_OK;
 }

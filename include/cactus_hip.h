@@ -371,9 +371,13 @@ int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* outp
  *   - the logit bias arguments of the reference are not taken: it overwrites the biased values
  *     before use (:473-496), so they never change a result.
  *   - workspace: device half[rows, vocab_size] scratch.
- *   - at most cactus_hip_sample_max_survivors() logits of a row may survive top-k (ties with the
- *     k-th value included; top_k == 0 keeps all finite ones): a row with more gets token
- *     0xFFFFFFFF and *status (device int, may be NULL, cleared by the caller) is set to 1.
+ *   - a row of which at most cactus_hip_sample_max_survivors() logits survive top-k is sampled by one
+ *     launch.  With top_k == 0 (every finite logit survives) or top_k above that number, rows with more
+ *     survivors are finished by a second, slower launch (about a millisecond for 150k survivors: the
+ *     reference's sequential fp32 sums in descending and in index order are kept) that works in the
+ *     library workspace (cactus_hip_workspace_reserve before stream capture: 25 MB).  Only a row whose
+ *     ties with the k-th value push a top_k <= that number beyond it gets token 0xFFFFFFFF and *status
+ *     (device int, may be NULL, cleared by the caller) set to 1.
  *   - equal logits keep ascending index order in the top-p pass (the reference leaves it to
  *     std::sort); exp is computed in double and rounded (the reference uses its libm's expf). */
 int cactus_hip_sample_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows,

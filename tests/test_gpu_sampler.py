@@ -35,6 +35,8 @@ def logits_rows(rng, rows, vocab, kind):
         x = (np.round(x.astype(np.float32) * 2) / 2).astype(np.float16)
     elif kind == "peaked":
         x[:, 7 % vocab] = np.float16(30.0)
+    elif kind == "flat":
+        x[:] = np.float16(0.5)
     elif kind == "neginf":
         x[:, ::3] = np.float16(-np.inf)
         x[:, 1] = np.float16(-0.0)
@@ -55,6 +57,13 @@ CASES = [
     (4, 999, 0.8, 0.95, 40, "neginf"),
     (3, 1, 0.7, 0.9, 3, "normal"),
     (2, 65, 0.5, 0.3, 7, "ties"),
+    # more survivors of top-k than one launch holds in LDS (4096): the second kernel's sums over the whole row
+    (2, 151936, 0.8, 0.9, 0, "normal"),      # top-p over the whole vocabulary
+    (2, 151936, 1.0, 0.5, 0, "ties"),        # the cut falls inside a bin of equal logits
+    (3, 20000, 0.7, 1.0, 0, "normal"),       # no cut: the draw walks every logit
+    (2, 20000, 0.0, 0.97, 6000, "neginf"),   # top_k above 4096, -inf entries
+    (40, 9000, 1.1, 0.8, 0, "peaked"),       # more rows than the second kernel has workgroups
+    (2, 10000, 1.0, 0.9, 0, "flat"),         # every logit equal
 ]
 
 
@@ -121,16 +130,14 @@ def test_sampler_greedy_parameters_take_the_argmax_branch(H):
 
 
 def test_sampler_reports_too_many_survivors(H):
+    """Only ties push a small top_k beyond what one launch holds: all 10000 equal logits survive top_k = 5."""
     x = np.zeros((2, 10000), np.float16)
     smp = H.Sampler(2, 10000)
     with pytest.raises(RuntimeError, match="survive"):
-        smp.sample(dev(x), 1.0, 0.9, 0, dev(np.full(2, 0.5, np.float32)))
-    out = smp.sample(dev(x), 1.0, 0.9, 0, dev(np.full(2, 0.5, np.float32)), check=False)
+        smp.sample(dev(x), 1.0, 0.9, 5, dev(np.full(2, 0.5, np.float32)))
+    out = smp.sample(dev(x), 1.0, 0.9, 5, dev(np.full(2, 0.5, np.float32)), check=False)
     assert out.cpu().numpy().astype(np.uint32).tolist() == [0xFFFFFFFF, 0xFFFFFFFF]
     smp.status.zero_()
-    # ties at the k-th value count as survivors too: all 10000 equal logits survive top_k = 5
-    with pytest.raises(RuntimeError, match="survive"):
-        smp.sample(dev(x), 1.0, 0.9, 5, dev(np.full(2, 0.5, np.float32)))
 
 
 def test_sampler_argument_errors(H):
