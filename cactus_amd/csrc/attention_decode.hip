@@ -27,8 +27,11 @@
 // the MFMA, summed by an MFMA from the same operand) block by block.  Weights enter as hi + lo binary16
 // parts (about 22 bits).
 // Per-key scales multiply the score column (K) and the weight (V), as the reference's dequantization
-// does per element.  Softmax is the online form with expf; key ranges (splits) leave (max, sum, O)
-// records that attn_merge_kernel reduces.
+// does per element.  Softmax is the online form on base-2 scores (s * log2 e, one v_exp_f32 per weight);
+// key ranges (splits) leave (max, sum, O) records that attn_merge_kernel reduces.
+// The LDS reads of the block loop are inline asm with hand-placed s_waitcnt lgkmcnt: the compiler would
+// order an LDS read it can see behind every outstanding LDS-DMA request, the next block's prefetch
+// included, and the loop would stop overlapping loads with arithmetic.
 #include "common.hip.h"
 #include "kernels.h"
 
@@ -44,12 +47,8 @@ constexpr int DC_BLOCK = 32;     // keys per block
 constexpr int DC_STAGES = 2;     // LDS stages and K register sets per wave: DC_STAGES - 1 blocks in flight
 constexpr int DC_MAX_NEW = 8;    // FP16 tokens of the step itself (decode: 1)
 
-typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-typedef short v4s __attribute__((ext_vector_type(4)));
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef __fp16 v2h __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) v4s* lds_v4s_t;
 
 __device__ __forceinline__ v8h as_v8h(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const v4i v = {(int)a, (int)b, (int)c, (int)d};
