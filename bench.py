@@ -598,7 +598,8 @@ def extra_table(H, gen, big):
     # decode attention over the INT8 KV cache
     rows = {}
     for name, Hq, Hkv, D, cache, Bn in (("qwen3_c512", 16, 8, 128, 512, 1), ("qwen3_c4096", 16, 8, 128, 4096, 1),
-                                        ("8b_c32768", 32, 8, 128, 32768, 1), ("qwen3_c4096_b64", 16, 8, 128, 4096, 64)):
+                                        ("8b_c32768", 32, 8, 128, 32768, 1), ("qwen3_c4096_b64", 16, 8, 128, 4096, 64),
+                                        ("qwen3_c512_b256", 16, 8, 128, 512, 256), ("lfm2_c512_b1024", 32, 8, 64, 512, 1024)):
         kq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
         vq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
         ks = torch.rand((Bn, cache, Hkv, 1), device="cuda", generator=gen) * 0.02
