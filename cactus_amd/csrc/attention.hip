@@ -685,6 +685,19 @@ size_t attn_workspace_bytes(const AttnArgs& a) {
     return a.B * a.Hq * a.S * (size_t)pl.nsplit * (a.D + 2) * sizeof(float);
 }
 
+hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f, void* workspace, hipStream_t st) {
+    if (!attn_decode_mfma_ok(a) || a.new_len != 1) return hipErrorInvalidValue;
+    const Plan pl = make_plan(a);
+    if (!pl.mfma) return hipErrorInvalidValue;
+    float* ws = reinterpret_cast<float*>(workspace);
+    hipError_t e = launch_attention_decode_mfma(a, ws, pl.nsplit, st, &f);
+    if (e == hipSuccess && pl.nsplit > 1) {
+        attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(ws, a.out, pl.nsplit, (int)a.D);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) {
     if (attn_prefill_ok(a)) return launch_attention_prefill(a, st);
     if (attn_prefill_hybrid_ok(a)) {

@@ -34,6 +34,7 @@
 // included, and the loop would stop overlapping loads with arithmetic.
 #include "common.hip.h"
 #include "kernels.h"
+#include "block_math.hip.h"
 
 #include <math.h>
 
@@ -84,6 +85,7 @@ struct DecodeParams {
     int n_items;  // batch * kv heads
     int gq;       // query heads per kv head (<= 16)
     float* ws;
+    AttnFusedIn f;    // FUSED kernels: what turns the projections' rows into q and k, and the cache to append to
 };
 
 // chunk swizzle of the V image: 16-byte chunk c of key row r sits at chunk c ^ swz(r), which keeps the
@@ -93,14 +95,20 @@ __device__ __forceinline__ int v_swz(int row) {
     return D == 128 ? ((row >> 1) & 3) << 1 : ((row >> 2) & 1) << 1;
 }
 
-template <int D, int NW>
+// FUSED: a.q / a.k_new / a.v_new are the q / k / v projections' rows of a decode step (one new token per
+// sequence).  Each wave first runs what qk_norm_rope_kernel does for its rows - per-head RMS norm and RoPE of its
+// query heads and of its kv head's key, with that kernel's arithmetic (16 lanes per row, rows in LDS) - and the
+// wave of key range 0 also quantizes the rotated key and the value into the cache at slot cache_lens[b]
+// (engine_cache.cpp:234-267), past the rows any wave reads.  One launch less per layer and token.
+template <int D, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     constexpr int ROWB = D;                         // bytes per key row
     constexpr int VBYTES = DC_BLOCK * ROWB;         // V image of one block
     constexpr int STAGE = VBYTES + 512;             // + 32 K scales, 128 B the request's idle lanes clear, 32 V scales, 128 B
     constexpr int KL = D / 64;                      // 16-byte loads per lane and 16-key group (D = 64: 1)
     constexpr int NC = D / 32;                      // 32-dim column blocks
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NW * DC_STAGES * STAGE];
+    constexpr int RING = NW * DC_STAGES * STAGE;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0)];   // + each wave's rotated key row
 
     const AttnArgs& a = p.a;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -132,11 +140,62 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride;
     const size_t row_stride = (size_t)Hkv * D;
 
+    uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
+    uint16_t* kn_lds = reinterpret_cast<uint16_t*>(lds + RING) + (FUSED ? w * D : 0);
+    if constexpr (FUSED) {
+        // rows of this wave, 16 lanes each, four at a time: its query heads, its key, and (key range 0) its value;
+        // they sit in the still idle ring: [gq] normalized + rotated q rows, the k row, the raw v row
+        const AttnFusedIn& f = p.f;
+        uint16_t* rows = reinterpret_cast<uint16_t*>(my_lds);
+        const int l = lane & 15, g = lane >> 4, base = lane & ~15;
+        const int nrows = gq + (split == 0 ? 2 : 0);      // only key range 0 uses the step's own key and value
+        const int pos = max(0, min((int)qabs, f.max_position));
+        const bool place = split == 0 && (size_t)cl < f.max_slots;
+        const size_t doff = (size_t)b * a.cache_batch_stride + ((size_t)cl * Hkv + kvh) * D;
+        const size_t soff = (size_t)b * a.scale_batch_stride + ((size_t)cl * Hkv + kvh) * (size_t)((D + (int)a.qgs - 1) / (int)a.qgs);
+        for (int r0 = 0; r0 < nrows; r0 += 4) {
+            const bool act = r0 + g < nrows;
+            const int r = min(r0 + g, nrows - 1);
+            const bool is_q = r < gq, is_k = r == gq, is_v = r > gq;
+            const uint16_t* src = is_q ? a.q + ((size_t)b * Hq + h0 + r) * D
+                                       : (is_k ? a.k_new : a.v_new) + ((size_t)b * Hkv + kvh) * D;
+            uint16_t* nrm = rows + (size_t)r * D;
+            if (act)
+                for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(nrm + c * 8) = *reinterpret_cast<const v4i*>(src + c * 8);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float inv = row_inv_rms([&](int i) -> uint16_t { return nrm[i]; }, D, f.eps, l, base);
+            const h16 inv_h = (h16)inv;
+            if (act && !is_v) {
+                const uint16_t* wv = is_q ? f.q_weight : f.k_weight;
+                for (int i = l; i < D; i += 16) nrm[i] = rms_out(nrm[i], wv[i], inv, inv_h, true);   // own elements
+                for (int i = l; i < D / 2; i += 16) {                                               // ... and their RoPE pairs
+                    uint16_t o1, o2;
+                    rope_pair(f.cos_t[(size_t)pos * (D / 2) + i], f.sin_t[(size_t)pos * (D / 2) + i], nrm[i], nrm[D / 2 + i], o1, o2);
+                    nrm[i] = o1;
+                    nrm[D / 2 + i] = o2;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (act && is_k)
+                for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(kn_lds + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
+            if (act && place && !is_q)
+                quant_row_groups(nrm, D, (int)a.qgs, (is_k ? f.kc : f.vc) + doff, (is_k ? f.ks : f.vs) + soff, l);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
     // Q^T operand: lane (head, q) holds, for MFMA step (ld, half), Q[head][64 ld + 16 q + 8 half .. + 8)
     v8h qreg[KL * 2];
     float qsum = 0.0f;
     {
-        const uint16_t* qrow = a.q + ((size_t)b * Hq + h0 + min(hd, gq - 1)) * D;
+        const uint16_t* qrow = FUSED ? reinterpret_cast<const uint16_t*>(my_lds) + (size_t)min(hd, gq - 1) * D
+                                     : a.q + ((size_t)b * Hq + h0 + min(hd, gq - 1)) * D;
 #pragma unroll
         for (int s = 0; s < KL * 2; s++) {
             v4i raw = *reinterpret_cast<const v4i*>(qrow + 64 * (s >> 1) + 16 * q + 8 * (s & 1));
@@ -150,8 +209,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     }
     const float nqsum = -1152.0f * qsum;
     const float scale2 = scale * 1.44269504f;     // scores are kept times log2(e)
+    if constexpr (FUSED) {      // the q rows are in registers: the ring may be written from here on
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
-    uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
     // per-lane pieces of the addresses
     const int dma_row = D == 128 ? lane >> 3 : lane >> 2;            // row inside one DMA instruction
     const int dma_chunk = D == 128 ? lane & 7 : lane & 3;
@@ -394,7 +456,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         float part = 0.0f;
 #pragma unroll
         for (int st = 0; st < KL * 2; st++) {
-            const v8h kv = *reinterpret_cast<const v8h*>(kn + 64 * (st >> 1) + 16 * q + 8 * (st & 1));
+            const int koff = 64 * (st >> 1) + 16 * q + 8 * (st & 1);
+            const v8h kv = FUSED ? *reinterpret_cast<const v8h*>(kn_lds + koff)      // the key this wave rotated itself
+                                 : *reinterpret_cast<const v8h*>(kn + koff);
 #pragma unroll
             for (int e = 0; e < 8; e++) part = fmaf((float)qreg[st][e], (float)kv[e], part);
         }
@@ -464,24 +528,26 @@ bool attn_decode_mfma_ok(const AttnArgs& a) {
     return true;
 }
 
-hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st) {
+hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st, const AttnFusedIn* fused) {
     DecodeParams p;
     p.a = a;
     p.nsplit = nsplit;
     p.n_items = (int)(a.B * a.Hkv);
     p.gq = (int)(a.Hq / a.Hkv);
     p.ws = ws;
+    if (fused) p.f = *fused;
     if (nsplit > 1 && ws == nullptr) return hipErrorInvalidValue;
+    if (fused && (a.new_len != 1 || !a.cache_lens || !a.pos_offsets || !a.is_causal)) return hipErrorInvalidValue;
     // 8 waves per workgroup cover a whole 8-head row of the cache; the wider workgroup pays when there are
     // many of them and their LDS rings are small (head_dim 64)
     const int nw = (a.D == 64 && p.n_items >= 4096) ? 8 : 4;
     const dim3 grid((unsigned)((p.n_items + nw - 1) / nw), (unsigned)nsplit);
-    if (a.D == 128)
-        attn_decode_mfma_kernel<128, 4><<<grid, dim3(256), 0, st>>>(p);
-    else if (nw == 8)
-        attn_decode_mfma_kernel<64, 8><<<grid, dim3(512), 0, st>>>(p);
-    else
-        attn_decode_mfma_kernel<64, 4><<<grid, dim3(256), 0, st>>>(p);
+#define DECODE_LAUNCH(F)                                                                   \
+    if (a.D == 128) attn_decode_mfma_kernel<128, 4, F><<<grid, dim3(256), 0, st>>>(p);      \
+    else if (nw == 8) attn_decode_mfma_kernel<64, 8, F><<<grid, dim3(512), 0, st>>>(p);     \
+    else attn_decode_mfma_kernel<64, 4, F><<<grid, dim3(256), 0, st>>>(p);
+    if (fused) { DECODE_LAUNCH(true) } else { DECODE_LAUNCH(false) }
+#undef DECODE_LAUNCH
     return hipGetLastError();
 }
 

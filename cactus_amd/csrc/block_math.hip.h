@@ -56,6 +56,38 @@ __device__ __forceinline__ uint16_t rms_out(uint16_t xb, uint16_t wb, float inv,
     return f2h_mul(h2f(xb) * inv, h2f(wb));   // all fp32, one conversion at the end (kernel_nn.cpp tail)
 }
 
+// one row of D halves in LDS -> int8 + one scale per group, by the 16 lanes of a group; lane l
+// owns elements 8l..8l+7 of each 128-wide slice of a group (kernel_quants.cpp:223-293)
+__device__ __forceinline__ void quant_row_groups(const uint16_t* row, int D, int gs, int8_t* dst, float* sc, int l) {
+    const int G = (D + gs - 1) / gs;
+    for (int g = 0; g < G; g++) {
+        const int start = g * gs, cnt = min(gs, D - start), cnt8 = cnt & ~7;
+        float m = 0.0f;
+        for (int k0 = l * 8; k0 < cnt; k0 += 128)
+            for (int k = k0; k < k0 + 8 && k < cnt; k++) m = fmaxf(m, fabsf(h2f(row[start + k])));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+        float scale = m / 127.0f;
+        if (scale < 1e-10f) scale = 1e-10f;
+        const float inv = 1.0f / scale;
+        if (l == 0) sc[g] = scale;
+        for (int k0 = l * 8; k0 < cnt; k0 += 128)
+            for (int k = k0; k < k0 + 8 && k < cnt; k++) {
+                const float v = h2f(row[start + k]) * inv;
+                dst[start + k] = (int8_t)((k < cnt8) ? clamp_i8(rne_i32(v)) : clamp_i8((int)roundf(v)));
+            }
+    }
+}
+
+// RoPE of one element pair with the arithmetic of rope_kernel's 8-wide part (kernel_attention.cpp:612-676): fp16
+// products, a fused subtract / add
+__device__ __forceinline__ void rope_pair(uint16_t cb, uint16_t sb, uint16_t x1b, uint16_t x2b, uint16_t& o1, uint16_t& o2) {
+    const h16 c = bits2h(cb), sn = bits2h(sb), x1 = bits2h(x1b), x2 = bits2h(x2b);
+    const h16 p1 = x1 * c, p2 = x2 * c;
+    o1 = h2bits(__builtin_fmaf16(-x2, sn, p1));
+    o2 = h2bits(__builtin_fmaf16(x1, sn, p2));
+}
+
 // polynomial e^x of the vector paths (kernel_utils.h:108-141)
 __device__ __forceinline__ float fast_exp(float x) {
     x = fmaxf(x, -87.0f);

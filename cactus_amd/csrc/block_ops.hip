@@ -199,29 +199,6 @@ struct KvAppendArgs {
     int window = 0, sink = 0, max_position = 0;
 };
 
-// one row of D halves in LDS -> int8 + one scale per group, by the 16 lanes of a group; lane l
-// owns elements 8l..8l+7 of each 128-wide slice of a group (kernel_quants.cpp:223-293)
-__device__ __forceinline__ void quant_row_groups(const uint16_t* row, int D, int gs, int8_t* dst, float* sc, int l) {
-    const int G = (D + gs - 1) / gs;
-    for (int g = 0; g < G; g++) {
-        const int start = g * gs, cnt = min(gs, D - start), cnt8 = cnt & ~7;
-        float m = 0.0f;
-        for (int k0 = l * 8; k0 < cnt; k0 += 128)
-            for (int k = k0; k < k0 + 8 && k < cnt; k++) m = fmaxf(m, fabsf(h2f(row[start + k])));
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
-        float scale = m / 127.0f;
-        if (scale < 1e-10f) scale = 1e-10f;
-        const float inv = 1.0f / scale;
-        if (l == 0) sc[g] = scale;
-        for (int k0 = l * 8; k0 < cnt; k0 += 128)
-            for (int k = k0; k < k0 + 8 && k < cnt; k++) {
-                const float v = h2f(row[start + k]) * inv;
-                dst[start + k] = (int8_t)((k < cnt8) ? clamp_i8(rne_i32(v)) : clamp_i8((int)roundf(v)));
-            }
-    }
-}
-
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __restrict__ q,
                                                            const uint16_t* __restrict__ k,
                                                            const uint16_t* __restrict__ qw,

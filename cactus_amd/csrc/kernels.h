@@ -130,7 +130,27 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 // cores (head_dim 64 / 128, one scale group per row, up to 16 query heads per kv head); key ranges split
 // over workgroups leave records in ws as attn_kernel does
 bool attn_decode_mfma_ok(const AttnArgs& a);
-hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st);
+// The producer of a decode step's q / k rows and the cache append, folded into the attention launch
+// (attn_decode_mfma_kernel<.., FUSED>): norm weights, RoPE tables from position 0 up to max_position, the cache
+// to append to (the buffers the attention reads, writable) and its slot count.
+struct AttnFusedIn {
+    const uint16_t* q_weight = nullptr;
+    const uint16_t* k_weight = nullptr;
+    const uint16_t* cos_t = nullptr;
+    const uint16_t* sin_t = nullptr;
+    int8_t* kc = nullptr;
+    int8_t* vc = nullptr;
+    float* ks = nullptr;
+    float* vs = nullptr;
+    float eps = 0.0f;
+    int max_position = 0;
+    size_t max_slots = 0;
+};
+hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st,
+                                        const AttnFusedIn* fused = nullptr);
+// the whole fused launch (decode kernel + split merge); a must satisfy attn_decode_mfma_ok with new_len 1 and
+// per-sequence cache_lens / pos_offsets; workspace as attn_workspace_bytes(a)
+hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f, void* workspace, hipStream_t st);
 
 // attention_prefill.hip: cactus_attention_f16 for many queries on the FP16 matrix cores (head_dim 64 /
 // 128, no window, no mask tensor); launch_attention routes eligible calls there

@@ -198,12 +198,18 @@ class Qwen3Decode:
             # cache in the same launch (the slot beyond the cached length: this step's attention reads them
             # as FP16), with a window they are appended after the attention, which must still see the token
             # a full window is about to drop
+            # Without a window all of it - norm, RoPE, cache append, attention - is one launch (head_dim 64 / 128).
             fused_append = kv.window == 0
-            H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta, kv.positions,
-                               self.max_position, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], 0, 0, 128,
-                               out_q=qr4, out_k=kr4)
-            H.attention_hybrid_batched(qr4, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], kr4, v4, 0.0, kv.cache_lens,
-                                       kv.positions, out=self.ao)
+            if fused_append and D in (64, 128):
+                H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
+                                         L["q_norm"], L["k_norm"], kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li],
+                                         kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao)
+            else:
+                H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta,
+                                   kv.positions, self.max_position, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], 0, 0,
+                                   128, out_q=qr4, out_k=kr4)
+                H.attention_hybrid_batched(qr4, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], kr4, v4, 0.0,
+                                           kv.cache_lens, kv.positions, out=self.ao)
             if not fused_append:
                 H.kv_append_windowed(kr4, v4, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], kv.positions, kv.window,
                                      kv.sink)
@@ -390,11 +396,16 @@ class Lfm2Decode:
                 ai = self.attn_index[li]
                 self.qkv[li].run(self.xq, self.xs)
                 fused_append = kv.window == 0
-                H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta,
-                                   kv.positions, self.max_position, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], 0, 0,
-                                   128, out_q=qr4, out_k=kr4)
-                H.attention_hybrid_batched(qr4, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], kr4, v4, 0.0, kv.cache_lens,
-                                           kv.positions, out=self.ao)
+                if fused_append and D in (64, 128):     # norm, RoPE, cache append and attention in one launch
+                    H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
+                                             L["q_norm"], L["k_norm"], kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai],
+                                             kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao)
+                else:
+                    H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta,
+                                       kv.positions, self.max_position, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], 0,
+                                       0, 128, out_q=qr4, out_k=kr4)
+                    H.attention_hybrid_batched(qr4, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], kr4, v4, 0.0,
+                                               kv.cache_lens, kv.positions, out=self.ao)
                 if not fused_append:
                     H.kv_append_windowed(kr4, v4, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], kv.positions, kv.window,
                                          kv.sink)

@@ -464,6 +464,26 @@ int cactus_hip_attention_hybrid_int8_fp16_batched_dev(
     float scale, const int32_t* position_offsets, size_t group_size,
     size_t cache_batch_stride, size_t scale_batch_stride, size_t max_cache_len, void* stream);
 
+/* A decode step's attention in one launch, from the q / k / v projections' rows to the attention output
+ * (model_qwen.cpp:63-99 for one new token per sequence): per-head RMS norm of q and k (q_weight, k_weight),
+ * RoPE at positions[b], the rotated key and the value quantized into slot cache_lens[b] of sequence b's cache
+ * (KVCache::update_from_graph, engine_cache.cpp:234-267), and cactus_attention_hybrid_int8_fp16 over the
+ * cache_lens[b] cached tokens plus the new one.  Results equal cactus_hip_qk_norm_rope_kv_append_f16_dev (or
+ * _seq_ with window 0) followed by cactus_hip_attention_hybrid_int8_fp16_batched_dev, bit for bit, one launch
+ * (plus the split merge) instead of two.  q half[B, Hq, D], k / v half[B, Hkv, D], output half[B, Hq, D];
+ * caches addressed as in the batched attention (max_cache_len: an upper bound of cache_lens[b], at most
+ * max_slots; a sequence whose cache is full appends nothing); RoPE tables as
+ * cactus_hip_qk_norm_rope_seq_f16_dev (max_position).  For
+ * head_dim 64 / 128 with group_size >= head_dim, up to 16 query heads per kv head, 16-byte aligned rows and at
+ * least one cached token per call; other shapes take the two separate calls. */
+int cactus_hip_attention_decode_fused_f16_dev(
+    const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,
+    const cactus_half_t* k_weight, int8_t* k_cache, int8_t* v_cache, float* k_scales, float* v_scales,
+    cactus_half_t* output, size_t batch_size, const int32_t* cache_lens, const int32_t* positions,
+    size_t max_position, size_t num_q_heads, size_t num_kv_heads, size_t head_dim, float eps, float theta,
+    float scale, size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+    size_t max_cache_len, void* stream);
+
 /* Batched-decode append: one new token per independent sequence, K and V [B,Hkv,D] quantized
  * (cactus_quantize_kv_fp16_to_int8 arithmetic) straight into slot slots[b] of sequence b's cache,
  * caches addressed as in the batched attention above (per-sequence strides in elements; a slot is

@@ -403,3 +403,44 @@ def test_windowed_append_argument_errors(ST):
     five = torch.zeros((1, 5, 1, 128), dtype=torch.float16, device="cuda")
     with pytest.raises(H.CactusHipError, match="sink < window"):
         H.kv_append_windowed(five, five, kc, kc, sc, sc, p, window=8, sink=4)        # more new tokens than recent slots
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,slots,lens", [
+    (1, 16, 8, 128, 600, (512,)),                     # Qwen3 heads, key ranges split over waves
+    (3, 16, 8, 128, 80, (5, 40, 79)),                 # different lengths; the last sequence fills its cache
+    (2, 32, 8, 64, 4200, (4100, 33)),                 # LFM2 heads, a long and a short sequence
+    (70, 16, 1, 128, 40, tuple(range(1, 36)) * 2),    # 16 query heads on one kv head, many sequences
+    (2, 6, 3, 128, 64, (64, 10)),                     # a full cache appends nothing and still attends
+    (3, 16, 8, 128, 16, (0, 1, 9)),                   # a sequence with nothing cached yet
+])
+def test_attention_decode_fused_equals_norm_rope_append_then_attention(ST, B, Hq, Hkv, D, slots, lens):
+    """One launch from the projections' rows to the attention output == q/k norm + RoPE + cache append, then the
+    batched attention: outputs, appended cache rows and scales bit for bit."""
+    import cactus_amd.hip as H
+    rng = np.random.default_rng(B + Hq + D + slots)
+    gen = torch.Generator(device="cuda").manual_seed(B + D)
+    half = lambda *sh: ((torch.rand(sh, device="cuda", generator=gen) * 2 - 1) * 3).half()
+    q, k, v = half(B, 1, Hq, D), half(B, 1, Hkv, D), half(B, 1, Hkv, D)
+    qw = (1.0 + 0.1 * torch.randn(D, device="cuda", generator=gen)).half()
+    kw = (1.0 + 0.1 * torch.randn(D, device="cuda", generator=gen)).half()
+    kc = torch.randint(-127, 128, (B, slots, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (B, slots, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ks = torch.rand((B, slots, Hkv, 1), device="cuda", generator=gen) * 0.02 + 1e-3
+    vs = torch.rand((B, slots, Hkv, 1), device="cuda", generator=gen) * 0.02 + 1e-3
+    cl = torch.tensor(lens[:B], dtype=torch.int32, device="cuda")
+    pos = cl + 3                                   # positions need not equal cache lengths (a slid window)
+    eps, theta, maxpos = 1e-6, 1e6, slots + 8
+    caches = [t.clone() for t in (kc, vc, ks, vs)]
+    # reference sequence: norm + rope (+ append at slot = cache length), then attention
+    slots_t = cl.clone()
+    oq, ok = H.qk_norm_rope_seq(q, k, None, qw, kw, eps, theta, pos, maxpos)
+    want = H.attention_hybrid_batched(oq, kc, vc, ks, vs, ok, v, 0.0, cl, pos)
+    H.kv_append_batched(ok.reshape(B, Hkv, D), v.reshape(B, Hkv, D), kc, vc, ks, vs, slots_t)
+    torch.cuda.synchronize()
+    kc2, vc2, ks2, vs2 = caches
+    got = H.attention_decode_fused(q.reshape(B, Hq, D), k.reshape(B, Hkv, D), v.reshape(B, Hkv, D), qw, kw, kc2, vc2,
+                                   ks2, vs2, cl, pos, maxpos, eps, theta)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    for a, b_ in ((kc, kc2), (vc, vc2), (ks, ks2), (vs, vs2)):
+        assert torch.equal(a, b_)
