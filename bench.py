@@ -25,6 +25,7 @@ scaling.  The same JSON line carries
                    decode attention over the INT8 KV cache.
 """
 import argparse
+import subprocess
 import json
 import os
 import sys
@@ -122,6 +123,46 @@ def cpu_baseline(work, steps=5):
             "ms_per_pass": round(dt * 1e3, 2)}
 
 
+def live_traffic(kernel="skinny_batch"):
+    """HBM bytes per launch of the timed kernel, measured now: this same command (no extras, no CPU leg, 3 steps)
+    run as a child under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (one counter per pass,
+    nothing else traced).  FETCH_SIZE is in KiB and, on gfx950, tallies the 128-byte requests of wide coalesced
+    reads at 64 bytes each: x 1024 x 2; WRITE_SIZE x 1024.  None when rocprofv3 is absent or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    means = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["timeout", "-s", "KILL", "75", exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-child", "--no-extra", "--no-cpu",
+                   "--steps", "3", "--warmup", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not vals:
+                return None
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = int(means["FETCH_SIZE"][0] * 1024 * 2), int(means["WRITE_SIZE"][0] * 1024)
+    return {"hbm_bytes_per_launch": rd + wr,
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (%d launches; KiB x 1024, "
+                      "reads x 2 for gfx950)" % means["FETCH_SIZE"][1]}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this file with torch.distributed.run as
     a child process (one rank per GPU, rendezvous on 127.0.0.1), pass its output through (rank 0 prints the one
@@ -150,6 +191,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / M=16 / M=512 / attention table")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # the run inside a --pmc pass
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -158,6 +201,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    live = None
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or \
+        any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)     # already under a profiler: no nested one
+    if world == 1 and not args.no_traffic and not args.traffic_child and not profiled:
+        live = live_traffic()        # child processes under rocprofv3, before this process touches the GPU
     if world > 1:
         print(f"[bench] rank {rank}/{world} (local rank {local_rank}, pid {os.getpid()}) starting", file=sys.stderr, flush=True)
     if world > 1:
@@ -250,19 +298,21 @@ def main():
     achieved = step_bytes / (ev_ms * 1e-3) / 1e9
     # HBM bytes per launch of this kernel from the PMC pass of this same command (collected in
     # its own rocprofv3 run, summarised by scripts/pmc_traffic.py); null when no summary exists.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pm = json.load(f)
-        # the summary is of this command (default shapes): its write figure is the sweep's outputs
-        if str(pm.get("kernel", "")).startswith("skinny_batch") and \
-                pm.get("algorithmic_bytes_per_launch", step_bytes) == step_bytes:
-            traffic = pm.get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_source = None, None
+    if live is not None:
+        traffic, traffic_source = live["hbm_bytes_per_launch"], live["source"]
+    else:   # no profiler here (or a pass failed): the committed summary of the same command, named as such
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if str(pm.get("kernel", "")).startswith("skinny_batch") and \
+                    pm.get("algorithmic_bytes_per_launch", step_bytes) == step_bytes:
+                traffic, traffic_source = pm.get("hbm_bytes_per_launch"), "profiles/pmc_traffic.json (an earlier run of this command)"
+        except (OSError, ValueError):
+            pass
     roofline = {"bound": "hbm", "kernel": "skinny_batch_sub_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": step_bytes, "us_per_launch": round(ev_ms * 1e3, 2)}
     # the largest single shape launched alone (8 rotating weight buffers, 512 MB > Infinity Cache)
     K = N = 8192
