@@ -1,6 +1,6 @@
 // Prefill-shaped cactus_attention_f16 (cactus/kernel/kernel_attention.cpp:10-255) on the FP16 matrix
-// cores: many queries against FP16 K/V, causal or not, head_dim 64 or 128, no window, no mask
-// tensor (those go to the VALU kernel in attention.hip).
+// cores: many queries against FP16 K/V, causal or not, head_dim 64 or 128, no mask tensor and no window
+// that cuts anything (those go to the VALU kernel in attention.hip).
 //
 // Roofline: MFMA (FP16) / VALU for the per-block softmax; algorithmic flops 4*S*KV*Hq*D (half of
 // that when causal).
@@ -575,7 +575,11 @@ hipError_t launch_attention_prefill_hybrid(const AttnArgs& a, float* ws, hipStre
 }
 
 bool attn_prefill_ok(const AttnArgs& a) {
-    return a.f16_mode && a.mask == nullptr && a.window_size == 0 && (a.D == 64 || a.D == 128) && a.S >= 32 &&
+    // a window that no (query, key) pair of the call can exceed does nothing (kernel_attention.cpp:78-90, 149-151:
+    // it moves kv_start only when window < KV and masks a key only when more than `window` behind its query)
+    const bool no_window = a.window_size == 0 ||
+                           (a.window_size >= a.new_len && a.position_offset + a.S <= a.window_size + 1);
+    return a.f16_mode && a.mask == nullptr && no_window && (a.D == 64 || a.D == 128) && a.S >= 32 &&
            a.new_len >= 1 && a.new_len < (size_t(1) << 30) && a.S < (size_t(1) << 30) && a.Hkv > 0 &&
            a.Hq % a.Hkv == 0 && a.Hq <= 65535 && a.B <= 65535 && a.Hq * a.B <= 1048576 &&
            ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k_new) |

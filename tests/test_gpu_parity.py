@@ -665,6 +665,9 @@ F16ATT = [
     (1, 33, 131, 8, 8, 64, 98, 0, True, False),
     (1, 1024, 1024, 2, 1, 128, 0, 0, True, False),
     (3, 64, 64, 6, 3, 64, 0, 0, True, False),
+    (1, 200, 200, 4, 1, 128, 0, 512, True, False),   # a window longer than the prompt cuts nothing: matrix-core kernel
+    (1, 64, 300, 4, 1, 128, 236, 512, True, False),  # ... with an offset, still inside the window
+    (1, 64, 600, 4, 1, 128, 536, 512, True, False),  # the window cuts: the VALU kernel
 ]
 
 
