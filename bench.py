@@ -649,17 +649,19 @@ def extra_table(H, gen, big):
     rows = {}
     for name, Hq, Hkv, D, cache, Bn in (("qwen3_c512", 16, 8, 128, 512, 1), ("qwen3_c4096", 16, 8, 128, 4096, 1),
                                         ("8b_c32768", 32, 8, 128, 32768, 1), ("qwen3_c4096_b64", 16, 8, 128, 4096, 64),
-                                        ("qwen3_c512_b256", 16, 8, 128, 512, 256), ("lfm2_c512_b1024", 32, 8, 64, 512, 1024)):
+                                        ("qwen3_c512_b256", 16, 8, 128, 512, 256), ("lfm2_c512_b1024", 32, 8, 64, 512, 1024),
+                                        ("gemma270m_c512_b1024", 4, 1, 256, 512, 1024)):
         kq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
         vq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-        ks = torch.rand((Bn, cache, Hkv, 1), device="cuda", generator=gen) * 0.02
-        vs = torch.rand((Bn, cache, Hkv, 1), device="cuda", generator=gen) * 0.02
+        ng = (D + 127) // 128      # scale groups per cached row (kernel.h:18)
+        ks = torch.rand((Bn, cache, Hkv, ng), device="cuda", generator=gen) * 0.02
+        vs = torch.rand((Bn, cache, Hkv, ng), device="cuda", generator=gen) * 0.02
         qh = (torch.rand((Bn, 1, Hq, D), device="cuda", generator=gen) * 2 - 1).half()
         kn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
         vn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
         lens = torch.full((Bn,), cache, dtype=torch.int32, device="cuda")
         ms = time_graph(lambda i: H.attention_hybrid_batched(qh, kq, vq, ks, vs, kn, vn, 0.0, lens, lens), 8)
-        byts = Bn * (2 * cache * Hkv * (D + 4) + 2 * Hkv * D * 2 + 2 * Hq * D * 2)
+        byts = Bn * (2 * cache * Hkv * (D + 4 * ng) + 2 * Hkv * D * 2 + 2 * Hq * D * 2)
         gb = byts / (ms * 1e-3) / 1e9
         rows[name] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1), "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
     ex["attn_decode_int8kv"] = rows

@@ -1142,7 +1142,7 @@ int cactus_hip_attention_decode_fused_f16_dev(
     a.cache_batch_stride = cache_batch_stride; a.scale_batch_stride = scale_batch_stride; a.f16_mode = 0;
     if (!attn_decode_mfma_ok(a) || ((reinterpret_cast<uintptr_t>(q_weight) | reinterpret_cast<uintptr_t>(k_weight)) & 1))
         return fail(CACTUS_HIP_EINVAL,
-                    "attention_decode_fused: needs head_dim 64 or 128, group_size >= head_dim, at most 16 query heads "
+                    "attention_decode_fused: needs head_dim 64 or 128 with group_size >= head_dim (or 256 with group_size 128), at most 16 query heads "
                     "per kv head, 16-byte aligned rows and a cache that is not empty");
     AttnFusedIn f;
     f.q_weight = q_weight; f.k_weight = k_weight; f.kc = k_cache; f.vc = v_cache; f.ks = k_scales; f.vs = v_scales;

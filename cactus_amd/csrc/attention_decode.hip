@@ -27,7 +27,8 @@
 // the MFMA, summed by an MFMA from the same operand) block by block.  Weights enter as hi + lo binary16
 // parts (about 22 bits).
 // Per-key scales multiply the score column (K) and the weight (V), as the reference's dequantization
-// does per element.  Softmax is the online form on base-2 scores (s * log2 e, one v_exp_f32 per weight);
+// does per element.  With two scale groups per row (head_dim 256) each group's 128 dims have their own score
+// chain, scaled and added, and their own weights (p * the group's V scale) for their half of the output dims.  Softmax is the online form on base-2 scores (s * log2 e, one v_exp_f32 per weight);
 // key ranges (splits) leave (max, sum, O) records that attn_merge_kernel reduces.
 // The LDS reads of the block loop are inline asm with hand-placed s_waitcnt lgkmcnt: the compiler would
 // order an LDS read it can see behind every outstanding LDS-DMA request, the next block's prefetch
@@ -92,7 +93,7 @@ struct DecodeParams {
 // transposed reads of a 32-lane half (8 rows x 32 bytes) on 64 distinct banks
 template <int D>
 __device__ __forceinline__ int v_swz(int row) {
-    return D == 128 ? ((row >> 1) & 3) << 1 : ((row >> 2) & 1) << 1;
+    return D == 256 ? (row & 7) << 1 : D == 128 ? ((row >> 1) & 3) << 1 : ((row >> 2) & 1) << 1;
 }
 
 // FUSED: a.q / a.k_new / a.v_new are the q / k / v projections' rows of a decode step (one new token per
@@ -104,9 +105,11 @@ template <int D, int NW, bool FUSED>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     constexpr int ROWB = D;                         // bytes per key row
     constexpr int VBYTES = DC_BLOCK * ROWB;         // V image of one block
-    constexpr int STAGE = VBYTES + 512;             // + 32 K scales, 128 B the request's idle lanes clear, 32 V scales, 128 B
+    constexpr int STAGE = VBYTES + 512;             // + 32 * NG K scales, 256 B in all with what the request's idle lanes clear, the V scales likewise
     constexpr int KL = D / 64;                      // 16-byte loads per lane and 16-key group (D = 64: 1)
     constexpr int NC = D / 32;                      // 32-dim column blocks
+    constexpr int NG = D == 256 ? 2 : 1;            // scale groups per row (head_dim 256: two groups of 128 dims)
+    constexpr int CG = NC / NG;                     // column blocks per scale group
     constexpr int RING = NW * DC_STAGES * STAGE;
     __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0)];   // + each wave's rotated key row
 
@@ -192,7 +195,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 
     // Q^T operand: lane (head, q) holds, for MFMA step (ld, half), Q[head][64 ld + 16 q + 8 half .. + 8)
     v8h qreg[KL * 2];
-    float qsum = 0.0f;
+    float qsum[NG];
+#pragma unroll
+    for (int n = 0; n < NG; n++) qsum[n] = 0.0f;
     {
         const uint16_t* qrow = FUSED ? reinterpret_cast<const uint16_t*>(my_lds) + (size_t)min(hd, gq - 1) * D
                                      : a.q + ((size_t)b * Hq + h0 + min(hd, gq - 1)) * D;
@@ -202,12 +207,17 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             if (hd >= gq) raw = v4i{0, 0, 0, 0};
             qreg[s] = __builtin_bit_cast(v8h, raw);
 #pragma unroll
-            for (int e = 0; e < 8; e++) qsum += (float)qreg[s][e];
+            for (int e = 0; e < 8; e++) qsum[(s >> 1) * NG / KL] += (float)qreg[s][e];
         }
-        qsum += xor_lanes(qsum, 16);
-        qsum += xor_lanes(qsum, 32);
+#pragma unroll
+        for (int n = 0; n < NG; n++) {
+            qsum[n] += xor_lanes(qsum[n], 16);
+            qsum[n] += xor_lanes(qsum[n], 32);
+        }
     }
-    const float nqsum = -1152.0f * qsum;
+    float nqsum[NG];        // per scale group: the group's scores are rescaled separately
+#pragma unroll
+    for (int n = 0; n < NG; n++) nqsum[n] = -1152.0f * qsum[n];
     const float scale2 = scale * 1.44269504f;     // scores are kept times log2(e)
     if constexpr (FUSED) {      // the q rows are in registers: the ring may be written from here on
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -215,9 +225,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     }
 
     // per-lane pieces of the addresses
-    const int dma_row = D == 128 ? lane >> 3 : lane >> 2;            // row inside one DMA instruction
-    const int dma_chunk = D == 128 ? lane & 7 : lane & 3;
-    constexpr int DMA_ROWS = D == 128 ? 8 : 16;
+    constexpr int ROW_CHUNKS = D / 16;                               // 16-byte chunks of a row
+    const int dma_row = lane / ROW_CHUNKS;                           // row inside one DMA instruction
+    const int dma_chunk = lane % ROW_CHUNKS;
+    constexpr int DMA_ROWS = 64 / ROW_CHUNKS;
     constexpr int NDMA = DC_BLOCK / DMA_ROWS;
 
     // K, V and the scales come through buffer descriptors that end with the last visible cached row: rows
@@ -228,8 +239,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     const unsigned valid_bytes = (unsigned)c_cnt * (unsigned)row_stride;
     const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Kc), 0, (int)valid_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Vc), 0, (int)valid_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ksrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ks), 0, c_cnt * Hkv * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vsrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, c_cnt * Hkv * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ksrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ks), 0, c_cnt * Hkv * NG * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vsrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Vs), 0, c_cnt * Hkv * NG * 4, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
     unsigned k_lane_off[2], v_lane_off[NDMA];
 #pragma unroll
@@ -239,8 +250,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         const int row = i * DMA_ROWS + dma_row;
         v_lane_off[i] = (unsigned)row * (unsigned)row_stride + kvh * D + ((dma_chunk ^ v_swz<D>(row)) << 4);
     }
-    // one scale per lane and request: lanes 0..31 the block's 32 keys, lanes 32..63 nothing
-    const unsigned s_lane_off = lane < 32 ? (unsigned)(lane * Hkv + kvh) * 4u : OOB;
+    // one scale per lane and request: lanes 0..32 NG - 1 the block's 32 keys (NG = 2: key lane / 2, group lane % 2),
+    // the other lanes nothing
+    const unsigned s_lane_off = lane < 32 * NG ? (unsigned)(((lane / NG) * Hkv + kvh) * NG + lane % NG) * 4u : OOB;
 
     struct KRegs { v4i k[2][KL]; };
     // K: 16 keys x 64 bytes per wave instruction, straight to registers
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     // the scales: each request writes its 32 scales and, from its idle lanes, 128 bytes of zeros behind them
     auto issue_v = [&](int blk, int stage) __attribute__((always_inline)) {
         const unsigned base = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)row_stride : OOB;
-        const unsigned sbase = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)Hkv * 4u : OOB;
+        const unsigned sbase = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)(Hkv * NG) * 4u : OOB;
         uint8_t* st = my_lds + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NDMA; i++)
@@ -268,7 +280,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     // m_run is the running maximum minus 6 (scores are base-2 logarithms): weights are 2^(s - m_run) <= 64, which
     // keeps the binary16 parts of small weights out of the subnormal range; numerator and denominator carry
     // the same factor.  pend: 1152 * (sum of the last block's weights as the MFMA saw them), still inside oacc.
-    float m_run = -INFINITY, l_part = 0.0f, pend = 0.0f;
+    float m_run = -INFINITY, l_part = 0.0f, pend[NG];
+#pragma unroll
+    for (int n = 0; n < NG; n++) pend[n] = 0.0f;
     v4f oacc[NC][2];
 #pragma unroll
     for (int c = 0; c < NC; c++)
@@ -295,16 +309,27 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         // ALL outstanding LDS-DMA requests (a wait for the next block's prefetch as well), which would take
         // the overlap of loads and arithmetic away.  The stage's requests are complete (the caller waited).
         const uint32_t sa = lds_addr(st);
-        v4f ksv[2], vsv[2];
+        // a lane's scales: keys 16 g + 4 q .. + 4, NG groups each (key-major: NG = 2 interleaves the groups)
+        v4f ksv[2][NG], vsv[2][NG];
         uint2 tv[2][NC];
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-            ksv[g] = lds_read_b128(sa + VBYTES + 64 * g + 16 * q);
-            vsv[g] = lds_read_b128(sa + VBYTES + 256 + 64 * g + 16 * q);
-        }
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int n = 0; n < NG; n++) {
+                ksv[g][n] = lds_read_b128(sa + VBYTES + NG * (64 * g + 16 * q) + 16 * n);
+                vsv[g][n] = lds_read_b128(sa + VBYTES + 256 + NG * (64 * g + 16 * q) + 16 * n);
+            }
+        // scale of key j (0..3) of the lane's four, group n
+        auto pick = [&](const v4f (&sv)[NG], int j, int n) __attribute__((always_inline)) -> float {
+            return NG == 1 ? sv[0][j] : sv[j >> 1][2 * (j & 1) + n];
+        };
         // ---- scores: S^T[key][head]; the two key groups' accumulation chains alternate.  The chains start
         // at -1152 * sum(q), which takes the conversion's constant out again.
-        v4f acc[2] = {v4f{nqsum, nqsum, nqsum, nqsum}, v4f{nqsum, nqsum, nqsum, nqsum}};
+        v4f acc[2][NG];
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int n = 0; n < NG; n++) acc[g][n] = v4f{nqsum[n], nqsum[n], nqsum[n], nqsum[n]};
 #pragma unroll
         for (int ld = 0; ld < KL; ld++)
 #pragma unroll
@@ -314,16 +339,21 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
                     const uint32_t x0 = (uint32_t)kr.k[g][ld][2 * hf] ^ 0x80808080u;
                     const uint32_t x1 = (uint32_t)kr.k[g][ld][2 * hf + 1] ^ 0x80808080u;
                     const v8h ka = as_v8h(pair_lo(x0), pair_hi(x0), pair_lo(x1), pair_hi(x1));
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qreg[2 * ld + hf], acc[g], 0, 0, 0);
+                    acc[g][ld * NG / KL] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qreg[2 * ld + hf], acc[g][ld * NG / KL], 0, 0, 0);
                 }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ksv[0]), "+v"(ksv[1]), "+v"(vsv[0]), "+v"(vsv[1]));
+        if constexpr (NG == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ksv[0][0]), "+v"(ksv[0][1]), "+v"(ksv[1][0]), "+v"(ksv[1][1]),
+                         "+v"(vsv[0][0]), "+v"(vsv[0][1]), "+v"(vsv[1][0]), "+v"(vsv[1][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ksv[0][0]), "+v"(ksv[1][0]), "+v"(vsv[0][0]), "+v"(vsv[1][0]));
         // scores in the base-2 domain: s * log2(e), so that the weights are one v_exp_f32 each
         float sc[2][4];
 #pragma unroll
         for (int g = 0; g < 2; g++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                sc[g][j] = acc[g][j] * (ksv[g][j] * scale2);
+                sc[g][j] = acc[g][0][j] * (pick(ksv[g], j, 0) * scale2);
+                if constexpr (NG == 2) sc[g][j] += acc[g][1][j] * (pick(ksv[g], j, 1) * scale2);
                 if (!FULL && 16 * g + 4 * q + j >= nv) sc[g][j] = -INFINITY;
             }
         // ---- online softmax, per head (lane % 16); a head's 32 keys sit in its 4 lanes (q = 0..3)
@@ -346,17 +376,19 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             // the rescale also takes out the constant the last block's V conversion added (1152 per weight):
             // the accumulators never hold more than one block's worth of it, so what the subtraction costs in
             // precision does not grow with the context
-            const float npc = -pend * corr;
+            float npc[NG];
+#pragma unroll
+            for (int n = 0; n < NG; n++) npc[n] = -pend[n] * corr;
 #pragma unroll
             for (int c = 0; c < NC; c++)
 #pragma unroll
                 for (int e = 0; e < 2; e++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++) oacc[c][e][j] = fmaf(oacc[c][e][j], corr, npc);
+                    for (int j = 0; j < 4; j++) oacc[c][e][j] = fmaf(oacc[c][e][j], corr, npc[c / CG]);
             m_run = mn;
         }
         // weights: w = p * v_scale as hi + lo halves (hi rounded toward zero, lo the rest: 21 bits or more)
-        uint32_t ph[4], pl[4];
+        uint32_t ph[NG][4], pl[NG][4];
         float bsum = 0.0f;
 #pragma unroll
         for (int g = 0; g < 2; g++)
@@ -365,26 +397,39 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
                 const float p0 = __builtin_amdgcn_exp2f(sc[g][2 * jj] - m_run);      // a masked key: 2^-inf = 0
                 const float p1 = __builtin_amdgcn_exp2f(sc[g][2 * jj + 1] - m_run);
                 bsum += p0 + p1;
-                const float w0 = p0 * vsv[g][2 * jj], w1 = p1 * vsv[g][2 * jj + 1];
-                const v2h hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
-                const v2h lo = __builtin_amdgcn_cvt_pkrtz(w0 - (float)hi[0], w1 - (float)hi[1]);
-                ph[2 * g + jj] = __builtin_bit_cast(uint32_t, hi);
-                pl[2 * g + jj] = __builtin_bit_cast(uint32_t, lo);
+#pragma unroll
+                for (int n = 0; n < NG; n++) {
+                    const float w0 = p0 * pick(vsv[g], 2 * jj, n), w1 = p1 * pick(vsv[g], 2 * jj + 1, n);
+                    const v2h hi = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+                    const v2h lo = __builtin_amdgcn_cvt_pkrtz(w0 - (float)hi[0], w1 - (float)hi[1]);
+                    ph[n][2 * g + jj] = __builtin_bit_cast(uint32_t, hi);
+                    pl[n][2 * g + jj] = __builtin_bit_cast(uint32_t, lo);
+                }
             }
         l_part += bsum;
-        const v8h phi = as_v8h(ph[0], ph[1], ph[2], ph[3]), plo = as_v8h(pl[0], pl[1], pl[2], pl[3]);
-        if constexpr (NC == 4)
+        v8h phi[NG], plo[NG];
+#pragma unroll
+        for (int n = 0; n < NG; n++) {
+            phi[n] = as_v8h(ph[n][0], ph[n][1], ph[n][2], ph[n][3]);
+            plo[n] = as_v8h(pl[n][0], pl[n][1], pl[n][2], pl[n][3]);
+        }
+        if constexpr (NC == 8)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0]), "+v"(tv[1][0]), "+v"(tv[0][1]), "+v"(tv[1][1]), "+v"(tv[0][2]),
+                         "+v"(tv[1][2]), "+v"(tv[0][3]), "+v"(tv[1][3]), "+v"(tv[0][4]), "+v"(tv[1][4]), "+v"(tv[0][5]),
+                         "+v"(tv[1][5]), "+v"(tv[0][6]), "+v"(tv[1][6]), "+v"(tv[0][7]), "+v"(tv[1][7]));
+        else if constexpr (NC == 4)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0]), "+v"(tv[1][0]), "+v"(tv[0][1]), "+v"(tv[1][1]), "+v"(tv[0][2]),
                          "+v"(tv[1][2]), "+v"(tv[0][3]), "+v"(tv[1][3]));
         else
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0][0]), "+v"(tv[1][0]), "+v"(tv[0][1]), "+v"(tv[1][1]));
         // the block's sum of weights exactly as the MFMAs below see them (a row of ones as the A operand: every
         // row of the result is the column's sum), for the constant's removal
-        {
+#pragma unroll
+        for (int n = 0; n < NG; n++) {
             const v8h ones = as_v8h(0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u);
-            v4f wb = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, phi, v4f{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
-            wb = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, plo, wb, 0, 0, 0);
-            pend = 1152.0f * wb[0];
+            v4f wb = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, phi[n], v4f{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+            wb = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, plo[n], wb, 0, 0, 0);
+            pend[n] = 1152.0f * wb[0];
         }
         // ---- O^T[dim][head] += V^T * P^T, 32 dims per column block: even dims and odd dims alternate
 #pragma unroll
@@ -394,10 +439,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             const uint32_t x2 = ub.x ^ 0x80808080u, x3 = ub.y ^ 0x80808080u;
             const v8h ve = as_v8h(pair_even(x0), pair_even(x1), pair_even(x2), pair_even(x3));
             const v8h vo = as_v8h(pair_odd(x0), pair_odd(x1), pair_odd(x2), pair_odd(x3));
-            oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ve, phi, oacc[c][0], 0, 0, 0);
-            oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vo, phi, oacc[c][1], 0, 0, 0);
-            oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ve, plo, oacc[c][0], 0, 0, 0);
-            oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vo, plo, oacc[c][1], 0, 0, 0);
+            oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ve, phi[c / CG], oacc[c][0], 0, 0, 0);
+            oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vo, phi[c / CG], oacc[c][1], 0, 0, 0);
+            oacc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ve, plo[c / CG], oacc[c][0], 0, 0, 0);
+            oacc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vo, plo[c / CG], oacc[c][1], 0, 0, 0);
         }
     };
 
@@ -444,7 +489,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 #pragma unroll
         for (int e = 0; e < 2; e++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) oacc[c][e][j] -= pend;
+            for (int j = 0; j < 4; j++) oacc[c][e][j] -= pend[c / CG];
     const uint16_t* Kn = a.k_new + (size_t)b * new_len * Hkv * D;
     const uint16_t* Vn = a.v_new + (size_t)b * new_len * Hkv * D;
     const int n_new = split == 0 ? (int)max(0LL, min((long long)new_len, kv_end - cl)) : 0;   // visible ones
@@ -510,12 +555,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 
 }  // namespace
 
-// One query position per sequence over an INT8 cache with head_dim 64 or 128 and one scale group per
-// row; up to 16 query heads per kv head and up to 8 FP16 tokens of the step itself.
+// One query position per sequence over an INT8 cache with head_dim 64 or 128 and one scale group per row, or
+// head_dim 256 and two groups of 128 (Gemma, model_gemma.cpp:67-113; KV_QUANT_GROUP_SIZE, kernel.h:18);
+// up to 16 query heads per kv head and up to 8 FP16 tokens of the step itself.
 bool attn_decode_mfma_ok(const AttnArgs& a) {
     if (a.f16_mode || a.S != 1 || a.new_len > (size_t)DC_MAX_NEW) return false;
-    if (a.D != 64 && a.D != 128) return false;
-    if (a.qgs < a.D || a.Hkv == 0 || a.Hq % a.Hkv != 0 || a.Hq / a.Hkv > 16) return false;
+    if (a.D != 64 && a.D != 128 && a.D != 256) return false;
+    if ((a.D == 256 ? a.qgs != 128 : a.qgs < a.D) || a.Hkv == 0 || a.Hq % a.Hkv != 0 || a.Hq / a.Hkv > 16) return false;
     if (a.cache_len == 0 && a.cache_lens == nullptr) return false;           // nothing cached: the plain kernel
     if (!a.k_cached || !a.v_cached || !a.k_scales || !a.v_scales || !a.q || !a.out) return false;
     if (a.new_len && (!a.k_new || !a.v_new)) return false;
@@ -540,10 +586,11 @@ hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit
     if (fused && (a.new_len != 1 || !a.cache_lens || !a.pos_offsets || !a.is_causal)) return hipErrorInvalidValue;
     // 8 waves per workgroup cover a whole 8-head row of the cache; the wider workgroup pays when there are
     // many of them and their LDS rings are small (head_dim 64)
-    const int nw = (a.D == 64 && p.n_items >= 4096) ? 8 : 4;
+    const int nw = a.D == 256 ? 2 : (a.D == 64 && p.n_items >= 4096) ? 8 : 4;
     const dim3 grid((unsigned)((p.n_items + nw - 1) / nw), (unsigned)nsplit);
 #define DECODE_LAUNCH(F)                                                                   \
-    if (a.D == 128) attn_decode_mfma_kernel<128, 4, F><<<grid, dim3(256), 0, st>>>(p);      \
+    if (a.D == 256) attn_decode_mfma_kernel<256, 2, F><<<grid, dim3(128), 0, st>>>(p);      \
+    else if (a.D == 128) attn_decode_mfma_kernel<128, 4, F><<<grid, dim3(256), 0, st>>>(p); \
     else if (nw == 8) attn_decode_mfma_kernel<64, 8, F><<<grid, dim3(512), 0, st>>>(p);     \
     else attn_decode_mfma_kernel<64, 4, F><<<grid, dim3(256), 0, st>>>(p);
     if (fused) { DECODE_LAUNCH(true) } else { DECODE_LAUNCH(false) }

@@ -127,7 +127,7 @@ size_t attn_workspace_bytes(const AttnArgs& a);
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
 
 // attention_decode.hip: cactus_attention_hybrid_int8_fp16 for one query position per sequence on the matrix
-// cores (head_dim 64 / 128, one scale group per row, up to 16 query heads per kv head); key ranges split
+// cores (head_dim 64 / 128 with one scale group per row or 256 with two, up to 16 query heads per kv head); key ranges split
 // over workgroups leave records in ws as attn_kernel does
 bool attn_decode_mfma_ok(const AttnArgs& a);
 // The producer of a decode step's q / k rows and the cache append, folded into the attention launch

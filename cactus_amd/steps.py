@@ -198,9 +198,9 @@ class Qwen3Decode:
             # cache in the same launch (the slot beyond the cached length: this step's attention reads them
             # as FP16), with a window they are appended after the attention, which must still see the token
             # a full window is about to drop
-            # Without a window all of it - norm, RoPE, cache append, attention - is one launch (head_dim 64 / 128).
+            # Without a window all of it - norm, RoPE, cache append, attention - is one launch (head_dim 64 / 128 / 256).
             fused_append = kv.window == 0
-            if fused_append and D in (64, 128):
+            if fused_append and D in (64, 128, 256):
                 H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
                                          L["q_norm"], L["k_norm"], kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li],
                                          kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao)
@@ -396,7 +396,7 @@ class Lfm2Decode:
                 ai = self.attn_index[li]
                 self.qkv[li].run(self.xq, self.xs)
                 fused_append = kv.window == 0
-                if fused_append and D in (64, 128):     # norm, RoPE, cache append and attention in one launch
+                if fused_append and D in (64, 128, 256):     # norm, RoPE, cache append and attention in one launch
                     H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
                                              L["q_norm"], L["k_norm"], kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai],
                                              kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao)

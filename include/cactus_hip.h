@@ -474,7 +474,7 @@ int cactus_hip_attention_hybrid_int8_fp16_batched_dev(
  * caches addressed as in the batched attention (max_cache_len: an upper bound of cache_lens[b], at most
  * max_slots; a sequence whose cache is full appends nothing); RoPE tables as
  * cactus_hip_qk_norm_rope_seq_f16_dev (max_position).  For
- * head_dim 64 / 128 with group_size >= head_dim, up to 16 query heads per kv head, 16-byte aligned rows and at
+ * head_dim 64 / 128 with group_size >= head_dim or head_dim 256 with group_size 128, up to 16 query heads per kv head, 16-byte aligned rows and at
  * least one cached token per call; other shapes take the two separate calls. */
 int cactus_hip_attention_decode_fused_f16_dev(
     const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,

@@ -572,6 +572,12 @@ HYBRID = [
     (1, 1, 4, 2, 64, 2048, 1, 1000),        # causal cut inside the cache, key ranges split
     (520, 1, 16, 8, 64, 40, 1, None),       # 4160 waves of work: the 8-wave workgroups
     (300, 1, 16, 8, 128, 65, 1, None),      # 2400 waves of work, no split
+    # head_dim 256 (Gemma): two scale groups per cached row, two-wave workgroups
+    (3, 1, 8, 2, 256, 700, 1, None),
+    (1, 1, 4, 1, 256, 4096, 1, None),       # key ranges split
+    (2, 1, 16, 1, 256, 45, 3, 46),          # 16 query heads, three tokens of the step itself, the last one masked
+    (1, 1, 8, 4, 256, 1500, 1, 900),        # causal cut inside the cache
+    (257, 1, 4, 1, 256, 33, 1, None),       # an odd number of waves: the last workgroup is half empty
 ]
 
 
@@ -592,7 +598,8 @@ def test_attention_hybrid_vs_oracle(H, B, S, Hq, Hkv, D, cache, new, off):
 
 
 @pytest.mark.parametrize("B,Hq,Hkv,D,cache", [(1, 16, 8, 128, 512), (4, 16, 8, 128, 4096), (1, 32, 8, 64, 333),
-                                              (64, 32, 8, 64, 100), (1, 32, 8, 128, 20000)])
+                                              (64, 32, 8, 64, 100), (1, 32, 8, 128, 20000), (2, 4, 1, 256, 512),
+                                              (1, 8, 4, 256, 6000)])
 def test_attention_decode_rounds_like_the_oracle(H, B, Hq, Hkv, D, cache):
     """The matrix-core decode kernel against the oracle, output by output.  Both sum in fp32, in different
     orders (the kernel: exact fp16 products, weights as two binary16 parts, the MFMA's order), so they

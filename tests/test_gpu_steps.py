@@ -412,6 +412,8 @@ def test_windowed_append_argument_errors(ST):
     (70, 16, 1, 128, 40, tuple(range(1, 36)) * 2),    # 16 query heads on one kv head, many sequences
     (2, 6, 3, 128, 64, (64, 10)),                     # a full cache appends nothing and still attends
     (3, 16, 8, 128, 16, (0, 1, 9)),                   # a sequence with nothing cached yet
+    (3, 4, 1, 256, 300, (256, 31, 299)),              # Gemma heads: two scale groups per cached row
+    (2, 8, 4, 256, 5000, (4999, 4097)),               # ... key ranges split
 ])
 def test_attention_decode_fused_equals_norm_rope_append_then_attention(ST, B, Hq, Hkv, D, slots, lens):
     """One launch from the projections' rows to the attention output == q/k norm + RoPE + cache append, then the
@@ -425,8 +427,8 @@ def test_attention_decode_fused_equals_norm_rope_append_then_attention(ST, B, Hq
     kw = (1.0 + 0.1 * torch.randn(D, device="cuda", generator=gen)).half()
     kc = torch.randint(-127, 128, (B, slots, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
     vc = torch.randint(-127, 128, (B, slots, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-    ks = torch.rand((B, slots, Hkv, 1), device="cuda", generator=gen) * 0.02 + 1e-3
-    vs = torch.rand((B, slots, Hkv, 1), device="cuda", generator=gen) * 0.02 + 1e-3
+    ks = torch.rand((B, slots, Hkv, (D + 127) // 128), device="cuda", generator=gen) * 0.02 + 1e-3
+    vs = torch.rand((B, slots, Hkv, (D + 127) // 128), device="cuda", generator=gen) * 0.02 + 1e-3
     cl = torch.tensor(lens[:B], dtype=torch.int32, device="cuda")
     pos = cl + 3                                   # positions need not equal cache lengths (a slid window)
     eps, theta, maxpos = 1e-6, 1e6, slots + 8
