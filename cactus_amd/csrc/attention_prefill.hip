@@ -1,5 +1,5 @@
 // Prefill-shaped cactus_attention_f16 (cactus/kernel/kernel_attention.cpp:10-255) on the FP16 matrix
-// cores: many queries against FP16 K/V, causal or not, head_dim 64 or 128, no mask tensor and no window
+// cores: many queries against FP16 K/V, causal or not, head_dim 64, 128 or 256, no mask tensor and no window
 // that cuts anything (those go to the VALU kernel in attention.hip).
 //
 // Roofline: MFMA (FP16) / VALU for the per-block softmax; algorithmic flops 4*S*KV*Hq*D (half of
@@ -53,8 +53,10 @@ __device__ __forceinline__ float pf_weight(float s, float bmax, bool poly) {
 #ifndef PF_WAVES_PER_EU
 #define PF_WAVES_PER_EU 2
 #endif
+// head_dim 256: the Q rows and the output accumulators of a lane alone are 192 registers, so that variant runs one
+// wave per SIMD with the whole register file
 template <int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF_WAVES_PER_EU, PF_WAVES_PER_EU)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : PF_WAVES_PER_EU, D == 256 ? 1 : PF_WAVES_PER_EU)))
 void attn_prefill_kernel(const AttnArgs a) {
     constexpr int KROW = D + 8;            // halves per K row in LDS (16-byte aligned, banks shifted)
     constexpr int VROW = PF_BLOCK + 4;     // halves per V^T row in LDS (8-byte aligned)
@@ -273,8 +275,8 @@ void attn_prefill_kernel(const AttnArgs a) {
 // cactus_attention_hybrid_int8_fp16 (kernel_attention.cpp:257-482) for a chunk of many queries:
 // the same transposed MFMA scheme over the INT8 cache followed by the chunk's own FP16 keys.
 //  - A cached block is converted to binary16 on its way into LDS (an int8 is exact there); the
-//    per-key scales (one group per head: head_dim <= group size) multiply the score column and the
-//    weight of the key, as in attn_kernel: s = (q . k8) * k_scale * scale, O += (w * v_scale) * v8.
+//    per-key scales (one group per head: head_dim <= group size; two for head_dim 256) multiply the score
+//    column and the weight of the key, as in attn_kernel: s = (q . k8) * k_scale * scale, O += (w * v_scale) * v8.
 //  - Standard online softmax with expf (:395-414), so partial results over disjoint key ranges
 //    combine exactly like the decode kernel's: the key blocks of a query tile are cut into
 //    `nsplit` ranges, each a workgroup of its own writing (max, sum, unnormalised O) records that
@@ -294,14 +296,19 @@ __device__ __forceinline__ uint2 i8x4_to_f16x4(uint32_t x) {
     return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
 }
 
+// head_dim 256 (Gemma): two scale groups of 128 dims per cached row (kernel.h:18) - each group's half of the
+// score is scaled and added, and each half of the output dims takes weights times its own V scale; one wave per
+// SIMD with the whole register file, as in attn_prefill_kernel<256>.
 template <int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PF_WAVES_PER_EU, PF_WAVES_PER_EU)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : PF_WAVES_PER_EU, D == 256 ? 1 : PF_WAVES_PER_EU)))
 void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int nsplit) {
     constexpr int KROW = D + 8, VROW = PF_BLOCK + 4, NDT = D / 32, NST = D / 16;
     constexpr int D16 = D / 16;            // 16-element pieces per row: a thread stages (key, d16)
+    constexpr int NP = (D16 + 7) / 8;      // staging passes: 8 pieces per key and pass
+    constexpr int NG = D == 256 ? 2 : 1;   // scale groups per cached row
     __shared__ __attribute__((aligned(16))) uint16_t sK[PF_BLOCK * KROW];
     __shared__ __attribute__((aligned(16))) uint16_t sVt[D * VROW];
-    __shared__ __attribute__((aligned(16))) float sKs[PF_BLOCK], sVs[PF_BLOCK];
+    __shared__ __attribute__((aligned(16))) float sKs[NG][PF_BLOCK], sVs[NG][PF_BLOCK];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jq = lane & 31, g = lane >> 5;
@@ -342,63 +349,70 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
     }
     const int8_t* Kc = a.k_cached + (size_t)b * a.cache_batch_stride + (size_t)kvh * D;
     const int8_t* Vc = a.v_cached + (size_t)b * a.cache_batch_stride + (size_t)kvh * D;
-    const float* Ks = a.k_scales + (size_t)b * a.scale_batch_stride + kvh;
-    const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride + kvh;
+    const float* Ks = a.k_scales + (size_t)b * a.scale_batch_stride + kvh * NG;
+    const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride + kvh * NG;
     const uint16_t* Kn = a.k_new + (size_t)b * new_len * Hkv * D + (size_t)kvh * D;
     const uint16_t* Vn = a.v_new + (size_t)b * new_len * Hkv * D + (size_t)kvh * D;
     const size_t row_stride = (size_t)Hkv * D;   // elements between consecutive tokens
 
-    // staging: thread = (key = lane % 32, d16 = 2 * wave + lane / 32): 16 elements of K and of V
+    // staging: thread = (key = lane % 32, d16 = 8 * pass + 2 * wave + lane / 32): 16 elements of K and of V
     const int skey = lane & 31, sd16 = w * 2 + g;
     const bool stager = sd16 < D16;
-    v4i kst[2], vst[2];          // cached: [0] holds 16 int8; FP16: two pieces of 8 halves
-    float ksv = 1.0f, vsv = 1.0f;
+    v4i kst[NP][2], vst[NP][2];  // cached: [0] holds 16 int8; FP16: two pieces of 8 halves
+    float ssv = 1.0f;            // threads 0 .. 64 NG - 1: one scale of the block (K / V alternate by wave half)
+    const int s_grp = tid >> 6, s_isv = (tid >> 5) & 1;
     auto fetch = [&](int blk) {
         if (blk < nbc) {
             const int kp = min(blk * PF_BLOCK + skey, cl - 1);
             if (stager) {
-                kst[0] = *reinterpret_cast<const v4i*>(Kc + (size_t)kp * row_stride + sd16 * 16);
-                vst[0] = *reinterpret_cast<const v4i*>(Vc + (size_t)kp * row_stride + sd16 * 16);
+#pragma unroll
+                for (int p = 0; p < NP; p++) {
+                    kst[p][0] = *reinterpret_cast<const v4i*>(Kc + (size_t)kp * row_stride + (p * 8 + sd16) * 16);
+                    vst[p][0] = *reinterpret_cast<const v4i*>(Vc + (size_t)kp * row_stride + (p * 8 + sd16) * 16);
+                }
             }
-            if (tid < 32) ksv = Ks[(size_t)kp * Hkv];
-            else if (tid < 64) vsv = Vs[(size_t)kp * Hkv];
+            if (tid < 64 * NG) ssv = (s_isv ? Vs : Ks)[(size_t)kp * Hkv * NG + s_grp];
         } else {
             const int kp = min((blk - nbc) * PF_BLOCK + skey, new_len - 1);
             if (stager) {
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    kst[u] = *reinterpret_cast<const v4i*>(Kn + (size_t)kp * row_stride + sd16 * 16 + u * 8);
-                    vst[u] = *reinterpret_cast<const v4i*>(Vn + (size_t)kp * row_stride + sd16 * 16 + u * 8);
-                }
+                for (int p = 0; p < NP; p++)
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        kst[p][u] = *reinterpret_cast<const v4i*>(Kn + (size_t)kp * row_stride + (p * 8 + sd16) * 16 + u * 8);
+                        vst[p][u] = *reinterpret_cast<const v4i*>(Vn + (size_t)kp * row_stride + (p * 8 + sd16) * 16 + u * 8);
+                    }
             }
-            ksv = 1.0f;
-            vsv = 1.0f;
+            ssv = 1.0f;
         }
     };
     auto stash = [&](int blk) {
         if (stager) {
-            v4i kh[2], vh[2];
-            if (blk < nbc) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                v4i kh[2], vh[2];
+                if (blk < nbc) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint2 k0 = i8x4_to_f16x4((uint32_t)kst[p][0][2 * u]), k1 = i8x4_to_f16x4((uint32_t)kst[p][0][2 * u + 1]);
+                        const uint2 v0 = i8x4_to_f16x4((uint32_t)vst[p][0][2 * u]), v1 = i8x4_to_f16x4((uint32_t)vst[p][0][2 * u + 1]);
+                        kh[u] = v4i{(int)k0.x, (int)k0.y, (int)k1.x, (int)k1.y};
+                        vh[u] = v4i{(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                    }
+                } else {
+                    kh[0] = kst[p][0]; kh[1] = kst[p][1]; vh[0] = vst[p][0]; vh[1] = vst[p][1];
+                }
+                const int d0 = (p * 8 + sd16) * 16;
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    const uint2 k0 = i8x4_to_f16x4((uint32_t)kst[0][2 * u]), k1 = i8x4_to_f16x4((uint32_t)kst[0][2 * u + 1]);
-                    const uint2 v0 = i8x4_to_f16x4((uint32_t)vst[0][2 * u]), v1 = i8x4_to_f16x4((uint32_t)vst[0][2 * u + 1]);
-                    kh[u] = v4i{(int)k0.x, (int)k0.y, (int)k1.x, (int)k1.y};
-                    vh[u] = v4i{(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                    *reinterpret_cast<v4i*>(sK + skey * KROW + d0 + u * 8) = kh[u];
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        sVt[(d0 + u * 8 + e) * VROW + skey] = (uint16_t)(((uint32_t)vh[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
                 }
-            } else {
-                kh[0] = kst[0]; kh[1] = kst[1]; vh[0] = vst[0]; vh[1] = vst[1];
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                *reinterpret_cast<v4i*>(sK + skey * KROW + sd16 * 16 + u * 8) = kh[u];
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                    sVt[(sd16 * 16 + u * 8 + e) * VROW + skey] = (uint16_t)(((uint32_t)vh[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
             }
         }
-        if (tid < 32) sKs[tid] = ksv;
-        else if (tid < 64) sVs[tid - 32] = vsv;
+        if (tid < 64 * NG) (s_isv ? sVs : sKs)[s_grp][skey] = ssv;
     };
 
     float m_run = -INFINITY, l_run = 0.0f;
@@ -422,29 +436,35 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
         const int lim = (cached ? min(cl, kv_end) : kv_end) - kb;               // this query: ib < lim visible
         const bool full = (cached ? min(cl, kv_end_wave_lo) : kv_end_wave_lo) - kb >= PF_BLOCK && q_first + 31 < S;
 
-        v16f sacc;
+        v16f sacc[NG];
 #pragma unroll
-        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+        for (int n = 0; n < NG; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[n][r] = 0.0f;
 #pragma unroll
         for (int st = 0; st < NST; st++) {
             const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+            sacc[st * NG / NST] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc[st * NG / NST], 0, 0, 0);
         }
         // per-key scales of this lane's 16 keys (in-block index 8*(r/4) + 4*g + r%4)
-        float ksc[16], vsc[16];
+        float ksc[NG][16], vsc[NG][16];
 #pragma unroll
-        for (int r4 = 0; r4 < 4; r4++) {
-            const v4f kq = *reinterpret_cast<const v4f*>(sKs + 8 * r4 + 4 * g);
-            const v4f vq = *reinterpret_cast<const v4f*>(sVs + 8 * r4 + 4 * g);
+        for (int n = 0; n < NG; n++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) { ksc[4 * r4 + e] = kq[e]; vsc[4 * r4 + e] = vq[e]; }
-        }
+            for (int r4 = 0; r4 < 4; r4++) {
+                const v4f kq = *reinterpret_cast<const v4f*>(&sKs[n][8 * r4 + 4 * g]);
+                const v4f vq = *reinterpret_cast<const v4f*>(&sVs[n][8 * r4 + 4 * g]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { ksc[n][4 * r4 + e] = kq[e]; vsc[n][4 * r4 + e] = vq[e]; }
+            }
         const int limg = lim - 4 * g;
         float sc[16], wgt[16];
         float bm = -INFINITY, bsum = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float sv = (sacc[r] * ksc[r]) * scale;
+            float sv = sacc[0][r] * ksc[0][r];
+            if constexpr (NG == 2) sv += sacc[1][r] * ksc[1][r];
+            sv *= scale;
             sc[r] = (full || 8 * (r >> 2) + (r & 3) < limg) ? sv : -INFINITY;
             bm = fmaxf(bm, sc[r]);
         }
@@ -473,16 +493,18 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
         bsum += __shfl_xor(bsum, 32);
         l_run += bsum;
 
-        v8hf phi[2], plo[2];
+        v8hf phi[NG][2], plo[NG][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+        for (int n = 0; n < NG; n++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float wv = wgt[8 * ks + e] * vsc[8 * ks + e];
-                const _Float16 hi = (_Float16)wv;
-                phi[ks][e] = hi;
-                plo[ks][e] = (_Float16)(wv - (float)hi);
-            }
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float wv = wgt[8 * ks + e] * vsc[n][8 * ks + e];
+                    const _Float16 hi = (_Float16)wv;
+                    phi[n][ks][e] = hi;
+                    plo[n][ks][e] = (_Float16)(wv - (float)hi);
+                }
 #pragma unroll
         for (int dt = 0; dt < NDT; dt++) {
 #pragma unroll
@@ -492,8 +514,8 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
                 const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
                 const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
                 const v8hf vf = __builtin_bit_cast(v8hf, packed);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[dt * NG / NDT][ks], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[dt * NG / NDT][ks], o[dt], 0, 0, 0);
             }
         }
     }
@@ -531,7 +553,8 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
 }  // namespace
 
 bool attn_prefill_hybrid_ok(const AttnArgs& a) {
-    return !a.f16_mode && a.S >= 32 && (a.D == 64 || a.D == 128) && a.qgs >= a.D && a.Hkv > 0 && a.Hq % a.Hkv == 0 &&
+    return !a.f16_mode && a.S >= 32 && (((a.D == 64 || a.D == 128) && a.qgs >= a.D) || (a.D == 256 && a.qgs == 128)) &&
+           a.Hkv > 0 && a.Hq % a.Hkv == 0 &&
            a.S < (size_t(1) << 30) && a.cache_len + a.new_len < (size_t(1) << 30) && a.cache_len + a.new_len >= 1 &&
            a.Hq * a.B <= 1048576 &&
            (a.cache_len == 0 || (a.k_cached && a.v_cached && a.k_scales && a.v_scales &&
@@ -569,7 +592,8 @@ hipError_t launch_attention_prefill_hybrid(const AttnArgs& a, float* ws, hipStre
     const size_t total = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B * (size_t)nsplit;
     if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)total), block(256);
-    if (a.D == 128) attn_prefill_hybrid_kernel<128><<<grid, block, 0, st>>>(a, ws, nsplit);
+    if (a.D == 256) attn_prefill_hybrid_kernel<256><<<grid, block, 0, st>>>(a, ws, nsplit);
+    else if (a.D == 128) attn_prefill_hybrid_kernel<128><<<grid, block, 0, st>>>(a, ws, nsplit);
     else attn_prefill_hybrid_kernel<64><<<grid, block, 0, st>>>(a, ws, nsplit);
     return hipGetLastError();
 }
@@ -579,7 +603,7 @@ bool attn_prefill_ok(const AttnArgs& a) {
     // it moves kv_start only when window < KV and masks a key only when more than `window` behind its query)
     const bool no_window = a.window_size == 0 ||
                            (a.window_size >= a.new_len && a.position_offset + a.S <= a.window_size + 1);
-    return a.f16_mode && a.mask == nullptr && no_window && (a.D == 64 || a.D == 128) && a.S >= 32 &&
+    return a.f16_mode && a.mask == nullptr && no_window && (a.D == 64 || a.D == 128 || a.D == 256) && a.S >= 32 &&
            a.new_len >= 1 && a.new_len < (size_t(1) << 30) && a.S < (size_t(1) << 30) && a.Hkv > 0 &&
            a.Hq % a.Hkv == 0 && a.Hq <= 65535 && a.B <= 65535 && a.Hq * a.B <= 1048576 &&
            ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k_new) |
@@ -591,7 +615,8 @@ hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st) {
     const size_t total = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B;
     if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)total), block(256);
-    if (a.D == 128) attn_prefill_kernel<128><<<grid, block, 0, st>>>(a);
+    if (a.D == 256) attn_prefill_kernel<256><<<grid, block, 0, st>>>(a);
+    else if (a.D == 128) attn_prefill_kernel<128><<<grid, block, 0, st>>>(a);
     else attn_prefill_kernel<64><<<grid, block, 0, st>>>(a);
     return hipGetLastError();
 }

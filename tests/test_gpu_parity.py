@@ -563,6 +563,10 @@ HYBRID = [
     (1, 130, 2, 1, 128, 0, 130, 0),         # empty cache: only the chunk's own keys
     (1, 64, 2, 2, 64, 300, 64, 120),        # offset < cache_len: causal cut inside the cache
     (1, 33, 4, 1, 128, 90, 33, 700),        # offset beyond the chunk: nothing masked
+    (1, 256, 4, 1, 256, 700, 256, None),    # Gemma heads (head_dim 256, two scale groups per cached row)
+    (2, 70, 8, 2, 256, 333, 70, None),
+    (1, 64, 4, 1, 256, 0, 64, 0),           # ... empty cache
+    (1, 40, 4, 2, 256, 300, 40, 150),       # ... causal cut inside the cache
     # one query per sequence: the matrix-core decode kernel, one wave per (sequence, kv head, key range)
     (5, 1, 6, 3, 128, 77, 1, None),         # 15 waves of work: the last workgroup is part empty
     (3, 1, 16, 1, 64, 100, 1, None),        # 16 query heads on one kv head
@@ -675,6 +679,9 @@ F16ATT = [
     (1, 200, 200, 4, 1, 128, 0, 512, True, False),   # a window longer than the prompt cuts nothing: matrix-core kernel
     (1, 64, 300, 4, 1, 128, 236, 512, True, False),  # ... with an offset, still inside the window
     (1, 64, 600, 4, 1, 128, 536, 512, True, False),  # the window cuts: the VALU kernel
+    (1, 300, 300, 4, 1, 256, 0, 512, True, False),   # Gemma heads, a local layer's window longer than the prompt
+    (2, 130, 200, 8, 4, 256, 70, 0, True, False),    # ... a global layer, offset
+    (1, 75, 75, 4, 1, 256, 0, 0, False, False),      # ... non-causal, tail of 3
 ]
 
 
