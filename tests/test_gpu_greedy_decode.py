@@ -208,7 +208,7 @@ def test_greedy_tokens_identical(G, seed, prompt_len, steps, LAYERS, VOCAB, gain
 GEM = dict(HID=640, HQ=4, HKV=1, D=256, FF=2048, LAYERS=18, VOCAB=262144, EPS=1e-6)
 
 
-def gemma_model(rng, gain):
+def gemma_model(rng, gain, post=1.0):
     c = GEM
 
     def mat(n, k, g):
@@ -222,7 +222,7 @@ def gemma_model(rng, gain):
             "down": (c["HID"], c["FF"])}.items()}
         for name, n in {"in_norm": c["HID"], "post_attn_norm": c["HID"], "pre_ffn_norm": c["HID"],
                         "post_ffn_norm": c["HID"], "q_norm": c["D"], "k_norm": c["D"]}.items():
-            L[name] = (1.0 + 0.1 * rng.standard_normal(n)).astype(np.float16)
+            L[name] = ((post if name.startswith("post") else 1.0) * (1.0 + 0.1 * rng.standard_normal(n))).astype(np.float16)
         layers.append(L)
     # embedding rows of standard deviation about 0.05: scaled by sqrt(640) they are the size of one
     # normalized branch output, so the blocks, not the tied embedding, decide the next token
@@ -298,16 +298,20 @@ def gemma_graph_forward(G, g, wn, tokens, pos, cache):
     return out
 
 
-def test_gemma3_270m_shape_greedy_64_tokens(G):
+@pytest.mark.parametrize("post,rel,max_ties", [(1.0, 5e-2, 2), (0.15, 2.5e-2, 0)])
+def test_gemma3_270m_shape_greedy_64_tokens(G, post, rel, max_ties):
     """The reference's CPU-runnable configuration (Gemma-3-270m, INT8, 64 greedy tokens) on a
     synthetic model of that shape: at every step the device's greedy token equals the oracle's and
     the logits agree.  Random weights with normalized branch outputs fall into a one-token loop, so
     whenever the chosen token was produced before, both sides continue from a fresh seeded token
     instead (the comparison of that step's choice has already been made).  At most two of the 64
-    choices may differ, and only as near ties of the oracle's own logits."""
+    choices may differ, and only as near ties of the oracle's own logits.
+    Second case: post-attention / post-MLP norm weights around 0.15 instead of 1, so that a block's output is a
+    correction to the residual stream rather than its equal; one flipped INT8 activation then no longer reshapes
+    the logits (observed: at most 1.7 % of the largest logit instead of 4 %) and all 64 tokens must be identical."""
     import cactus_amd.hip as H
     rng = np.random.default_rng(12)
-    m = gemma_model(rng, 0.02)
+    m = gemma_model(rng, 0.02, post)
     prompt = rng.integers(0, GEM["VOCAB"], 6).tolist()
     g = G.CactusGraph()
     wn = bind(G, g, m)
@@ -324,7 +328,7 @@ def test_gemma3_270m_shape_greedy_64_tokens(G):
         # activation quantization of the next matmul until one flips a quantized value; from then on
         # the K/V rows in the two caches differ and Gemma's four norms per block carry the relative
         # difference through 18 blocks: observed up to 3.5 % of the largest logit, 0.6 % rms.
-        assert err <= 2e-2 + 5e-2 * np.abs(ref).max(), (step, err, np.abs(ref).max())
+        assert err <= 2e-2 + rel * np.abs(ref).max(), (step, err, np.abs(ref).max())
         td = int(H.sample_greedy(torch.from_numpy(lg_d[None].copy()).cuda()).cpu()[0])
         to = int(O.sample_greedy(lg_o[None])[0])
         dev_tokens.append(td)
@@ -338,7 +342,7 @@ def test_gemma3_270m_shape_greedy_64_tokens(G):
             td = to
         pos += len(feed)
         feed = [td] if dev_tokens.count(td) <= 1 and ora_tokens.count(td) <= 1 else [int(rng.integers(0, GEM["VOCAB"]))]
-    assert cache.get_total_seq_len() == 6 + 63 and near_ties <= 2
+    assert cache.get_total_seq_len() == 6 + 63 and near_ties <= max_ties
     g.close()
     cache.close()
 
