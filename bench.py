@@ -555,6 +555,30 @@ def qwen3_decode_via_graph(H, gen, cache_len=512, tokens=24):
         m.close()
     out["note"] = ("one sequence, cache_len %d, %d tokens: graph rebuilt per token through the Python binding of the C ABI "
                    "(about 700 node calls), synchronous token read-back" % (cache_len, tokens))
+    # the same loop from a C++ host program on the C ABI (examples/qwen_graph_decode.cpp), the model read from a
+    # folder in the reference's layout: what the op surface costs a compiled engine
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cactus_amd", "lib", "qwen_graph_decode")
+    if os.path.exists(exe):
+        import json as _json
+        import shutil
+        import tempfile
+        from cactus_amd import cact
+        folder = tempfile.mkdtemp(prefix="cactus_qwen3_")
+        try:
+            cact.write_qwen_folder(folder, host, cfg)
+            prompt = [str(t) for t in np.random.default_rng(3).integers(0, cfg["vocab"], cache_len).tolist()]
+            for fusion in (1, 0):
+                r = subprocess.run([exe, folder, str(tokens + 2), str(fusion)] + prompt, capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    out["cpp_host_error"] = r.stderr[-300:]
+                    break
+                d = _json.loads(r.stdout.strip().splitlines()[-1])
+                out["cpp_host_fused" if fusion else "cpp_host_node_by_node"] = {
+                    "ms_per_token": round(d["ms_per_token"], 3), "tokens_per_s": round(1e3 / d["ms_per_token"], 1),
+                    "build_ms": round(d["build_ms"], 3), "execute_ms": round(d["execute_ms"], 3),
+                    "cache_update_ms": round(d["cache_update_ms"], 3), "soft_reset_ms": round(d["soft_reset_ms"], 3)}
+        finally:
+            shutil.rmtree(folder, ignore_errors=True)
     return out
 
 

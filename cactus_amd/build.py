@@ -56,7 +56,25 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_examples(force or bool(procs), verbose)
     return SO
+
+
+def build_examples(force=False, verbose=False):
+    """examples/qwen_graph_decode.cpp -> cactus_amd/lib/qwen_graph_decode: a C++ host program on the C ABI
+    (host code only; it finds the library next to itself)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "qwen_graph_decode.cpp")
+    exe = os.path.join(LIBDIR, "qwen_graph_decode")
+    if not os.path.exists(src):
+        return None
+    inc = os.path.join(root, "include")
+    if force or _stale(exe, [src, SO, os.path.join(inc, "cactus_hip.h"), os.path.join(inc, "cactus_hip_graph.h")]):
+        cmd = ["hipcc", "-O2", "-std=c++17", "-Wall", "-I", inc, src, "-L", LIBDIR, "-lcactus_hip", "-Wl,-rpath,$ORIGIN", "-o", exe]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return exe
 
 
 if __name__ == "__main__":

@@ -1157,6 +1157,39 @@ int cactus_hip_attention_decode_fused_f16_dev(
     return CACTUS_HIP_OK;
 }
 
+int cactus_hip_attention_decode_fused_single_f16_dev(
+    const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,
+    const cactus_half_t* k_weight, const int8_t* k_cache, const int8_t* v_cache, const float* k_scales,
+    const float* v_scales, cactus_half_t* output, cactus_half_t* k_out, size_t cache_len, size_t position,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim, float eps, float theta, float scale, size_t group_size,
+    void* stream) {
+    if (!q || !k || !v || !q_weight || !k_weight || !k_cache || !v_cache || !k_scales || !v_scales || !output || !k_out)
+        return fail(CACTUS_HIP_EINVAL, "attention_decode_fused_single: null operand");
+    if (cache_len == 0 || position >= (size_t(1) << 30))
+        return fail(CACTUS_HIP_EINVAL, "attention_decode_fused_single: empty cache or position out of range");
+    AttnArgs a{};
+    a.q = q; a.k_cached = k_cache; a.v_cached = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;
+    a.k_new = k; a.v_new = v; a.out = output; a.B = 1; a.S = 1; a.cache_len = cache_len; a.new_len = 1;
+    a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.D = head_dim; a.scale = scale; a.is_causal = 1; a.qgs = group_size;
+    a.position_offset = position; a.f16_mode = 0;
+    if (!attn_decode_mfma_ok(a) || ((reinterpret_cast<uintptr_t>(q_weight) | reinterpret_cast<uintptr_t>(k_weight)) & 1) ||
+        (reinterpret_cast<uintptr_t>(k_out) & 15))
+        return fail(CACTUS_HIP_EINVAL,
+                    "attention_decode_fused_single: needs head_dim 64 or 128 with group_size >= head_dim (or 256 with group_size "
+                    "128), at most 16 query heads per kv head and 16-byte aligned rows");
+    AttnFusedIn f;
+    f.q_weight = q_weight; f.k_weight = k_weight; f.eps = eps; f.max_position = (int)position; f.max_slots = 0;
+    f.k_out = k_out;
+    int rc = rope_rows(head_dim, theta, 0, position + 1, &f.cos_t, &f.sin_t);
+    if (rc != CACTUS_HIP_OK) return rc;
+    void* ws = nullptr;
+    rc = workspace(attn_workspace_bytes(a), &ws);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_attention_decode_fused(a, f, ws, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "attention_decode_fused_single launch", e);
+    return CACTUS_HIP_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------

@@ -183,8 +183,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (act && is_k)
+            if (act && is_k) {
                 for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(kn_lds + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
+                if (f.k_out)      // key range 0 only (the other ranges do not process the key): one writer per row
+                    for (int c = l; c < D / 8; c += 16)
+                        *reinterpret_cast<v4i*>(f.k_out + ((size_t)b * Hkv + kvh) * D + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
+            }
             if (act && place && !is_q)
                 quant_row_groups(nrm, D, (int)a.qgs, (is_k ? f.kc : f.vc) + doff, (is_k ? f.ks : f.vs) + soff, l);
         }
@@ -583,7 +587,7 @@ hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit
     p.ws = ws;
     if (fused) p.f = *fused;
     if (nsplit > 1 && ws == nullptr) return hipErrorInvalidValue;
-    if (fused && (a.new_len != 1 || !a.cache_lens || !a.pos_offsets || !a.is_causal)) return hipErrorInvalidValue;
+    if (fused && (a.new_len != 1 || !a.is_causal || ((!a.cache_lens || !a.pos_offsets) && a.B != 1))) return hipErrorInvalidValue;
     // 8 waves per workgroup cover a whole 8-head row of the cache; the wider workgroup pays when there are
     // many of them and their LDS rings are small (head_dim 64)
     const int nw = a.D == 256 ? 2 : (a.D == 64 && p.n_items >= 4096) ? 8 : 4;

@@ -1018,22 +1018,134 @@ bool CactusGraph::try_fuse_activation(size_t mul_idx, std::vector<char>& done) {
     return true;
 }
 
-// A node a fused launch skipped (RMS_NORM, SILU / GELU, MULTIPLY), computed now from its inputs.
+// A node a fused launch skipped (RMS_NORM, SILU / GELU, MULTIPLY; RESHAPE and ROPE in front of a fused decode
+// attention), computed now from its inputs.
 void CactusGraph::materialize(size_t idx) {
     GraphNode& n = *nodes_[idx];
     if (n.output_buffer.device_valid) return;
     if (n.op_type != OpType::RMS_NORM && n.op_type != OpType::SILU && n.op_type != OpType::GELU &&
-        n.op_type != OpType::MULTIPLY)
+        n.op_type != OpType::MULTIPLY && n.op_type != OpType::RESHAPE && n.op_type != OpType::ROPE)
         return;
     for (size_t in : n.input_ids) {
         materialize(node_index_map_.at(in));
         if (!node(in).output_buffer.device_valid) return;
     }
+    if (n.op_type == OpType::RESHAPE) {
+        make_view(n);
+        return;
+    }
     ensure_device(n.output_buffer);
     if (n.op_type == OpType::RMS_NORM) compute_rms_norm_node(n);
     else if (n.op_type == OpType::MULTIPLY) compute_binary_node(n);
+    else if (n.op_type == OpType::ROPE) compute_rope_node(n);
     else compute_activation_node(n);
     n.output_buffer.device_valid = true;
+}
+
+// RESHAPE: a view - same bytes, new shape
+void CactusGraph::make_view(GraphNode& n) {
+    BufferDesc& in = node(n.input_ids[0]).output_buffer;
+    BufferDesc& out = n.output_buffer;
+    if (out.owns_device && out.device_data) pool_.release(out.device_data);
+    out.device_data = in.device_data;
+    out.owns_device = false;
+    out.device_valid = true;
+}
+
+// nodes_[attn_idx] is an ATTENTION_INT8_HYBRID over one new token of one sequence whose q and k inputs are each
+// rope(reshape(rms_norm(reshape(projection)))) - per-head norm and RoPE of the projections' rows, as every
+// decoder of the reference builds them (model_qwen.cpp:63-84) - read by nothing else in the graph, with equal
+// epsilon, theta and position on both sides, on a shape the fused decode kernel takes.
+bool CactusGraph::match_decode_attention(size_t attn_idx, AttnChain* out) const {
+    const GraphNode& a = *nodes_[attn_idx];
+    if (a.op_type != OpType::ATTENTION_INT8_HYBRID || a.input_ids.size() < 3) return false;
+    const OpParams& p = a.params;
+    const size_t D = p.head_dim, Hkv = p.num_kv_heads;
+    if (p.cache_seq_len == 0 || !p.cached_keys_int8 || !p.cached_values_int8 || !p.cached_k_scales || !p.cached_v_scales)
+        return false;
+    if (D != 64 && D != 128 && D != 256) return false;
+    auto chain = [&](size_t rope_id, size_t heads, size_t* norm_i, size_t* view_i, size_t* rope_i, size_t* src_id) {
+        auto it = node_index_map_.find(rope_id);
+        if (it == node_index_map_.end()) return false;
+        const GraphNode& rope = *nodes_[it->second];
+        if (rope.op_type != OpType::ROPE || rope.params.backend == ComputeBackend::NPU) return false;
+        const std::vector<size_t>& rs = rope.output_buffer.shape;
+        if (rs.size() != 4 || rs[0] != 1 || rs[1] != 1 || rs[2] != heads || rs[3] != D) return false;
+        if (rope.output_buffer.precision != Precision::FP16 || consumers_[it->second].size() != 1) return false;
+        const size_t vi = node_index_map_.at(rope.input_ids[0]);
+        const GraphNode& view = *nodes_[vi];
+        if (view.op_type != OpType::RESHAPE || consumers_[vi].size() != 1) return false;
+        const size_t ni = node_index_map_.at(view.input_ids[0]);
+        const GraphNode& norm = *nodes_[ni];
+        if (norm.op_type != OpType::RMS_NORM || consumers_[ni].size() != 1) return false;
+        const BufferDesc& in = node(norm.input_ids[0]).output_buffer;
+        const BufferDesc& w = node(norm.input_ids[1]).output_buffer;
+        if (in.shape.size() != 2 || in.shape[0] != heads || in.shape[1] != D || in.precision != Precision::FP16) return false;
+        if (w.precision != Precision::FP16 || w.total_size < D || !w.device_valid) return false;
+        *norm_i = ni; *view_i = vi; *rope_i = it->second; *src_id = norm.input_ids[0];
+        return true;
+    };
+    const BufferDesc& q = node(a.input_ids[0]).output_buffer;
+    if (q.shape.size() != 4 || Hkv == 0 || q.shape[2] % Hkv != 0 || q.shape[2] / Hkv > 16) return false;
+    AttnChain c;
+    if (!chain(a.input_ids[0], q.shape[2], &c.q_norm, &c.q_view, &c.q_rope, &c.q_src)) return false;
+    if (!chain(a.input_ids[1], Hkv, &c.k_norm, &c.k_view, &c.k_rope, &c.k_src)) return false;
+    const OpParams& qr = nodes_[c.q_rope]->params;
+    const OpParams& kr = nodes_[c.k_rope]->params;
+    if (qr.theta != kr.theta || qr.position_offset != kr.position_offset || qr.position_offset != p.position_offset) return false;
+    if (nodes_[c.q_norm]->params.epsilon != nodes_[c.k_norm]->params.epsilon) return false;
+    const BufferDesc& v = node(a.input_ids[2]).output_buffer;
+    if (v.precision != Precision::FP16 || v.total_size != Hkv * D) return false;
+    if (out) *out = c;
+    return true;
+}
+
+// RMS_NORM / RESHAPE / ROPE node idx sits in such a run: it is left for the attention node to take
+bool CactusGraph::deferred_to_attention(size_t idx) const {
+    size_t i = idx;
+    for (int hop = 0; hop < 3; hop++) {       // norm -> view -> rope -> attention
+        if (consumers_[i].size() != 1) return false;
+        i = consumers_[i][0];
+        if (nodes_[i]->op_type == OpType::ATTENTION_INT8_HYBRID) break;
+    }
+    AttnChain c;
+    if (nodes_[i]->op_type != OpType::ATTENTION_INT8_HYBRID || !match_decode_attention(i, &c)) return false;
+    return idx == c.q_norm || idx == c.q_view || idx == c.q_rope || idx == c.k_norm || idx == c.k_view || idx == c.k_rope;
+}
+
+// One launch for the run; the rotated key node is written by it (the KV cache is fed from that node), the
+// other five nodes stay unmaterialized until somebody asks for their output.
+bool CactusGraph::try_fuse_decode_attention(size_t attn_idx, std::vector<char>& done) {
+    AttnChain c;
+    if (!match_decode_attention(attn_idx, &c)) return false;
+    for (size_t i : {c.q_norm, c.q_view, c.q_rope, c.k_norm, c.k_view, c.k_rope})
+        if (done[i]) return false;      // computed on its own already: the plain path
+    GraphNode& a = *nodes_[attn_idx];
+    const BufferDesc& qs = node(c.q_src).output_buffer;
+    const BufferDesc& ks = node(c.k_src).output_buffer;
+    const BufferDesc& v = node(a.input_ids[2]).output_buffer;
+    if (!qs.device_valid || !ks.device_valid || !v.device_valid) return false;
+    GraphNode& krope = *nodes_[c.k_rope];
+    ensure_device(a.output_buffer);
+    ensure_device(krope.output_buffer);
+    const OpParams& p = a.params;
+    const int rc = cactus_hip_attention_decode_fused_single_f16_dev(
+        static_cast<const cactus_half_t*>(qs.device_data), static_cast<const cactus_half_t*>(ks.device_data),
+        static_cast<const cactus_half_t*>(v.device_data),
+        static_cast<const cactus_half_t*>(node(nodes_[c.q_norm]->input_ids[1]).output_buffer.device_data),
+        static_cast<const cactus_half_t*>(node(nodes_[c.k_norm]->input_ids[1]).output_buffer.device_data),
+        p.cached_keys_int8, p.cached_values_int8, p.cached_k_scales, p.cached_v_scales,
+        static_cast<cactus_half_t*>(a.output_buffer.device_data), static_cast<cactus_half_t*>(krope.output_buffer.device_data),
+        p.cache_seq_len, p.position_offset, node(a.input_ids[0]).output_buffer.shape[2], p.num_kv_heads, p.head_dim,
+        nodes_[c.q_norm]->params.epsilon, nodes_[c.q_rope]->params.theta, p.scale, CACTUS_KV_QUANT_GROUP_SIZE, nullptr);
+    if (rc != CACTUS_HIP_OK) return false;      // a shape or alignment the kernel does not take: the plain path
+    fused_launches_++;
+    for (size_t i : {c.q_norm, c.q_view, c.q_rope, c.k_norm, c.k_view}) done[i] = 1;   // not valid: computed on demand
+    krope.output_buffer.device_valid = true;
+    done[c.k_rope] = 1;
+    a.output_buffer.device_valid = true;
+    done[attn_idx] = 1;
+    return true;
 }
 
 void CactusGraph::execute() {
@@ -1088,6 +1200,24 @@ void CactusGraph::execute() {
                     done[a_idx] = 1;
                 }
             }
+            // per-head norm and RoPE in front of a one-token attention over the cache: the attention node takes
+            // them into its launch
+            if ((n.op_type == OpType::RMS_NORM || n.op_type == OpType::RESHAPE || n.op_type == OpType::ROPE) &&
+                deferred_to_attention(idx))
+                continue;               // not done: the attention node decides
+            if (n.op_type == OpType::ATTENTION_INT8_HYBRID) {
+                const size_t q_idx = node_index_map_.at(n.input_ids[0]);
+                if (!done[q_idx]) {     // the run deferred above
+                    if (try_fuse_decode_attention(idx, done)) continue;
+                    for (int s = 0; s < 2; s++) {           // the plain path: compute what was left for this node
+                        const size_t r = node_index_map_.at(n.input_ids[s]);
+                        const size_t v = node_index_map_.at(nodes_[r]->input_ids[0]);
+                        const size_t m = node_index_map_.at(nodes_[v]->input_ids[0]);
+                        materialize(r);
+                        done[m] = done[v] = done[r] = 1;
+                    }
+                }
+            }
         }
         for (size_t in : n.input_ids)
             if (!node(in).output_buffer.device_valid)
@@ -1126,13 +1256,8 @@ void CactusGraph::execute() {
             }
         }
 
-        if (n.op_type == OpType::RESHAPE) {   // a view: same bytes, new shape
-            BufferDesc& in = node(n.input_ids[0]).output_buffer;
-            BufferDesc& out = n.output_buffer;
-            if (out.owns_device && out.device_data) pool_.release(out.device_data);
-            out.device_data = in.device_data;
-            out.owns_device = false;
-            out.device_valid = true;
+        if (n.op_type == OpType::RESHAPE) {
+            make_view(n);
             continue;
         }
         if ((n.op_type == OpType::SLICE || n.op_type == OpType::INDEX) && n.params.axis == 0) {
@@ -1262,8 +1387,14 @@ void KVCache::init(size_t layers, size_t max_seq, size_t kv_heads, size_t dim) {
     total_seq_len = 0;
 }
 
+// Grows a layer's device buffers.  Growth is geometric (at least 256 tokens, at least double, never past
+// max_seq_len unless a single request asks for more): one token per step would otherwise re-allocate and copy
+// every layer's four buffers on every decode step.
 void KVCache::ensure_capacity(LayerCache& c, size_t tokens) {
     if (c.capacity_tokens >= tokens) return;
+    size_t want = std::max<size_t>(std::max<size_t>(256, 2 * c.capacity_tokens), tokens);
+    if (max_seq_len >= tokens) want = std::min(want, max_seq_len);
+    tokens = want;
     const size_t G = (head_dim + CACTUS_KV_QUANT_GROUP_SIZE - 1) / CACTUS_KV_QUANT_GROUP_SIZE;
     const size_t eb = tokens * num_kv_heads * head_dim, sb = tokens * num_kv_heads * G * sizeof(float);
     auto grow = [&](void* old, size_t old_bytes, size_t new_bytes) {
@@ -1351,13 +1482,29 @@ void KVCache::update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_no
     if (sliding && sink_size > window_size)
         throw std::runtime_error("KVCache: sink larger than the window");
 
+    // Quantization jobs are collected and launched together at the end, the equally sized ones of all layers in
+    // one launch (a decode step: K and V of every layer): they write disjoint rows, and every copy that moves
+    // older rows out of their way has been queued on the same stream by then.
+    std::vector<std::pair<size_t, cactus_hip::KvQuantJob>> jobs;
     auto quant = [&](const cactus_half_t* src, size_t src_token, LayerCache& c, bool keys, size_t dst_token,
                      size_t tokens) {
         if (tokens == 0) return;
         int8_t* d = (keys ? c.keys : c.values) + dst_token * ept;
         float* sc = (keys ? c.key_scales : c.value_scales) + dst_token * spt;
-        abi_check(cactus_hip_quantize_kv_fp16_to_int8_dev(src + src_token * ept, d, sc, tokens, kv_heads, dim,
-                                                          CACTUS_KV_QUANT_GROUP_SIZE, nullptr));
+        jobs.push_back({tokens, cactus_hip::KvQuantJob{src + src_token * ept, d, sc}});
+    };
+    auto flush_jobs = [&]() {
+        std::stable_sort(jobs.begin(), jobs.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        std::vector<cactus_hip::KvQuantJob> same;
+        for (size_t i = 0; i < jobs.size();) {
+            same.clear();
+            size_t j = i;
+            for (; j < jobs.size() && jobs[j].first == jobs[i].first; j++) same.push_back(jobs[j].second);
+            hip_check(cactus_hip::launch_kv_quant_jobs(same.data(), same.size(), jobs[i].first, kv_heads, dim,
+                                                       CACTUS_KV_QUANT_GROUP_SIZE, nullptr), "kv_quant launch");
+            i = j;
+        }
+        jobs.clear();
     };
 
     // validate before any state changes
@@ -1458,6 +1605,7 @@ void KVCache::update_from_graph(CactusGraph* gb, const std::vector<size_t>& k_no
         quant(ksrc, 0, c, true, dst_token, seq_len);
         quant(vsrc, 0, c, false, dst_token, seq_len);
     }
+    flush_jobs();
     if (scratch) {
         (void)hipStreamSynchronize(nullptr);
         (void)hipFree(scratch);

@@ -230,6 +230,15 @@ private:
     void launch_produced(int kind, bool int4, const std::vector<size_t>& mm, const void* x, const void* x2,
                          const void* w, void* sum_out, float eps, size_t M, size_t K);
     void materialize(size_t idx);
+    // the run rms_norm -> reshape -> rope on the q and k projections of a one-token attention_int8_hybrid node
+    struct AttnChain {
+        size_t q_norm, q_view, q_rope, k_norm, k_view, k_rope;   // node indices
+        size_t q_src, k_src;                                     // the projections' rows (node ids)
+    };
+    bool match_decode_attention(size_t attn_idx, AttnChain* out) const;
+    bool deferred_to_attention(size_t idx) const;
+    bool try_fuse_decode_attention(size_t attn_idx, std::vector<char>& done);
+    void make_view(GraphNode& n);
     void compute_matmul_node(GraphNode& n);
     void compute_attention_node(GraphNode& n);
     void compute_attention_int8_hybrid_node(GraphNode& n);

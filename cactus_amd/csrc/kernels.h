@@ -17,6 +17,15 @@ hipError_t launch_fp16_to_int8(const uint16_t* src, int8_t* dst, size_t count, f
 hipError_t launch_max_abs(const uint16_t* src, size_t count, float* out, hipStream_t st);
 hipError_t launch_kv_quant(const uint16_t* src, int8_t* dst, float* scales, size_t seq, size_t heads,
                            size_t D, size_t gs, hipStream_t st);
+// equally shaped quantization jobs ([seq, heads, D] rows each) in launches of up to KV_QUANT_MAX_JOBS
+constexpr int KV_QUANT_MAX_JOBS = 64;
+struct KvQuantJob {
+    const uint16_t* src;
+    int8_t* dst;
+    float* scales;
+};
+hipError_t launch_kv_quant_jobs(const KvQuantJob* jobs, size_t count, size_t seq, size_t heads, size_t D, size_t gs,
+                                hipStream_t st);
 hipError_t launch_kv_quant_pair(const uint16_t* k_src, int8_t* k_dst, float* k_scales, const uint16_t* v_src,
                                 int8_t* v_dst, float* v_scales, size_t seq, size_t heads, size_t D, size_t gs,
                                 hipStream_t st);
@@ -144,12 +153,14 @@ struct AttnFusedIn {
     float* vs = nullptr;
     float eps = 0.0f;
     int max_position = 0;
-    size_t max_slots = 0;
+    size_t max_slots = 0;      // 0: nothing is appended
+    uint16_t* k_out = nullptr; // when given: the normalized, rotated key rows [B, Hkv, D] are also written here
 };
 hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st,
                                         const AttnFusedIn* fused = nullptr);
 // the whole fused launch (decode kernel + split merge); a must satisfy attn_decode_mfma_ok with new_len 1 and
-// per-sequence cache_lens / pos_offsets; workspace as attn_workspace_bytes(a)
+// per-sequence cache_lens / pos_offsets (one sequence: a.cache_len / a.position_offset will do); workspace as
+// attn_workspace_bytes(a)
 hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f, void* workspace, hipStream_t st);
 
 // attention_prefill.hip: cactus_attention_f16 for many queries on the FP16 matrix cores (head_dim 64 /

@@ -104,15 +104,11 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const uint16_t* __restrict
 // One 16-lane subgroup per (token*head, group) item; lane j owns elements 8j..8j+7 of each
 // 128-wide slice of the group.
 // blockIdx.y = 1 takes the second (src, dst, scales) set: K and V of a step in one launch.
-__global__ __launch_bounds__(256) void kv_quant_kernel(
-    const uint16_t* __restrict__ src0, int8_t* __restrict__ dst0, float* __restrict__ scales0,
-    const uint16_t* __restrict__ src1, int8_t* __restrict__ dst1, float* __restrict__ scales1,
+__device__ __forceinline__ void kv_quant_rows(
+    const uint16_t* __restrict__ src, int8_t* __restrict__ dst, float* __restrict__ scales,
     size_t rows, size_t D, size_t gs, size_t G, const int32_t* __restrict__ slots, size_t heads,
     size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
-    const int32_t* __restrict__ positions = nullptr, size_t seq_len = 1, int window = 0, int sink = 0) {
-    const uint16_t* __restrict__ src = blockIdx.y ? src1 : src0;
-    int8_t* __restrict__ dst = blockIdx.y ? dst1 : dst0;
-    float* __restrict__ scales = blockIdx.y ? scales1 : scales0;
+    const int32_t* __restrict__ positions, size_t seq_len, int window, int sink) {
     const size_t item = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int j = threadIdx.x & 15;
     const bool live = item < rows * G;
@@ -175,6 +171,16 @@ __global__ __launch_bounds__(256) void kv_quant_kernel(
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void kv_quant_kernel(
+    const uint16_t* __restrict__ src0, int8_t* __restrict__ dst0, float* __restrict__ scales0,
+    const uint16_t* __restrict__ src1, int8_t* __restrict__ dst1, float* __restrict__ scales1,
+    size_t rows, size_t D, size_t gs, size_t G, const int32_t* __restrict__ slots, size_t heads,
+    size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+    const int32_t* __restrict__ positions = nullptr, size_t seq_len = 1, int window = 0, int sink = 0) {
+    kv_quant_rows(blockIdx.y ? src1 : src0, blockIdx.y ? dst1 : dst0, blockIdx.y ? scales1 : scales0, rows, D, gs, G, slots,
+                  heads, cache_batch_stride, scale_batch_stride, max_slots, positions, seq_len, window, sink);
 }
 
 // One thread per packed byte.  Low nibble -> even element, high nibble -> odd element,
@@ -247,6 +253,40 @@ hipError_t launch_kv_quant_pair(const uint16_t* k_src, int8_t* k_dst, float* k_s
     kv_quant_kernel<<<dim3((unsigned)((items + 15) / 16), 2), dim3(256), 0, st>>>(
         k_src, k_dst, k_scales, v_src, v_dst, v_scales, rows, D, gs, G, nullptr, 1, 0, 0, 0);
     return hipGetLastError();
+}
+
+// Up to KV_QUANT_MAX_JOBS equally shaped (src, dst, scales) sets in one launch, blockIdx.y = set: the K and V rows
+// of every layer of a step (KVCache::update_from_graph, engine_cache.cpp:186-266).
+struct KvQuantJobSet {
+    const uint16_t* src[KV_QUANT_MAX_JOBS];
+    int8_t* dst[KV_QUANT_MAX_JOBS];
+    float* scales[KV_QUANT_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void kv_quant_jobs_kernel(const KvQuantJobSet jobs, size_t rows, size_t D, size_t gs, size_t G) {
+    const int jb = blockIdx.y;
+    kv_quant_rows(jobs.src[jb], jobs.dst[jb], jobs.scales[jb], rows, D, gs, G, nullptr, 1, 0, 0, 0, nullptr, 1, 0, 0);
+}
+
+hipError_t launch_kv_quant_jobs(const KvQuantJob* jobs, size_t count, size_t seq, size_t heads, size_t D, size_t gs,
+                                hipStream_t st) {
+    const size_t rows = seq * heads;
+    if (rows == 0 || D == 0) return hipSuccess;
+    const size_t G = (D + gs - 1) / gs;
+    const size_t items = rows * G;
+    for (size_t first = 0; first < count; first += KV_QUANT_MAX_JOBS) {
+        const size_t n = count - first < (size_t)KV_QUANT_MAX_JOBS ? count - first : (size_t)KV_QUANT_MAX_JOBS;
+        KvQuantJobSet set;
+        for (size_t i = 0; i < (size_t)KV_QUANT_MAX_JOBS; i++) {
+            const KvQuantJob& j = jobs[first + (i < n ? i : 0)];
+            set.src[i] = j.src;
+            set.dst[i] = j.dst;
+            set.scales[i] = j.scales;
+        }
+        kv_quant_jobs_kernel<<<dim3((unsigned)((items + 15) / 16), (unsigned)n), dim3(256), 0, st>>>(set, rows, D, gs, G);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_kv_append(const uint16_t* k_src, int8_t* k_cache, float* k_scales, const uint16_t* v_src,

@@ -58,6 +58,8 @@ SIGNATURES = {
         _i, [_vp] * 8 + [_sz, _sz, _vp, _sz, _sz, _sz, _sz, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_attention_decode_fused_f16_dev": (
         _i, [_vp] * 10 + [_sz, _vp, _vp, _sz, _sz, _sz, _sz, _f, _f, _f, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_attention_decode_fused_single_f16_dev": (
+        _i, [_vp] * 11 + [_sz, _sz, _sz, _sz, _sz, _f, _f, _f, _sz, _vp]),
     "cactus_hip_matmul_int8": (None, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz]),
     "cactus_hip_matmul_int4": (None, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz]),
     "cactus_hip_matmul_f16": (None, [_vp, _vp, _vp, _sz, _sz, _sz]),
@@ -710,6 +712,21 @@ def attention_decode_fused(q, k, v, q_weight, k_weight, k_cache, v_cache, k_scal
         B, _p(cache_lens), _p(positions), int(max_position), Hq, Hkv, D, float(eps), float(theta), float(scale),
         group_size, slots * Hkv * D, slots * Hkv * G, slots, slots, _stream()))
     return out
+
+
+def attention_decode_fused_single(q, k, v, q_weight, k_weight, k_cache, v_cache, k_scales, v_scales, cache_len, position,
+                                  eps, theta, scale=0.0, group_size=128):
+    """One sequence, cache length and position given by the host, nothing appended: q [Hq, D], k / v [Hkv, D] fp16
+    (the projections' rows), caches int8 [>= cache_len, Hkv, D] / fp32 [.., Hkv, G].  Returns (attention output
+    [1, 1, Hq, D], the normalized and rotated key rows [1, 1, Hkv, D])."""
+    Hq, D, Hkv = q.shape[-2], q.shape[-1], k.shape[-2]
+    out = torch.empty((1, 1, Hq, D), dtype=torch.float16, device=q.device)
+    k_out = torch.empty((1, 1, Hkv, D), dtype=torch.float16, device=q.device)
+    _check(lib.cactus_hip_attention_decode_fused_single_f16_dev(
+        _p(q), _p(k), _p(v), _p(q_weight), _p(k_weight), _p(k_cache), _p(v_cache), _p(k_scales), _p(v_scales), _p(out),
+        _p(k_out), int(cache_len), int(position), Hq, Hkv, D, float(eps), float(theta), float(scale), group_size,
+        _stream()))
+    return out, k_out
 
 
 def attention_hybrid_batched(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale, cache_lens,

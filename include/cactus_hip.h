@@ -484,6 +484,19 @@ int cactus_hip_attention_decode_fused_f16_dev(
     float scale, size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
     size_t max_cache_len, void* stream);
 
+/* The same launch for ONE sequence whose cache length and position the host knows, with nothing appended to the
+ * cache: CactusGraph::execute hands it the run rms_norm -> rope (on the q and k projections) ->
+ * attention_int8_hybrid of a decode step (model_qwen.cpp:63-99).  The normalized, rotated key rows are also
+ * written to k_out half[Hkv, D], from which KVCache::update_from_graph feeds the cache afterwards
+ * (engine_cache.cpp:186-266).  output and k_out equal those of cactus_hip_rms_norm_f16_dev + cactus_hip_rope_f16_dev
+ * + cactus_hip_attention_hybrid_int8_fp16_dev bit for bit.  Same shape limits as above; cache_len >= 1. */
+int cactus_hip_attention_decode_fused_single_f16_dev(
+    const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,
+    const cactus_half_t* k_weight, const int8_t* k_cache, const int8_t* v_cache, const float* k_scales,
+    const float* v_scales, cactus_half_t* output, cactus_half_t* k_out, size_t cache_len, size_t position,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim, float eps, float theta, float scale, size_t group_size,
+    void* stream);
+
 /* Batched-decode append: one new token per independent sequence, K and V [B,Hkv,D] quantized
  * (cactus_quantize_kv_fp16_to_int8 arithmetic) straight into slot slots[b] of sequence b's cache,
  * caches addressed as in the batched attention above (per-sequence strides in elements; a slot is

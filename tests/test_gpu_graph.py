@@ -741,6 +741,78 @@ def test_fused_runs_equal_node_by_node_execution(G, M, mixed, act):
         assert np.array_equal(outs[True][k], outs[False][k]), k
 
 
+def _decode_attention_run(G, g, rng, Hq, Hkv, D, cache_len, pos, dev_cache, share_q=False):
+    """q / k / v projections' rows -> per-head norm -> RoPE -> attention over an INT8 cache, as a decoder builds it."""
+    def inp(shape, data):
+        n = g.input(shape, G.FP16)
+        g.set_input(n, data)
+        return n
+    half = lambda *sh: (rng.standard_normal(sh) * 2).astype(np.float16)
+    qp, kp, vp = inp((1, Hq * D), half(1, Hq * D)), inp((1, Hkv * D), half(1, Hkv * D)), inp((1, Hkv * D), half(1, Hkv * D))
+    qw, kw = inp((D,), (1 + 0.1 * rng.standard_normal(D)).astype(np.float16)), inp((D,), (1 + 0.1 * rng.standard_normal(D)).astype(np.float16))
+    # the projections pass through an op first, so that they are computed nodes as in a model
+    qp, kp, vp = g.scalar_multiply(qp, 1.0), g.scalar_multiply(kp, 1.0), g.scalar_multiply(vp, 1.0)
+    qn = g.rms_norm(g.reshape(qp, (Hq, D)), qw, 1e-6)
+    kn = g.rms_norm(g.reshape(kp, (Hkv, D)), kw, 1e-6)
+    qr = g.rope(g.reshape(qn, (1, 1, Hq, D)), 1e4, pos)
+    kr = g.rope(g.reshape(kn, (1, 1, Hkv, D)), 1e4, pos)
+    v4 = g.reshape(vp, (1, 1, Hkv, D))
+    kc, vc, ks, vs = dev_cache
+    att = g.attention_int8_hybrid(qr, kr, v4, 1.0 / np.sqrt(D), pos, kc.data_ptr(), vc.data_ptr(), ks.data_ptr(), vs.data_ptr(),
+                                  cache_len, Hkv, D)
+    nodes = dict(att=att, kr=kr, qr=qr, qn=qn, kn=kn)
+    if share_q:
+        nodes["extra"] = g.scalar_multiply(qr, 2.0)     # a second reader of the rotated queries
+    return nodes
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,cache_len,pos", [(16, 8, 128, 512, 512), (4, 1, 256, 77, 300), (32, 8, 64, 2500, 2500),
+                                                    (6, 3, 128, 1, 1)])
+def test_fused_decode_attention_equals_node_by_node_execution(G, Hq, Hkv, D, cache_len, pos):
+    """rms_norm -> rope on q and k -> attention_int8_hybrid of one token as ONE launch: the attention rows, the
+    rotated key rows (written by that launch) and the nodes it skipped (computed on request) are identical to
+    node-by-node execution."""
+    gen = torch.Generator(device="cuda").manual_seed(D + cache_len)
+    NG = (D + 127) // 128
+    kc = torch.randint(-127, 128, (cache_len, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (cache_len, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ks = torch.rand((cache_len, Hkv, NG), device="cuda", generator=gen) * 0.02 + 1e-3
+    vs = torch.rand((cache_len, Hkv, NG), device="cuda", generator=gen) * 0.02 + 1e-3
+    outs = {}
+    for fusion in (False, True):
+        rng = np.random.default_rng(Hq + D)
+        g = G.CactusGraph()
+        g.set_fusion(fusion)
+        nodes = _decode_attention_run(G, g, rng, Hq, Hkv, D, cache_len, pos, (kc, vc, ks, vs))
+        g.execute()
+        assert g.fused_launches() == (1 if fusion else 0)
+        outs[fusion] = {k: u16(g.get_output(v)).copy() for k, v in nodes.items()}
+        g.close()
+    for k in outs[True]:
+        assert np.array_equal(outs[True][k], outs[False][k]), k
+
+
+def test_decode_attention_run_with_a_second_reader_is_left_alone(G):
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    Hq, Hkv, D, cache_len = 16, 8, 128, 100
+    kc = torch.randint(-127, 128, (cache_len, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (cache_len, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ks = torch.rand((cache_len, Hkv, 1), device="cuda", generator=gen) * 0.02 + 1e-3
+    vs = torch.rand((cache_len, Hkv, 1), device="cuda", generator=gen) * 0.02 + 1e-3
+    outs = {}
+    for share in (False, True):
+        g = G.CactusGraph()
+        nodes = _decode_attention_run(G, g, np.random.default_rng(2), Hq, Hkv, D, cache_len, cache_len, (kc, vc, ks, vs), share_q=share)
+        g.execute()
+        assert g.fused_launches() == (0 if share else 1)
+        outs[share] = {k: u16(g.get_output(v)).copy() for k, v in nodes.items()}
+        g.close()
+    for k in outs[False]:
+        assert np.array_equal(outs[True][k], outs[False][k]), k
+    qr = outs[True]["qr"].view(np.float16).astype(np.float32)
+    assert np.array_equal(outs[True]["extra"], (qr * 2).astype(np.float16).view(np.uint16))
+
+
 def test_fusion_leaves_open_runs_alone(G):
     """A norm that something other than a matmul reads, and an activation read twice, are computed as nodes."""
     rng = np.random.default_rng(4)

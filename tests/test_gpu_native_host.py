@@ -1,0 +1,78 @@
+"""A C++ host program on the C ABI (examples/qwen_graph_decode.cpp, built to cactus_amd/lib/qwen_graph_decode): it
+loads a model folder in the reference's layout (config.txt + CACT tensor files, models/model_qwen.cpp:17-44), runs
+prefill + greedy decode node by node through the graph surface and prints its tokens.  They must equal the
+oracle's greedy tokens on the same weights (the cut-down Qwen3 model of test_gpu_greedy_decode, whose top two
+logits are far apart at every step of this prompt) and those of the Python binding driving the same library."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from tests import test_gpu_greedy_decode as GD
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+EXE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cactus_amd", "lib", "qwen_graph_decode")
+
+
+def run_host(folder, steps, fusion, prompt):
+    r = subprocess.run([EXE, str(folder), str(steps), str(int(fusion))] + [str(t) for t in prompt], capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("fusion", [True, False])
+def test_cpp_host_decodes_the_oracles_tokens(tmp_path, fusion):
+    from cactus_amd import cact
+    assert os.path.exists(EXE), "cactus_amd/lib/qwen_graph_decode is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    LAYERS, VOCAB, steps = 4, 8192, 12
+    rng = np.random.default_rng(3)
+    m = GD.make_model(rng, LAYERS, VOCAB, 0.05)
+    prompt = rng.integers(0, VOCAB, 11).tolist()
+    cfg = dict(hidden=GD.HID, layers=LAYERS, q_heads=GD.HQ, kv_heads=GD.HKV, head_dim=GD.D, ffn=GD.FF, eps=GD.EPS, theta=GD.THETA)
+    cact.write_qwen_folder(tmp_path, m, cfg)
+    got = run_host(tmp_path, steps, fusion, prompt)
+    assert len(got["tokens"]) == steps + 1 and got["timed_steps"] == steps - 2
+    if fusion:
+        assert got["fused_launches"] > 0
+    # the oracle's greedy run; a step whose two best logits are closer than 1 % of the largest is not compared
+    # (decode attention rounds about one output in thirty the other way) and ends the comparison
+    caches = [None] * LAYERS
+    feed, pos, compared = prompt, 0, 0
+    for step in range(steps + 1):
+        ref = GD.oracle_forward(m, feed, pos, caches).view(np.float16).astype(np.float64)
+        srt = np.sort(ref)
+        if srt[-1] - srt[-2] < 1e-2 * np.abs(ref).max():
+            break
+        assert got["tokens"][step] == int(np.argmax(ref)), (step, got["tokens"])
+        compared += 1
+        pos += len(feed)
+        feed = [got["tokens"][step]]
+    assert compared >= 6
+
+
+def test_cpp_host_and_python_binding_agree(tmp_path):
+    """The same folder through cactus_amd.steps.Qwen3GraphModel (weights bound from host arrays instead of files):
+    identical tokens, step for step."""
+    import cactus_amd.hip as H
+    H.init(0)
+    from cactus_amd import cact, steps as ST
+    LAYERS, VOCAB, steps = 4, 8192, 10
+    rng = np.random.default_rng(8)
+    m = GD.make_model(rng, LAYERS, VOCAB, 0.05)
+    prompt = rng.integers(0, VOCAB, 5).tolist()
+    cfg = dict(hidden=GD.HID, layers=LAYERS, q_heads=GD.HQ, kv_heads=GD.HKV, head_dim=GD.D, ffn=GD.FF, eps=GD.EPS,
+               theta=GD.THETA, vocab=VOCAB)
+    cact.write_qwen_folder(tmp_path, m, cfg)
+    got = run_host(tmp_path, steps, True, prompt)["tokens"]
+    model = ST.Qwen3GraphModel(m, cfg, max_seq=256)
+    want = [model.step(prompt)]
+    for _ in range(steps):
+        want.append(model.step([want[-1]]))
+    model.close()
+    assert got == want
