@@ -770,7 +770,11 @@ def extra_table(H, gen, big):
                                      "entropy_us": round(ms_e * 1e3, 2)}
         del lg, smp
     ex["decode_tail"] = rows
-    ex["qwen3_0p6b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256)}
+    # Model::prefill's chunk_size (engine_model.cpp:170; 256 unless the backend names its own, :637-642): the
+    # engine's default, and chunks sized for this device (one chunk: FP16 attention over the whole prompt)
+    ex["qwen3_0p6b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256),
+                                "t4096_chunk1024": qwen3_prefill(H, gen, 4096, 1024),
+                                "t4096_chunk4096": qwen3_prefill(H, gen, 4096, 4096)}
     torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512),

@@ -229,6 +229,25 @@ def test_qwen3_chunked_prefill_matches_oracle(ST):
     assert frac[1] > 0.9 and min(frac) > 0.5, frac
 
 
+def test_qwen3_single_chunk_prefill_matches_oracle(ST):
+    """The whole prompt as one chunk (Model::prefill with chunk_size >= the prompt, engine_model.cpp:198-201): FP16
+    attention over all 160 tokens on the matrix cores, GEMMs with M = 160; logits, greedy choice, block 0's cache."""
+    layers, vocab, tokens = 4, 8192, 160
+    rng = np.random.default_rng(78)
+    m = make_model(rng, layers, vocab, 0.05, False)
+    cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
+    pf = ST.Qwen3Prefill(ST.weights_to_device(m), cfg, tokens, tokens)
+    prompt = rng.integers(0, vocab, tokens)
+    pf.toks.copy_(torch.from_numpy(prompt.reshape(1, tokens).astype(np.int32)))
+    caches = [None] * layers
+    pf.run_chunk(0)
+    lg_o = oracle_forward(m, prompt.tolist(), 0, caches)
+    torch.cuda.synchronize()
+    StepChecker().check(pf.logits.cpu().numpy()[0], int(pf.tok.cpu()[0]), lg_o, "prefill")
+    assert np.array_equal(pf.kc[0, 0].cpu().numpy(), caches[0][0])
+    assert np.array_equal(pf.ksc[0, 0].cpu().numpy(), caches[0][1])
+
+
 def conv_rows(cc):
     """The oracle's circular ConvCache rows of one block in temporal order, zeros for rows not held yet."""
     W, Cc = cc.W, cc.rows.shape[1]
