@@ -576,7 +576,15 @@ def qwen3_decode_via_graph(H, gen, cache_len=512, tokens=24):
                 out["cpp_host_fused" if fusion else "cpp_host_node_by_node"] = {
                     "ms_per_token": round(d["ms_per_token"], 3), "tokens_per_s": round(1e3 / d["ms_per_token"], 1),
                     "build_ms": round(d["build_ms"], 3), "execute_ms": round(d["execute_ms"], 3),
-                    "cache_update_ms": round(d["cache_update_ms"], 3), "soft_reset_ms": round(d["soft_reset_ms"], 3)}
+                    "cache_update_ms": round(d["cache_update_ms"], 3), "soft_reset_ms": round(d["soft_reset_ms"], 3),
+                    "prefill_%d_tokens_ms" % cache_len: round(d["prefill_ms"], 2)}
+            # a 4096-token prompt as one chunk through the same surface
+            long_prompt = [str(t) for t in np.random.default_rng(4).integers(0, cfg["vocab"], 4096).tolist()]
+            r = subprocess.run([exe, folder, "4", "1"] + long_prompt, capture_output=True, text=True, timeout=300)
+            if r.returncode == 0:
+                d = _json.loads(r.stdout.strip().splitlines()[-1])
+                out["cpp_host_prefill_4096"] = {"ms": round(d["prefill_ms"], 2),
+                                                "tokens_per_s": round(4096 / (d["prefill_ms"] * 1e-3), 1)}
         finally:
             shutil.rmtree(folder, ignore_errors=True)
     return out
