@@ -27,6 +27,8 @@
 #include "common.hip.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace cactus_hip {
 
 namespace {
@@ -156,102 +158,109 @@ void attn_prefill_kernel(const AttnArgs a) {
         const int ke = min(KV, kb + PF_BLOCK);
         const int vec = ((ke - kb) / 4) * 4;
 
-        // scores of 32 keys x 32 queries
-        v16f sacc;
+        // One block's arithmetic.  FULL: every one of the block's 32 keys is visible to every query of the wave
+        // (all but the blocks on the causal diagonal and the last one): no masks, no selects, no expf tail.
+        auto block_math = [&](auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            // scores of 32 keys x 32 queries
+            v16f sacc;
 #pragma unroll
-        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+            for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
 #pragma unroll
-        for (int st = 0; st < NST; st++) {
-            const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
-        }
+            for (int st = 0; st < NST; st++) {
+                const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+            }
 
-        // This lane's 16 keys: in-block index ib = 8*(r/4) + 4*g + r%4.  A key is visible when
-        // ib < lim (the block's keys below KV and, if causal, not after the query); most blocks
-        // are visible to the whole wave and whole (32 keys, all on the polynomial) -- that path
-        // has no per-element selects.
-        const int lim_blk = ke - kb;
-        const int lim = a.is_causal ? (int)max(-1LL, min((long long)lim_blk, qabs - kb + 1)) : lim_blk;
-        const bool full = lim_blk == PF_BLOCK && (!a.is_causal || off + q_first - kb + 1 >= PF_BLOCK) && q_first + 31 < S;
-        const int limg = lim - 4 * g;
-        float sc[16], wgt[16];
-        float bm = -INFINITY, bsum = 0.0f;
-        if (full) {
+            // This lane's 16 keys: in-block index ib = 8*(r/4) + 4*g + r%4.  A key is visible when
+            // ib < lim (the block's keys below KV and, if causal, not after the query); most blocks
+            // are visible to the whole wave and whole (32 keys, all on the polynomial) -- that path
+            // has no per-element selects.
+            const int lim_blk = ke - kb;
+            const int lim = a.is_causal ? (int)max(-1LL, min((long long)lim_blk, qabs - kb + 1)) : lim_blk;
+            const int limg = lim - 4 * g;
+            float sc[16], wgt[16];
+            float bm = -INFINITY, bsum = 0.0f;
+            if constexpr (FULL) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[r] = sacc[r] * scale;
-                bm = fmaxf(bm, sc[r]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[r] = (8 * (r >> 2) + (r & 3) < limg) ? sacc[r] * scale : -INFINITY;
-                bm = fmaxf(bm, sc[r]);
-            }
-        }
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        if (bm > -INFINITY) {            // :160-169, the running maximum is replaced
-            const float corr = __expf(m_run - bm);
-            l_run *= corr;
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const v2f c2 = {corr, corr};
-#pragma unroll
-            for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const v2f t = v2f{o[dt][r], o[dt][r + 1]} * c2;
-                    o[dt][r] = t[0];
-                    o[dt][r + 1] = t[1];
+                for (int r = 0; r < 16; r++) {
+                    sc[r] = sacc[r] * scale;
+                    bm = fmaxf(bm, sc[r]);
                 }
-            m_run = bm;
-        }
-        // weights: the polynomial of :178-191 evaluated without branches (a masked key's -inf gives
-        // garbage that the select discards); the expf tail of :197-204 only exists in a block that
-        // ends at KV with KV % 4 != 0
-        const int vecg = vec - 4 * g;
+            } else {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const float x = (sc[r] - bm) * 1.442695f;
-            const int xi = (int)x;
-            const float xf = x - (float)xi;
-            float y = fmaf(xf, 0.6931472f, 1.0f);
-            y = fmaf(xf * xf, 0.2402265f, y);
-            float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
-            if (!full) {
-                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(sc[r] - bm);
-                wv = (sc[r] == -INFINITY) ? 0.0f : wv;
+                for (int r = 0; r < 16; r++) {
+                    sc[r] = (8 * (r >> 2) + (r & 3) < limg) ? sacc[r] * scale : -INFINITY;
+                    bm = fmaxf(bm, sc[r]);
+                }
             }
-            wgt[r] = wv;
-            bsum += wv;
-        }
-        bsum += __shfl_xor(bsum, 32);
-        l_run += bsum;
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            if (FULL || bm > -INFINITY) {    // :160-169, the running maximum is replaced
+                const float corr = __expf(m_run - bm);
+                l_run *= corr;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f c2 = {corr, corr};
+#pragma unroll
+                for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const v2f t = v2f{o[dt][r], o[dt][r + 1]} * c2;
+                        o[dt][r] = t[0];
+                        o[dt][r + 1] = t[1];
+                    }
+                m_run = bm;
+            }
+            // weights: the polynomial of :178-191 evaluated without branches (a masked key's -inf gives
+            // garbage that the select discards); the expf tail of :197-204 only exists in a block that
+            // ends at KV with KV % 4 != 0
+            const int vecg = vec - 4 * g;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float x = (sc[r] - bm) * 1.442695f;
+                const int xi = (int)x;
+                const float xf = x - (float)xi;
+                float y = fmaf(xf, 0.6931472f, 1.0f);
+                y = fmaf(xf * xf, 0.2402265f, y);
+                float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
+                if constexpr (!FULL) {
+                    if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(sc[r] - bm);
+                    wv = (sc[r] == -INFINITY) ? 0.0f : wv;
+                }
+                wgt[r] = wv;
+                bsum += wv;
+            }
+            bsum += __shfl_xor(bsum, 32);
+            l_run += bsum;
 
-        // P^T operands: the lane's weights r = 8*ks .. 8*ks+7, as hi + lo binary16 parts
-        v8hf phi[2], plo[2];
+            // P^T operands: the lane's weights r = 8*ks .. 8*ks+7, as hi + lo binary16 parts
+            v8hf phi[2], plo[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+            for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float wv = wgt[8 * ks + e];
-                const _Float16 hi = (_Float16)wv;
-                phi[ks][e] = hi;
-                plo[ks][e] = (_Float16)(wv - (float)hi);
+                for (int e = 0; e < 8; e++) {
+                    const float wv = wgt[8 * ks + e];
+                    const _Float16 hi = (_Float16)wv;
+                    phi[ks][e] = hi;
+                    plo[ks][e] = (_Float16)(wv - (float)hi);
+                }
+            // V^T operand of (d tile, k step): keys {16ks + 4g + 0..3} and {16ks + 8 + 4g + 0..3} of row d
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
+                    const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                    const v8hf vf = __builtin_bit_cast(v8hf, packed);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
+                }
             }
-        // V^T operand of (d tile, k step): keys {16ks + 4g + 0..3} and {16ks + 8 + 4g + 0..3} of row d
-#pragma unroll
-        for (int dt = 0; dt < NDT; dt++) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
-                const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
-                const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
-                const v8hf vf = __builtin_bit_cast(v8hf, packed);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
-            }
-        }
+        };
+        const int lim_blk_w = ke - kb;
+        if (lim_blk_w == PF_BLOCK && (!a.is_causal || off + q_first - kb + 1 >= PF_BLOCK) && q_first + 31 < S) block_math(std::true_type{});
+        else block_math(std::false_type{});
     }
 
     if (!q_live) return;
