@@ -445,88 +445,96 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
         const int lim = (cached ? min(cl, kv_end) : kv_end) - kb;               // this query: ib < lim visible
         const bool full = (cached ? min(cl, kv_end_wave_lo) : kv_end_wave_lo) - kb >= PF_BLOCK && q_first + 31 < S;
 
-        v16f sacc[NG];
+        // One block's arithmetic.  FULL: all 32 keys are visible to every query of the wave: no masks.
+        auto block_math = [&](auto full_tag) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            v16f sacc[NG];
 #pragma unroll
-        for (int n = 0; n < NG; n++)
+            for (int n = 0; n < NG; n++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) sacc[n][r] = 0.0f;
+                for (int r = 0; r < 16; r++) sacc[n][r] = 0.0f;
 #pragma unroll
-        for (int st = 0; st < NST; st++) {
-            const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
-            sacc[st * NG / NST] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc[st * NG / NST], 0, 0, 0);
-        }
-        // per-key scales of this lane's 16 keys (in-block index 8*(r/4) + 4*g + r%4)
-        float ksc[NG][16], vsc[NG][16];
-#pragma unroll
-        for (int n = 0; n < NG; n++)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) {
-                const v4f kq = *reinterpret_cast<const v4f*>(&sKs[n][8 * r4 + 4 * g]);
-                const v4f vq = *reinterpret_cast<const v4f*>(&sVs[n][8 * r4 + 4 * g]);
-#pragma unroll
-                for (int e = 0; e < 4; e++) { ksc[n][4 * r4 + e] = kq[e]; vsc[n][4 * r4 + e] = vq[e]; }
+            for (int st = 0; st < NST; st++) {
+                const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
+                sacc[st * NG / NST] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc[st * NG / NST], 0, 0, 0);
             }
-        const int limg = lim - 4 * g;
-        float sc[16], wgt[16];
-        float bm = -INFINITY, bsum = 0.0f;
+            // per-key scales of this lane's 16 keys (in-block index 8*(r/4) + 4*g + r%4)
+            float ksc[NG][16], vsc[NG][16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float sv = sacc[0][r] * ksc[0][r];
-            if constexpr (NG == 2) sv += sacc[1][r] * ksc[1][r];
-            sv *= scale;
-            sc[r] = (full || 8 * (r >> 2) + (r & 3) < limg) ? sv : -INFINITY;
-            bm = fmaxf(bm, sc[r]);
-        }
-        bm = fmaxf(bm, __shfl_xor(bm, 32));
-        const float mn = fmaxf(m_run, bm);
-        if (mn > -INFINITY) {              // :395-414
-            const float corr = __expf(m_run - mn);
-            l_run *= corr;
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            const v2f c2 = {corr, corr};
+            for (int n = 0; n < NG; n++)
 #pragma unroll
-            for (int dt = 0; dt < NDT; dt++)
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const v4f kq = *reinterpret_cast<const v4f*>(&sKs[n][8 * r4 + 4 * g]);
+                    const v4f vq = *reinterpret_cast<const v4f*>(&sVs[n][8 * r4 + 4 * g]);
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const v2f t = v2f{o[dt][r], o[dt][r + 1]} * c2;
-                    o[dt][r] = t[0];
-                    o[dt][r + 1] = t[1];
+                    for (int e = 0; e < 4; e++) { ksc[n][4 * r4 + e] = kq[e]; vsc[n][4 * r4 + e] = vq[e]; }
                 }
-            m_run = mn;
-        }
+            const int limg = lim - 4 * g;
+            float sc[16], wgt[16];
+            float bm = -INFINITY, bsum = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            wgt[r] = (sc[r] == -INFINITY) ? 0.0f : __expf(sc[r] - mn);
-            bsum += wgt[r];
-        }
-        bsum += __shfl_xor(bsum, 32);
-        l_run += bsum;
+            for (int r = 0; r < 16; r++) {
+                float sv = sacc[0][r] * ksc[0][r];
+                if constexpr (NG == 2) sv += sacc[1][r] * ksc[1][r];
+                sv *= scale;
+                sc[r] = (FULL || 8 * (r >> 2) + (r & 3) < limg) ? sv : -INFINITY;
+                bm = fmaxf(bm, sc[r]);
+            }
+            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            const float mn = fmaxf(m_run, bm);
+            // :395-414.  Once the running maximum has settled no lane's changes, the factor is exactly 1 in every
+            // lane and the accumulators are left alone (a wave-uniform test).
+            if (__builtin_amdgcn_ballot_w64(mn > m_run) != 0) {
+                const float corr = mn > m_run ? __expf(m_run - mn) : 1.0f;   // a lane whose maximum stays (or that has seen no key yet)
+                l_run *= corr;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f c2 = {corr, corr};
+#pragma unroll
+                for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const v2f t = v2f{o[dt][r], o[dt][r + 1]} * c2;
+                        o[dt][r] = t[0];
+                        o[dt][r + 1] = t[1];
+                    }
+                m_run = mn;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                wgt[r] = (!FULL && sc[r] == -INFINITY) ? 0.0f : __expf(sc[r] - mn);
+                bsum += wgt[r];
+            }
+            bsum += __shfl_xor(bsum, 32);
+            l_run += bsum;
 
-        v8hf phi[NG][2], plo[NG][2];
+            v8hf phi[NG][2], plo[NG][2];
 #pragma unroll
-        for (int n = 0; n < NG; n++)
+            for (int n = 0; n < NG; n++)
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
+                for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const float wv = wgt[8 * ks + e] * vsc[n][8 * ks + e];
-                    const _Float16 hi = (_Float16)wv;
-                    phi[n][ks][e] = hi;
-                    plo[n][ks][e] = (_Float16)(wv - (float)hi);
+                    for (int e = 0; e < 8; e++) {
+                        const float wv = wgt[8 * ks + e] * vsc[n][8 * ks + e];
+                        const _Float16 hi = (_Float16)wv;
+                        phi[n][ks][e] = hi;
+                        plo[n][ks][e] = (_Float16)(wv - (float)hi);
+                    }
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
+                    const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                    const v8hf vf = __builtin_bit_cast(v8hf, packed);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[dt * NG / NDT][ks], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[dt * NG / NDT][ks], o[dt], 0, 0, 0);
                 }
-#pragma unroll
-        for (int dt = 0; dt < NDT; dt++) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
-                const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
-                const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
-                const v8hf vf = __builtin_bit_cast(v8hf, packed);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[dt * NG / NDT][ks], o[dt], 0, 0, 0);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[dt * NG / NDT][ks], o[dt], 0, 0, 0);
             }
-        }
+        };
+        if (full) block_math(std::true_type{});
+        else block_math(std::false_type{});
     }
 
     if (!q_live) return;
