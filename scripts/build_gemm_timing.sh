@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing-experiment variants of the GEMM (wrong results by design):
-#   scripts/build_gemm_timing.sh name "-DG3_TIMING=2" [name2 "flags2" ...]
+#   scripts/build_gemm_timing.sh name "-DG3_TIMING=2" (bits: cactus_amd/csrc/matmul_gemm.hip) [name2 "flags2" ...]
 # -> scripts/variants/libcactus_hip_<name>.so
 set -e
 cd "$(dirname "$0")/.."

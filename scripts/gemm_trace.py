@@ -21,6 +21,6 @@ G = K // 128
 for wg in (0, 3):
     for wv in range(8):
         slot = wg * 8 + wv
-        tot, b1, issue, load, b2, math = (buf[slot * 8 + i] for i in range(6))
-        print(f"wg {wg} wave {wv}: {tot / G:.0f}/group; barrier A {b1 / G:.0f}, load phase {load / G:.0f}, "
-              f"barrier B {b2 / G:.0f}, math phase {math / G:.0f}; prologue {buf[slot * 8 + 6]}, epilogue {buf[slot * 8 + 7]}")
+        cyc, ticks, pa, bar, pb = (buf[slot * 8 + i] for i in range(5))
+        print(f"wg {wg} wave {wv}: loop {cyc / G:.0f} cycles/step, {ticks * 10.0 / G:.0f} ns/step (clock {cyc / max(ticks, 1) * 100:.0f} MHz); "
+              f"first slab {pa / G:.0f}, barrier {bar / G:.0f}, second slab {pb / G:.0f}")
