@@ -691,7 +691,7 @@ hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f
     if (!pl.mfma) return hipErrorInvalidValue;
     float* ws = reinterpret_cast<float*>(workspace);
     hipError_t e = launch_attention_decode_mfma(a, ws, pl.nsplit, st, &f);
-    if (e == hipSuccess && pl.nsplit > 1) {
+    if (e == hipSuccess && pl.nsplit > 1 && !attn_decode_merge_waves(a, pl.nsplit)) {
         attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(ws, a.out, pl.nsplit, (int)a.D);
         e = hipGetLastError();
     }
@@ -730,7 +730,7 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) 
     }
     if (pl.mfma) {
         hipError_t em = launch_attention_decode_mfma(a, p.ws, pl.nsplit, st);
-        if (em == hipSuccess && pl.nsplit > 1) {
+        if (em == hipSuccess && pl.nsplit > 1 && !attn_decode_merge_waves(a, pl.nsplit)) {
             attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(p.ws, a.out, pl.nsplit, (int)a.D);
             em = hipGetLastError();
         }

@@ -101,7 +101,11 @@ __device__ __forceinline__ int v_swz(int row) {
 // query heads and of its kv head's key, with that kernel's arithmetic (16 lanes per row, rows in LDS) - and the
 // wave of key range 0 also quantizes the rotated key and the value into the cache at slot cache_lens[b]
 // (engine_cache.cpp:234-267), past the rows any wave reads.  One launch less per layer and token.
-template <int D, int NW, bool FUSED>
+// MERGE: the NW waves of a workgroup are the NW key ranges of ONE item; their (max, sum, O) records meet in LDS
+// (each wave's own, by then idle, ring region) and the workgroup writes the finished rows itself.  For launches of
+// few items and short caches, where a second launch for the merge costs more than the attention (one decoding
+// sequence: 8 items of 16 blocks).
+template <int D, int NW, bool FUSED, bool MERGE = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     constexpr int ROWB = D;                         // bytes per key row
     constexpr int VBYTES = DC_BLOCK * ROWB;         // V image of one block
@@ -117,9 +121,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hd = lane & 15, q = lane >> 4;         // hd: query head (B / D column) or key / dim row (A operand)
     const int Hkv = (int)a.Hkv, Hq = (int)a.Hq, gq = p.gq;
-    const int split = blockIdx.y;
-    const int item = (int)blockIdx.x * NW + w;
-    if (item >= p.n_items) return;                  // wave-uniform; the kernel has no barrier
+    const int split = MERGE ? w : (int)blockIdx.y;
+    const int nsplit = MERGE ? NW : p.nsplit;
+    const int item = MERGE ? (int)blockIdx.x : (int)blockIdx.x * NW + w;
+    if (item >= p.n_items) return;                  // wave-uniform (MERGE: never taken, every wave reaches the barrier)
     const int kvh = item % Hkv, b = item / Hkv;
     const int h0 = kvh * gq;
 
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     if (a.is_causal) kv_end = min(kv_end, qabs + 1);          // kernel_attention.cpp:331-332
     const int c_cnt = (int)min((long long)cl, kv_end);        // visible cached keys
     const int nbc = (c_cnt + DC_BLOCK - 1) / DC_BLOCK;
-    const int bps = (nbc + p.nsplit - 1) / p.nsplit;
+    const int bps = (nbc + nsplit - 1) / nsplit;
     const int blk_first = split * bps, blk_last = min(nbc, blk_first + bps);
 
     float scale = a.scale;
@@ -527,6 +532,65 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         }
         m_run = mn;
     }
+    if constexpr (MERGE) {
+        // this wave's record -> its own ring region: [head][m, l, O[D]] (every request of the wave has landed:
+        // rows past its range were still requested, as zeros)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float* recs = reinterpret_cast<float*>(my_lds);
+        static_assert(16 * (D + 2) * 4 <= DC_STAGES * STAGE, "record fits the wave's ring region");
+        if (hd < gq) {
+            float* rec = recs + hd * (D + 2);
+            if (q == 0) {
+                rec[0] = m_run;
+                rec[1] = l_part;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    *reinterpret_cast<float2*>(rec + 2 + 32 * c + 8 * q + 2 * j) = make_float2(oacc[c][0][j], oacc[c][1][j]);
+        }
+        __syncthreads();
+        // TPH threads per head, each four dims at a time; factors 2^(m_s - M) (scores are base 2 here)
+        constexpr int TPH = NW * 4;
+        const int head = (int)threadIdx.x / TPH, part = (int)threadIdx.x % TPH;
+        if (head < gq) {
+            const float* r0 = reinterpret_cast<const float*>(lds) + head * (D + 2);
+            constexpr int WSTR = DC_STAGES * STAGE / 4;     // floats between two waves' regions
+            float M = -INFINITY;
+#pragma unroll
+            for (int sp = 0; sp < NW; sp++) M = fmaxf(M, r0[sp * WSTR]);
+            float f[NW], L = 0.0f;
+#pragma unroll
+            for (int sp = 0; sp < NW; sp++) {
+                f[sp] = M > -INFINITY ? __builtin_amdgcn_exp2f(r0[sp * WSTR] - M) : 0.0f;
+                L = fmaf(r0[sp * WSTR + 1], f[sp], L);
+            }
+            const float inv = 1.0f / L;
+            const size_t orow = (size_t)b * Hq + h0 + head;
+            for (int d4 = part; d4 < D / 4; d4 += TPH) {
+                float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int sp = 0; sp < NW; sp++) {
+                    const float2 v0 = *reinterpret_cast<const float2*>(r0 + sp * WSTR + 2 + 4 * d4);
+                    const float2 v1 = *reinterpret_cast<const float2*>(r0 + sp * WSTR + 4 + 4 * d4);
+                    o[0] = fmaf(v0.x, f[sp], o[0]);
+                    o[1] = fmaf(v0.y, f[sp], o[1]);
+                    o[2] = fmaf(v1.x, f[sp], o[2]);
+                    o[3] = fmaf(v1.y, f[sp], o[3]);
+                }
+                uint32_t pk[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const uint16_t lo = L > 0.0f ? f2h_mul(o[2 * j], inv) : (uint16_t)0;       // :460-479
+                    const uint16_t hi = L > 0.0f ? f2h_mul(o[2 * j + 1], inv) : (uint16_t)0;
+                    pk[j] = (uint32_t)lo | ((uint32_t)hi << 16);
+                }
+                *reinterpret_cast<uint2*>(a.out + orow * D + 4 * d4) = make_uint2(pk[0], pk[1]);
+            }
+        }
+        return;
+    }
     if (hd >= gq) return;
     const size_t orow = (size_t)b * Hq + h0 + hd;
     if (p.nsplit == 1) {
@@ -578,6 +642,16 @@ bool attn_decode_mfma_ok(const AttnArgs& a) {
     return true;
 }
 
+// Waves per workgroup when the key ranges of an item are merged inside the workgroup (0: not for this shape).
+// It replaces the merge launch whenever the plan splits at all and an eighth (head_dim 256: a half) of the cache
+// is at most 8 blocks per wave: short caches of few sequences, where a launch costs more than the work.
+int attn_decode_merge_waves(const AttnArgs& a, int planned_splits) {
+    if (planned_splits <= 1) return 0;
+    const int nw = a.D == 256 ? 2 : 8;
+    const size_t blocks = (a.cache_len + DC_BLOCK - 1) / DC_BLOCK;
+    return blocks <= (size_t)nw * 8 ? nw : 0;
+}
+
 hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st, const AttnFusedIn* fused) {
     DecodeParams p;
     p.a = a;
@@ -586,8 +660,19 @@ hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit
     p.gq = (int)(a.Hq / a.Hkv);
     p.ws = ws;
     if (fused) p.f = *fused;
-    if (nsplit > 1 && ws == nullptr) return hipErrorInvalidValue;
     if (fused && (a.new_len != 1 || !a.is_causal || ((!a.cache_lens || !a.pos_offsets) && a.B != 1))) return hipErrorInvalidValue;
+    if (const int mw = attn_decode_merge_waves(a, nsplit)) {
+        p.nsplit = mw;
+        const dim3 grid((unsigned)p.n_items);
+#define DECODE_MERGE_LAUNCH(F)                                                                     \
+        if (a.D == 256) attn_decode_mfma_kernel<256, 2, F, true><<<grid, dim3(128), 0, st>>>(p);      \
+        else if (a.D == 128) attn_decode_mfma_kernel<128, 8, F, true><<<grid, dim3(512), 0, st>>>(p); \
+        else attn_decode_mfma_kernel<64, 8, F, true><<<grid, dim3(512), 0, st>>>(p);
+        if (fused) { DECODE_MERGE_LAUNCH(true) } else { DECODE_MERGE_LAUNCH(false) }
+#undef DECODE_MERGE_LAUNCH
+        return hipGetLastError();
+    }
+    if (nsplit > 1 && ws == nullptr) return hipErrorInvalidValue;
     // 8 waves per workgroup cover a whole 8-head row of the cache; the wider workgroup pays when there are
     // many of them and their LDS rings are small (head_dim 64)
     const int nw = a.D == 256 ? 2 : (a.D == 64 && p.n_items >= 4096) ? 8 : 4;
