@@ -591,9 +591,21 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* __restrict
     float best = first;
     uint32_t bi = 0;
     if (first == first) {   // not NaN
-        for (size_t i = threadIdx.x; i < vocab; i += 1024) {
-            const float v = h2f(row[i]);
-            if (v > best) { best = v; bi = (uint32_t)i; }   // per thread i increases: first maximum kept
+        if ((vocab & 7) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+            // eight logits per access; a thread's indices still increase, so its first maximum is kept
+            for (size_t c = threadIdx.x; c < vocab / 8; c += 1024) {
+                const v4i x = *reinterpret_cast<const v4i*>(row + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float v = h2f((uint16_t)(((uint32_t)x[e >> 1] >> (16 * (e & 1))) & 0xFFFFu));
+                    if (v > best) { best = v; bi = (uint32_t)(c * 8 + e); }
+                }
+            }
+        } else {
+            for (size_t i = threadIdx.x; i < vocab; i += 1024) {
+                const float v = h2f(row[i]);
+                if (v > best) { best = v; bi = (uint32_t)i; }   // per thread i increases: first maximum kept
+            }
         }
     }
     auto better = [](float v, uint32_t i, float bv, uint32_t bidx) { return v > bv || (v == bv && i < bidx); };

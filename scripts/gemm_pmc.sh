@@ -11,7 +11,7 @@ import csv, glob, collections
 for f in sorted(glob.glob('gpurun_out/gemm_pmc/*/*/*counter_collection.csv')):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'gemm2' in r['Kernel_Name']:
+        if 'gemm3' in r['Kernel_Name']:
             k = 'int4' if 'ILb1E' in r['Kernel_Name'] or '<true>' in r['Kernel_Name'] else 'int8'
             acc[(k, r['Counter_Name'])].append(float(r['Counter_Value']))
     for k, v in sorted(acc.items()):
