@@ -194,9 +194,11 @@ SHAPES = [
     (24, 25600, 32),                                                        # 200 groups: falls back to the plain tile kernel
     (512, 384, 8192), (520, 256, 8200),                                     # >= 256 tiles: 128-row tiles (fewer: 64-row tiles)
     (512, 256, 2048), (1000, 384, 2100),                                    # 128 or more 64-row tiles, fewer than 256 128-row tiles: 64-row tiles (below that: 32-row tiles)
-    # the INT8 kernel's six-stage ring (64- and 32-row tiles): K steps around its depth of five, and long runs
+    # the tile kernel's four-stage ring (loader waves run three tiles ahead): K steps around its depth, and long runs
     (48, 640, 256), (100, 896, 640), (70, 1408, 400), (256, 640, 4224), (256, 768, 4224), (256, 1152, 4224),
     (256, 2048, 4224), (200, 8192, 256),
+    # a single K step (no steady state at all) at each tile height: 32-, 64- and 128-row tiles
+    (40, 128, 300), (512, 128, 2048), (512, 128, 8192),
 ]
 
 
