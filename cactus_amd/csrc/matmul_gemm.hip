@@ -371,7 +371,10 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
             int q_tmp[PQ], q_dst[PQ][2];
 #pragma unroll
             for (int j = 0; j < PQ; j++) {
-                const int pi = p * PQ + j, row = pi * 16 + (lane >> 2), c4 = lane & 3, sw = (row >> 1) & 7;
+                // eight consecutive lanes (one cycle of a 16-byte LDS store) take rows r and r ^ 2, whose swizzles
+                // differ in the low bit: their eight 16-byte slots fall on distinct banks of the 128-byte store row
+                const int l4 = lane >> 2, rsel = (l4 & ~3) | ((l4 & 1) << 1) | ((l4 >> 1) & 1);
+                const int pi = p * PQ + j, row = pi * 16 + rsel, c4 = lane & 3, sw = (row >> 1) & 7;
                 q_src[j] = (unsigned)min(row, N - 1 - n0) * (unsigned)(K / 2) + c4 * 16;
                 q_tmp[j] = 16384 + pi * 2048 + 1024;
                 q_dst[j][0] = 16384 + row * 128 + (((2 * c4) ^ sw) << 4);
