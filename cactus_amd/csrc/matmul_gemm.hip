@@ -280,7 +280,10 @@ constexpr int G3_LW = G3_LOADERS;                 // loader waves per workgroup
 constexpr int G3_THREADS = 512 + 64 * G3_LW;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <bool INT4, int NI>
+// NJ: 16-column MFMA tiles per compute wave along n (2: 128-column workgroup tile; 1: 64 columns, for launches of
+// few rows whose 128-column tiles would leave most CUs without a workgroup -- the weight stream of a small batch is
+// bound by how many CUs pull on it).
+template <bool INT4, int NI, int NJ>
 __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B_arg,
     const uint16_t* __restrict__ B_scales_arg, uint16_t* __restrict__ C_arg, int M, int K, int N_arg, int G, int nbm,
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         bn -= pi ? bt.bn_end[pi - 1] : 0;
         B = bt.B[pi]; B_scales = bt.Bs[pi]; C = bt.C[pi]; N = bt.N[pi];
     }
-    constexpr int BM = 32 * NI;
-    const int m0 = bm * BM, n0 = bn * GM_BN;
+    constexpr int BM = 32 * NI, BN = 64 * NJ;
+    const int m0 = bm * BM, n0 = bn * BN;
 
     auto barrier = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -316,17 +319,17 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
     // scale panel -> LDS, transposed to [group][column]; every wave helps
     auto stage_scales = [&]() {
         if ((G & 7) == 0 && (reinterpret_cast<uintptr_t>(B_scales) & 15) == 0) {
-            for (int idx = t; idx < GM_BN * (G >> 3); idx += G3_THREADS) {
+            for (int idx = t; idx < BN * (G >> 3); idx += G3_THREADS) {
                 const int n = idx / (G >> 3), g8 = (idx - n * (G >> 3)) * 8;
                 const v4i v = *reinterpret_cast<const v4i*>(B_scales + (size_t)min(n0 + n, N - 1) * G + g8);
 #pragma unroll
                 for (int e = 0; e < 8; e++)
-                    sc16[(g8 + e) * GM_BN + n] = (uint16_t)(((uint32_t)v[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                    sc16[(g8 + e) * BN + n] = (uint16_t)(((uint32_t)v[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
             }
         } else {
-            for (int idx = t; idx < GM_BN * G; idx += G3_THREADS) {
+            for (int idx = t; idx < BN * G; idx += G3_THREADS) {
                 const int n = idx / G, g = idx - n * G;
-                sc16[g * GM_BN + n] = B_scales[(size_t)min(n0 + n, N - 1) * G + g];
+                sc16[g * BN + n] = B_scales[(size_t)min(n0 + n, N - 1) * G + g];
             }
         }
     };
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
     if (w >= 8) {
         // ---- loader wave ----
         const int p = w - 8;
-        constexpr int PA = 4 * NI / G3_LW, PB = 16 / G3_LW;   // pieces (8 rows x 128 B) of the two tiles per loader
+        constexpr int PA = 4 * NI / G3_LW, PB = BN / 8 / G3_LW;   // pieces (8 rows x 128 B) of the two tiles per loader
         constexpr int R = PA + PB;                            // requests per tile and loader wave
         const int8_t* a_base = A + (size_t)m0 * K;
         unsigned a_src[PA];
@@ -355,8 +358,8 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         };
         if constexpr (INT4) {
             // Packed weights are unpacked HERE, once per tile, instead of by every compute wave on every
-            // fragment.  A loader owns 32 weight rows of the tile: it requests their packed bytes (two pieces of
-            // 16 rows x 64 bytes) by LDS-DMA into the upper half of the 4 KB those rows take up unpacked, and when
+            // fragment.  A loader owns a quarter of the tile's weight rows: it requests their packed bytes (pieces of
+            // 16 rows x 64 bytes) by LDS-DMA into the upper half of the 2 KB a piece's rows take up unpacked, and when
             // they have landed reads its own 16 bytes per lane back, turns each packed word into two words of
             // INT8 values x 16 in k order (nibble to the top of its byte: the sign comes for free and the exact
             // 1/16 goes into the scale) and stores them where an INT8 tile would lie.  Only the loader itself
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
             // overlap of a piece's staging bytes with its unpacked rows is harmless.  The compute waves run the
             // INT8 loop unchanged.  The LDS accesses are inline asm: beside LDS-DMA the compiler puts a
             // vmcnt(0) in front of LDS accesses it can see, which would drain the three tiles in flight.
-            constexpr int PQ = 8 / G3_LW;       // packed pieces per tile and loader
+            constexpr int PQ = BN / 16 / G3_LW;  // packed pieces (16 rows x 64 B) per tile and loader
             constexpr int R = PA + PQ;          // requests per tile and loader wave
             const uint8_t* b_base = B + (size_t)n0 * (size_t)(K / 2);
             unsigned q_src[PQ];
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
     // ---- compute wave ----
     const int wm = w >> 2, wn = w & 3;
     const int r = lane & 15, q = lane >> 4;
-    int fa_off[NI][2], fb_off[2][2];
+    int fa_off[NI][2], fb_off[NJ][2];
 #pragma unroll
     for (int i = 0; i < NI; i++) {
         const int row = wm * (16 * NI) + i * 16 + r;
@@ -511,36 +514,38 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         for (int sl = 0; sl < 2; sl++) fa_off[i][sl] = row * 128 + (((4 * sl + q) ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int row = wn * 32 + j * 16 + r;
+    for (int j = 0; j < NJ; j++) {
+        const int row = wn * (16 * NJ) + j * 16 + r;
 #pragma unroll
         for (int sl = 0; sl < 2; sl++) fb_off[j][sl] = 16384 + row * 128 + (((4 * sl + q) ^ ((row >> 1) & 7)) << 4);
     }
-    float run[NI][2][4];
-    v4i acc[NI][2];
+    float run[NI][NJ][4];
+    v4i acc[NI][NJ];
 #pragma unroll
     for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < NJ; j++) {
             acc[i][j] = v4i{0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 4; e++) run[i][j][e] = 0.0f;
         }
-    v4i f0a[NI], f0b[2], f1a[NI], f1b[2];   // fragments of the first / second slab of a step
-    // fragment read number x of a slab: the two weight fragments first, then the activation fragments
-    auto read_one = [&](const uint8_t* st, int sl, int x, v4i (&xa)[NI], v4i (&xb)[2]) {
-        if (x < 2) xb[x] = *reinterpret_cast<const v4i*>(st + fb_off[x][sl]);
-        else if (x < 2 + NI) xa[x - 2] = *reinterpret_cast<const v4i*>(st + fa_off[x - 2][sl]);
+    v4i f0a[NI], f0b[NJ], f1a[NI], f1b[NJ];   // fragments of the first / second slab of a step
+    // fragment read number x of a slab: the weight fragments first, then the activation fragments
+    auto read_one = [&](const uint8_t* st, int sl, int x, v4i (&xa)[NI], v4i (&xb)[NJ]) {
+        if (x < NJ) xb[x] = *reinterpret_cast<const v4i*>(st + fb_off[x][sl]);
+        else if (x < NJ + NI) xa[x - NJ] = *reinterpret_cast<const v4i*>(st + fa_off[x - NJ][sl]);
     };
     auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
-    constexpr int NT = 2 * NI;                       // MFMAs per slab
-    constexpr int RPS = (2 + NI + NT - 1) / NT;      // fragment reads issued behind each MFMA
+    constexpr int NT = NJ * NI;                      // MFMAs per slab
+    constexpr int RPS = (NJ + NI + NT - 1) / NT;     // fragment reads issued behind each MFMA
 
     stage_scales();
     barrier();   // scale panel and tile 0 visible
 #pragma unroll
-    for (int x = 0; x < 2 + NI; x++) read_one(g2_lds, 0, x, f0a, f0b);
-    float sprev[2] = {0.0f, 0.0f};   // scales of the group whose sums sit in acc (first pass: acc = 0 leaves run at +0)
+    for (int x = 0; x < NJ + NI; x++) read_one(g2_lds, 0, x, f0a, f0b);
+    float sprev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sprev[j] = 0.0f;   // scales of the group whose sums sit in acc (first pass: acc = 0 leaves run at +0)
 #ifdef GEMM_TRACE
     unsigned long long tr[3] = {0, 0, 0};
     const unsigned long long tr_c0 = clock64(), tr_r0 = wall_clock64();
@@ -555,12 +560,12 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         const uint8_t* stn = g2_lds + ((kt + 1) % G2_STAGES) * G2_STAGE;   // past the last tile: a finished stage, values unused
         G2_T(t0);
         fence();
-        unsigned sraw[2];
+        unsigned sraw[NJ];
 #pragma unroll
-        for (int j = 0; j < 2; j++) sraw[j] = sc16[kt * GM_BN + wn * 32 + j * 16 + r];
+        for (int j = 0; j < NJ; j++) sraw[j] = sc16[kt * BN + wn * (16 * NJ) + j * 16 + r];
 #pragma unroll
         for (int x = 0; x < NT; x++) {
-            const int i = x >> 1, j = x & 1;
+            const int i = x / NJ, j = x % NJ;
             float tmp[4];
             if (!(G3_TIMING & 2)) {
 #pragma unroll
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         fence();
 #pragma unroll
         for (int x = 0; x < NT; x++) {
-            const int i = x >> 1, j = x & 1;
+            const int i = x / NJ, j = x % NJ;
             if (!(G3_TIMING & 4) || x == 0)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f1a[i], f1b[j], acc[i][j], 0, 0, 0);
             if (!(G3_TIMING & 8)) {
@@ -603,9 +608,11 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         }
         // widened once per step behind an empty asm, so that the folds above are plain v_fma_f32 (the
         // compiler otherwise folds the conversion into every fma as v_fma_mix_f32)
-        sprev[0] = INT4 ? h2f((uint16_t)sraw[0]) * 0.0625f : h2f((uint16_t)sraw[0]);   // x 1/16: exact
-        sprev[1] = INT4 ? h2f((uint16_t)sraw[1]) * 0.0625f : h2f((uint16_t)sraw[1]);
-        asm volatile("" : "+v"(sprev[0]), "+v"(sprev[1]));
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            sprev[j] = INT4 ? h2f((uint16_t)sraw[j]) * 0.0625f : h2f((uint16_t)sraw[j]);   // x 1/16: exact
+            asm volatile("" : "+v"(sprev[j]));
+        }
 #pragma unroll
         for (int x = 0; x < NT; x++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -628,13 +635,13 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
 #pragma unroll
     for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++) run[i][j][e] = __builtin_fmaf((float)acc[i][j][e], sprev[j], run[i][j][e]);
 
     // Output: half(running * A_scale[m]), through LDS so that it leaves as 16-byte row segments.
     if (vec_store) {
-        constexpr int CS = GM_BN + 8;
+        constexpr int CS = BN + 8;
         uint16_t* ct = reinterpret_cast<uint16_t*>(g2_lds);
         barrier();                      // every wave is done with the ring
 #pragma unroll
@@ -644,14 +651,15 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
                 const int lm = wm * (16 * NI) + i * 16 + q * 4 + e;
                 const float as = A_scales[min(m0 + lm, M - 1)];
 #pragma unroll
-                for (int j = 0; j < 2; j++) ct[lm * CS + wn * 32 + j * 16 + r] = f2h_mul(run[i][j][e], as);
+                for (int j = 0; j < NJ; j++) ct[lm * CS + wn * (16 * NJ) + j * 16 + r] = f2h_mul(run[i][j][e], as);
             }
         barrier();
+        constexpr int SPR = BN / 8;                     // 16-byte segments per row
 #pragma unroll
-        for (int p = 0; p < NI; p++) {
-            const int idx = p * 512 + t, lm = idx >> 4, c8 = (idx & 15) * 8;
+        for (int p = 0; p < (BM * SPR + 511) / 512; p++) {
+            const int idx = p * 512 + t, lm = idx / SPR, c8 = (idx % SPR) * 8;
             const int m = m0 + lm, n = n0 + c8;
-            if (m < M && n < N)
+            if (lm < BM && m < M && n < N)
                 *reinterpret_cast<v4i*>(C + (size_t)m * N + n) = *reinterpret_cast<const v4i*>(ct + lm * CS + c8);
         }
     } else {
@@ -663,8 +671,8 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
                 if (m >= M) continue;
                 const float as = A_scales[m];
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int n = n0 + wn * 32 + j * 16 + r;
+                for (int j = 0; j < NJ; j++) {
+                    const int n = n0 + wn * (16 * NJ) + j * 16 + r;
                     if (n < N) C[(size_t)m * N + n] = f2h_mul(run[i][j][e], as);
                 }
             }
@@ -672,13 +680,13 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
 }
 
 // more than 64 KB of dynamic LDS has to be allowed once per device
-template <bool INT4, int NI>
+template <bool INT4, int NI, int NJ>
 static hipError_t gemm3_allow_lds() {
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<INT4, NI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<INT4, NI, NJ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
@@ -686,38 +694,44 @@ static hipError_t gemm3_allow_lds() {
     return hipSuccess;
 }
 
-template <bool INT4, int NI>
+template <bool INT4, int NI, int NJ>
 static hipError_t launch_gemm3(const int8_t* A, const float* A_scales, const uint8_t* B, const uint16_t* B_scales,
                                uint16_t* C, int M, int K, int N, int G, int nwg, const GemmBatch& bt, hipStream_t st) {
-    hipError_t e = gemm3_allow_lds<INT4, NI>();
+    hipError_t e = gemm3_allow_lds<INT4, NI, NJ>();
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * GM_BN * sizeof(uint16_t);
+    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * (64 * NJ) * sizeof(uint16_t);
     const int nbm = (M + 32 * NI - 1) / (32 * NI);
-    gemm3_kernel<INT4, NI><<<dim3((unsigned)nwg), dim3(G3_THREADS), lds, st>>>(A, A_scales, B, B_scales, C, M, K, N, G,
-                                                                              nbm, nwg, bt);
+    gemm3_kernel<INT4, NI, NJ><<<dim3((unsigned)nwg), dim3(G3_THREADS), lds, st>>>(A, A_scales, B, B_scales, C, M, K, N,
+                                                                                  G, nbm, nwg, bt);
     return hipGetLastError();
 }
 
-// Rows of the workgroup tile for M rows against nbn column tiles: 32 when even 64-row tiles would leave more
-// than half of the CUs without a workgroup, 64 when 128-row tiles would not give every CU one, else 128.
-static int gemm3_tile_rows(size_t M, size_t nbn) {
-    if (((M + 63) / 64) * nbn < 128) return 32;
-    if (((M + GM_BM - 1) / GM_BM) * nbn < 256) return 64;
-    return 128;
+// Workgroup tile for M rows against weight matrices of the given widths.  Rows: 32 when even 64-row tiles would
+// leave more than half of the CUs without a workgroup, 64 when 128-row tiles would not give every CU one, else
+// 128.  Columns: 128, or 64 when 32-row tiles of 128 columns still number fewer than the CUs.
+struct GemmTile { int rows, cols; };
+static GemmTile gemm3_tile(size_t M, const size_t* Ns, size_t count) {
+    size_t nbn = 0;
+    for (size_t i = 0; i < count; i++) nbn += (Ns[i] + GM_BN - 1) / GM_BN;
+    if (((M + 63) / 64) * nbn < 128) return {32, ((M + 31) / 32) * nbn < 256 ? 64 : 128};
+    if (((M + GM_BM - 1) / GM_BM) * nbn < 256) return {64, 128};
+    return {128, 128};
 }
 
-// bt.count == 0: the single problem B / B_scales / C / N; else the problems of bt side by side (nbn column tiles in all)
+// bt.count == 0: the single problem B / B_scales / C / N; else the problems of bt side by side (nbn column tiles of
+// tl.cols in all, as bt.bn_end counts them)
 template <bool INT4>
 static hipError_t launch_gemm3_any(const int8_t* A, const float* A_scales, const uint8_t* B, const uint16_t* B_scales,
-                                   uint16_t* C, size_t M, size_t K, size_t N, int G, size_t nbn, const GemmBatch& bt,
-                                   hipStream_t st) {
-    const int rows = gemm3_tile_rows(M, nbn);
-    const size_t nwg = ((M + rows - 1) / rows) * nbn;
+                                   uint16_t* C, size_t M, size_t K, size_t N, int G, GemmTile tl, size_t nbn,
+                                   const GemmBatch& bt, hipStream_t st) {
+    const size_t nwg = ((M + tl.rows - 1) / tl.rows) * nbn;
     if (nwg == 0) return hipSuccess;
     if (nwg >= (size_t(1) << 30)) return hipErrorInvalidValue;
-    if (rows == 32) return launch_gemm3<INT4, 1>(A, A_scales, B, B_scales, C, (int)M, (int)K, (int)N, G, (int)nwg, bt, st);
-    if (rows == 64) return launch_gemm3<INT4, 2>(A, A_scales, B, B_scales, C, (int)M, (int)K, (int)N, G, (int)nwg, bt, st);
-    return launch_gemm3<INT4, 4>(A, A_scales, B, B_scales, C, (int)M, (int)K, (int)N, G, (int)nwg, bt, st);
+    const int m = (int)M, k = (int)K, n = (int)N, g = (int)nwg;
+    if (tl.rows == 32 && tl.cols == 64) return launch_gemm3<INT4, 1, 1>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
+    if (tl.rows == 32) return launch_gemm3<INT4, 1, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
+    if (tl.rows == 64) return launch_gemm3<INT4, 2, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
+    return launch_gemm3<INT4, 4, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
 }
 
 #ifdef GEMM_TRACE
@@ -740,9 +754,12 @@ hipError_t launch_matmul_gemm_batch(bool int4, const int8_t* A, const float* A_s
     GemmBatch bt;
     memset(&bt, 0, sizeof bt);
     bt.count = (int)count;
+    size_t Ns[G2_MAXB];
+    for (size_t i = 0; i < count; i++) Ns[i] = pr[i].N;
+    const GemmTile tl = gemm3_tile(M, Ns, count);
     size_t nbn = 0;
     for (size_t i = 0; i < count; i++) {
-        nbn += (pr[i].N + GM_BN - 1) / GM_BN;
+        nbn += (pr[i].N + tl.cols - 1) / tl.cols;
         if (nbn >= (size_t(1) << 30)) return hipErrorInvalidValue;
         bt.bn_end[i] = (int)nbn;
         bt.B[i] = static_cast<const uint8_t*>(pr[i].B);
@@ -750,8 +767,8 @@ hipError_t launch_matmul_gemm_batch(bool int4, const int8_t* A, const float* A_s
         bt.C[i] = pr[i].C;
         bt.N[i] = (int)pr[i].N;
     }
-    return int4 ? launch_gemm3_any<true>(A, A_scales, nullptr, nullptr, nullptr, M, K, 0, G, nbn, bt, st)
-                : launch_gemm3_any<false>(A, A_scales, nullptr, nullptr, nullptr, M, K, 0, G, nbn, bt, st);
+    return int4 ? launch_gemm3_any<true>(A, A_scales, nullptr, nullptr, nullptr, M, K, 0, G, tl, nbn, bt, st)
+                : launch_gemm3_any<false>(A, A_scales, nullptr, nullptr, nullptr, M, K, 0, G, tl, nbn, bt, st);
 }
 
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
@@ -763,9 +780,10 @@ hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales,
         GemmBatch none;
         memset(&none, 0, sizeof none);
         const uint8_t* Bp = static_cast<const uint8_t*>(B);
-        const size_t nbn = (N + GM_BN - 1) / GM_BN;
-        return int4 ? launch_gemm3_any<true>(A, A_scales, Bp, B_scales, C, M, K, N, G, nbn, none, st)
-                    : launch_gemm3_any<false>(A, A_scales, Bp, B_scales, C, M, K, N, G, nbn, none, st);
+        const GemmTile tl = gemm3_tile(M, &N, 1);
+        const size_t nbn = (N + tl.cols - 1) / tl.cols;
+        return int4 ? launch_gemm3_any<true>(A, A_scales, Bp, B_scales, C, M, K, N, G, tl, nbn, none, st)
+                    : launch_gemm3_any<false>(A, A_scales, Bp, B_scales, C, M, K, N, G, tl, nbn, none, st);
     }
     const dim3 grid((unsigned)((N + GM_BN - 1) / GM_BN), (unsigned)((M + GM_BM - 1) / GM_BM)), block(256);
     if (int4)

@@ -199,6 +199,8 @@ SHAPES = [
     (256, 2048, 4224), (200, 8192, 256),
     # a single K step (no steady state at all) at each tile height: 32-, 64- and 128-row tiles
     (40, 128, 300), (512, 128, 2048), (512, 128, 8192),
+    # 12 to 16 rows against a wide matrix: the tile kernel with 64-column tiles (INT8; INT4 stays on the streaming kernel)
+    (16, 1024, 12288 + 16), (12, 256, 12300), (11, 256, 12300),
 ]
 
 
