@@ -706,16 +706,31 @@ static hipError_t launch_gemm3(const int8_t* A, const float* A_scales, const uin
     return hipGetLastError();
 }
 
-// Workgroup tile for M rows against weight matrices of the given widths.  Rows: 32 when even 64-row tiles would
-// leave more than half of the CUs without a workgroup, 64 when 128-row tiles would not give every CU one, else
-// 128.  Columns: 128, or 64 when 32-row tiles of 128 columns still number fewer than the CUs.
+// Workgroup tile for M rows against weight matrices of the given widths: the largest of 128x128, 64x128, 128x64,
+// 64x64, 32x128, 32x64 (rows x columns) among those that give the most workgroups without exceeding one per CU;
+// 128x128 when every tile gives more.  Measured over decode- and prefill-step shapes (scripts/tile_sweep.sh): a
+// launch is fastest with as many CUs pulling on the operands as it can get, and slower again once the workgroups
+// no longer fit the chip at once (M = 256, K = 1024: N = 4096 7.1 us at 64x128 = 128 workgroups, 6.1 at 64x64 = 256,
+// 8.6 at 32x64 = 512; N = 6144 7.5 us at 64x128 = 192, 9.9 at 64x64 = 384).
 struct GemmTile { int rows, cols; };
 static GemmTile gemm3_tile(size_t M, const size_t* Ns, size_t count) {
-    size_t nbn = 0;
-    for (size_t i = 0; i < count; i++) nbn += (Ns[i] + GM_BN - 1) / GM_BN;
-    if (((M + 63) / 64) * nbn < 128) return {32, ((M + 31) / 32) * nbn < 256 ? 64 : 128};
-    if (((M + GM_BM - 1) / GM_BM) * nbn < 256) return {64, 128};
-    return {128, 128};
+#ifdef G3_FORCE_ROWS
+    return {G3_FORCE_ROWS, G3_FORCE_COLS};
+#endif
+    constexpr size_t NCU = 256;
+    static const GemmTile cand[6] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}, {32, 128}, {32, 64}};
+    GemmTile best = cand[0];
+    size_t best_wg = 0;
+    for (const GemmTile& t : cand) {
+        size_t nbn = 0;
+        for (size_t i = 0; i < count; i++) nbn += (Ns[i] + t.cols - 1) / t.cols;
+        const size_t wg = ((M + t.rows - 1) / t.rows) * nbn;
+        if (wg <= NCU && wg > best_wg) {
+            best = t;
+            best_wg = wg;
+        }
+    }
+    return best;   // no tile fits the chip at once: 128 x 128
 }
 
 // bt.count == 0: the single problem B / B_scales / C / N; else the problems of bt side by side (nbn column tiles of
@@ -730,7 +745,9 @@ static hipError_t launch_gemm3_any(const int8_t* A, const float* A_scales, const
     const int m = (int)M, k = (int)K, n = (int)N, g = (int)nwg;
     if (tl.rows == 32 && tl.cols == 64) return launch_gemm3<INT4, 1, 1>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
     if (tl.rows == 32) return launch_gemm3<INT4, 1, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
+    if (tl.rows == 64 && tl.cols == 64) return launch_gemm3<INT4, 2, 1>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
     if (tl.rows == 64) return launch_gemm3<INT4, 2, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
+    if (tl.cols == 64) return launch_gemm3<INT4, 4, 1>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
     return launch_gemm3<INT4, 4, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
 }
 
