@@ -706,26 +706,26 @@ static hipError_t launch_gemm3(const int8_t* A, const float* A_scales, const uin
     return hipGetLastError();
 }
 
-// Workgroup tile for M rows against weight matrices of the given widths: the largest of 128x128, 64x128, 128x64,
-// 64x64, 32x128, 32x64 (rows x columns) among those that give the most workgroups without exceeding one per CU;
-// 128x128 when every tile gives more.  Measured over decode- and prefill-step shapes (scripts/tile_sweep.sh): a
-// launch is fastest with as many CUs pulling on the operands as it can get, and slower again once the workgroups
-// no longer fit the chip at once (M = 256, K = 1024: N = 4096 7.1 us at 64x128 = 128 workgroups, 6.1 at 64x64 = 256,
-// 8.6 at 32x64 = 512; N = 6144 7.5 us at 64x128 = 192, 9.9 at 64x64 = 384).
+// Workgroup tile for M rows against weight matrices of the given widths: among 128x128, 64x128, 64x64, 32x128 and
+// 32x64 (rows x columns) the one that gives the most workgroups without exceeding one per CU (between equals the
+// smaller tile, then the taller); 128x128 when every tile gives more.  Measured over decode- and prefill-step
+// shapes (scripts/tile_sweep.sh): a launch is fastest with as many CUs pulling on the operands as it can get, and
+// slower again once the workgroups no longer fit the chip at once (M = 256, K = 1024: N = 4096 7.1 us at 64x128 =
+// 128 workgroups, 6.1 at 64x64 = 256, 8.6 at 32x64 = 512; N = 6144 7.5 us at 64x128 = 192, 9.9 at 64x64 = 384).
 struct GemmTile { int rows, cols; };
 static GemmTile gemm3_tile(size_t M, const size_t* Ns, size_t count) {
 #ifdef G3_FORCE_ROWS
     return {G3_FORCE_ROWS, G3_FORCE_COLS};
 #endif
     constexpr size_t NCU = 256;
-    static const GemmTile cand[6] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}, {32, 128}, {32, 64}};
+    static const GemmTile cand[5] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {32, 64}};
     GemmTile best = cand[0];
     size_t best_wg = 0;
     for (const GemmTile& t : cand) {
         size_t nbn = 0;
         for (size_t i = 0; i < count; i++) nbn += (Ns[i] + t.cols - 1) / t.cols;
         const size_t wg = ((M + t.rows - 1) / t.rows) * nbn;
-        if (wg <= NCU && wg > best_wg) {
+        if (wg <= NCU && (wg > best_wg || (wg == best_wg && t.rows * t.cols < best.rows * best.cols))) {
             best = t;
             best_wg = wg;
         }
@@ -747,7 +747,6 @@ static hipError_t launch_gemm3_any(const int8_t* A, const float* A_scales, const
     if (tl.rows == 32) return launch_gemm3<INT4, 1, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
     if (tl.rows == 64 && tl.cols == 64) return launch_gemm3<INT4, 2, 1>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
     if (tl.rows == 64) return launch_gemm3<INT4, 2, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
-    if (tl.cols == 64) return launch_gemm3<INT4, 4, 1>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
     return launch_gemm3<INT4, 4, 2>(A, A_scales, B, B_scales, C, m, k, n, G, g, bt, st);
 }
 
