@@ -1162,6 +1162,44 @@ int cactus_hip_attention_decode_fused_f16_dev(
     return CACTUS_HIP_OK;
 }
 
+int cactus_hip_attention_decode_fused_quant_f16_dev(
+    const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,
+    const cactus_half_t* k_weight, int8_t* k_cache, int8_t* v_cache, float* k_scales, float* v_scales,
+    cactus_half_t* output, int8_t* output_q, float* output_scales, size_t batch_size, const int32_t* cache_lens,
+    const int32_t* positions, size_t max_position, size_t num_q_heads, size_t num_kv_heads, size_t head_dim, float eps,
+    float theta, float scale, size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+    size_t max_cache_len, void* stream) {
+    if (batch_size == 0) return CACTUS_HIP_OK;
+    if (!q || !k || !v || !q_weight || !k_weight || !k_cache || !v_cache || !k_scales || !v_scales || !output ||
+        !output_q || !output_scales || !cache_lens || !positions)
+        return fail(CACTUS_HIP_EINVAL, "attention_decode_fused_quant: null operand");
+    if (max_position >= (size_t(1) << 30) || max_cache_len > max_slots)
+        return fail(CACTUS_HIP_EINVAL, "attention_decode_fused_quant: max_cache_len beyond max_slots");
+    AttnArgs a{};
+    a.q = q; a.k_cached = k_cache; a.v_cached = v_cache; a.k_scales = k_scales; a.v_scales = v_scales;
+    a.k_new = k; a.v_new = v; a.out = output; a.B = batch_size; a.S = 1; a.cache_len = max_cache_len; a.new_len = 1;
+    a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.D = head_dim; a.scale = scale; a.is_causal = 1; a.qgs = group_size;
+    a.cache_lens = cache_lens; a.pos_offsets = positions;
+    a.cache_batch_stride = cache_batch_stride; a.scale_batch_stride = scale_batch_stride; a.f16_mode = 0;
+    if (!attn_decode_mfma_ok(a) || ((reinterpret_cast<uintptr_t>(q_weight) | reinterpret_cast<uintptr_t>(k_weight)) & 1) ||
+        (reinterpret_cast<uintptr_t>(output_q) & 7))
+        return fail(CACTUS_HIP_EINVAL,
+                    "attention_decode_fused_quant: needs head_dim 64 or 128 with group_size >= head_dim (or 256 with group_size 128), at most 16 "
+                    "query heads per kv head, 16-byte aligned rows and a cache that is not empty");
+    AttnFusedIn f;
+    f.q_weight = q_weight; f.k_weight = k_weight; f.kc = k_cache; f.vc = v_cache; f.ks = k_scales; f.vs = v_scales;
+    f.eps = eps; f.max_position = (int)max_position; f.max_slots = max_slots;
+    f.q_out = output_q; f.q_scales_out = output_scales;
+    int rc = rope_rows(head_dim, theta, 0, max_position + 1, &f.cos_t, &f.sin_t);
+    if (rc != CACTUS_HIP_OK) return rc;
+    void* ws = nullptr;
+    rc = workspace(attn_workspace_bytes(a), &ws);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_attention_decode_fused(a, f, ws, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "attention_decode_fused_quant launch", e);
+    return CACTUS_HIP_OK;
+}
+
 int cactus_hip_attention_decode_fused_single_f16_dev(
     const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,
     const cactus_half_t* k_weight, const int8_t* k_cache, const int8_t* v_cache, const float* k_scales,

@@ -690,11 +690,16 @@ hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f
     const Plan pl = make_plan(a);
     if (!pl.mfma) return hipErrorInvalidValue;
     float* ws = reinterpret_cast<float*>(workspace);
-    hipError_t e = launch_attention_decode_mfma(a, ws, pl.nsplit, st, &f);
+    // quantized output rows: inside the launch when a workgroup can hold a row, else by the row kernel behind it
+    AttnFusedIn fl = f;
+    const bool quant_behind = f.q_out != nullptr && !attn_decode_quant_ok(a, pl.nsplit);
+    if (quant_behind) fl.q_out = nullptr;
+    hipError_t e = launch_attention_decode_mfma(a, ws, pl.nsplit, st, &fl);
     if (e == hipSuccess && pl.nsplit > 1 && !attn_decode_merge_waves(a, pl.nsplit)) {
         attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(ws, a.out, pl.nsplit, (int)a.D);
         e = hipGetLastError();
     }
+    if (e == hipSuccess && quant_behind) e = launch_act_quant(a.out, f.q_out, f.q_scales_out, a.B, a.Hq * a.D, st);
     return e;
 }
 

@@ -105,7 +105,11 @@ __device__ __forceinline__ int v_swz(int row) {
 // (each wave's own, by then idle, ring region) and the workgroup writes the finished rows itself.  For launches of
 // few items and short caches, where a second launch for the merge costs more than the attention (one decoding
 // sequence: 8 items of 16 blocks).
-template <int D, int NW, bool FUSED, bool MERGE = false>
+// QOUT (with FUSED, one key range): the NW waves of a workgroup are the NW kv heads of ONE sequence, so the workgroup
+// holds a whole output row [Hq * D] and also leaves it quantized for the output projection - the row's absmax over the
+// waves, then act_quant_rowwise_kernel's arithmetic on the fp16 values (graph_ops_nn.cpp:35-66) - which saves the
+// activation-quantization launch in front of that projection.
+template <int D, int NW, bool FUSED, bool MERGE = false, bool QOUT = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     constexpr int ROWB = D;                         // bytes per key row
     constexpr int VBYTES = DC_BLOCK * ROWB;         // V image of one block
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     constexpr int NG = D == 256 ? 2 : 1;            // scale groups per row (head_dim 256: two groups of 128 dims)
     constexpr int CG = NC / NG;                     // column blocks per scale group
     constexpr int RING = NW * DC_STAGES * STAGE;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0)];   // + each wave's rotated key row
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0)];   // + each wave's rotated key row (+ its absmax)
 
     const AttnArgs& a = p.a;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     const int Hkv = (int)a.Hkv, Hq = (int)a.Hq, gq = p.gq;
     const int split = MERGE ? w : (int)blockIdx.y;
     const int nsplit = MERGE ? NW : p.nsplit;
-    const int item = MERGE ? (int)blockIdx.x : (int)blockIdx.x * NW + w;
+    const int item = MERGE ? (int)blockIdx.x : (int)blockIdx.x * NW + w;   // QOUT: NW = Hkv, a workgroup is a sequence
     if (item >= p.n_items) return;                  // wave-uniform (MERGE: never taken, every wave reaches the barrier)
     const int kvh = item % Hkv, b = item / Hkv;
     const int h0 = kvh * gq;
@@ -591,6 +595,45 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         }
         return;
     }
+    if constexpr (QOUT) {
+        const size_t orow = (size_t)b * Hq + h0 + min(hd, gq - 1);
+        const bool live = hd < gq && l_part > 0.0f;     // :460-479
+        const float inv = 1.0f / l_part;
+        uint16_t hv[NC][8];
+        float m = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const uint16_t v = live ? f2h_mul(oacc[c][e][j], inv) : (uint16_t)0;
+                    hv[c][2 * j + e] = v;
+                    m = fmaxf(m, fabsf(h2f(v)));
+                }
+        m = wave_max(m);
+        float* smax = reinterpret_cast<float*>(lds + RING + (FUSED ? NW * D * 2 : 0));
+        if (lane == 0) smax[w] = m;
+        __syncthreads();
+        float rm = smax[0];
+#pragma unroll
+        for (int i = 1; i < NW; i++) rm = fmaxf(rm, smax[i]);
+        float qscale = rm / 127.0f;
+        if (qscale < 1e-10f) qscale = 1e-10f;
+        if (threadIdx.x == 0) p.f.q_scales_out[b] = qscale;
+        const float iq = 1.0f / qscale;
+        if (hd < gq) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                v4i packed;
+#pragma unroll
+                for (int j = 0; j < 4; j++) packed[j] = (int)((uint32_t)hv[c][2 * j] | ((uint32_t)hv[c][2 * j + 1] << 16));
+                *reinterpret_cast<v4i*>(a.out + orow * D + 32 * c + 8 * q) = packed;
+                *reinterpret_cast<uint2*>(p.f.q_out + orow * D + 32 * c + 8 * q) = quant8_bits(packed, iq);
+            }
+        }
+        return;
+    }
     if (hd >= gq) return;
     const size_t orow = (size_t)b * Hq + h0 + hd;
     if (p.nsplit == 1) {
@@ -642,6 +685,13 @@ bool attn_decode_mfma_ok(const AttnArgs& a) {
     return true;
 }
 
+// The fused launch can also leave the output rows quantized (AttnFusedIn::q_out) when a workgroup can hold a whole
+// row: 8 kv heads of head_dim 128, one key range per item.  (At head_dim 64 the 8-wave workgroups it needs cost
+// more than the launch they save: LFM2-shape step 1.32 -> 1.35 ms at 128 sequences.)
+bool attn_decode_quant_ok(const AttnArgs& a, int planned_splits) {
+    return planned_splits == 1 && a.Hkv == 8 && a.D == 128 && a.new_len == 1;
+}
+
 // Waves per workgroup when the key ranges of an item are merged inside the workgroup (0: not for this shape).
 // It replaces the merge launch whenever the plan splits at all and an eighth (head_dim 256: a half) of the cache
 // is at most 8 blocks per wave: short caches of few sequences, where a launch costs more than the work.
@@ -661,6 +711,11 @@ hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit
     p.ws = ws;
     if (fused) p.f = *fused;
     if (fused && (a.new_len != 1 || !a.is_causal || ((!a.cache_lens || !a.pos_offsets) && a.B != 1))) return hipErrorInvalidValue;
+    if (fused && fused->q_out) {   // the caller checked attn_decode_quant_ok
+        const dim3 grid((unsigned)a.B);
+        attn_decode_mfma_kernel<128, 8, true, false, true><<<grid, dim3(512), 0, st>>>(p);
+        return hipGetLastError();
+    }
     if (const int mw = attn_decode_merge_waves(a, nsplit)) {
         p.nsplit = mw;
         const dim3 grid((unsigned)p.n_items);

@@ -155,12 +155,16 @@ struct AttnFusedIn {
     int max_position = 0;
     size_t max_slots = 0;      // 0: nothing is appended
     uint16_t* k_out = nullptr; // when given: the normalized, rotated key rows [B, Hkv, D] are also written here
+    int8_t* q_out = nullptr;   // when given (attn_decode_quant_ok): the output rows [B, Hq * D] quantized for the
+    float* q_scales_out = nullptr;   // output projection, and their scales [B]
 };
 hipError_t launch_attention_decode_mfma(const AttnArgs& a, float* ws, int nsplit, hipStream_t st,
                                         const AttnFusedIn* fused = nullptr);
 // nonzero: launch_attention_decode_mfma merges the key ranges inside its workgroups (that many ranges per item)
 // and no merge launch follows; 0: it leaves `planned_splits` records per row in ws for attn_merge_kernel
 int attn_decode_merge_waves(const AttnArgs& a, int planned_splits);
+// true: launch_attention_decode_mfma with fused->q_out set also writes the quantized output rows and their scales
+bool attn_decode_quant_ok(const AttnArgs& a, int planned_splits);
 // the whole fused launch (decode kernel + split merge); a must satisfy attn_decode_mfma_ok with new_len 1 and
 // per-sequence cache_lens / pos_offsets (one sequence: a.cache_len / a.position_offset will do); workspace as
 // attn_workspace_bytes(a)

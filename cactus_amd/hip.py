@@ -58,6 +58,8 @@ SIGNATURES = {
         _i, [_vp] * 8 + [_sz, _sz, _vp, _sz, _sz, _sz, _sz, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_attention_decode_fused_f16_dev": (
         _i, [_vp] * 10 + [_sz, _vp, _vp, _sz, _sz, _sz, _sz, _f, _f, _f, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "cactus_hip_attention_decode_fused_quant_f16_dev": (
+        _i, [_vp] * 12 + [_sz, _vp, _vp, _sz, _sz, _sz, _sz, _f, _f, _f, _sz, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_attention_decode_fused_single_f16_dev": (
         _i, [_vp] * 11 + [_sz, _sz, _sz, _sz, _sz, _f, _f, _f, _sz, _vp]),
     "cactus_hip_matmul_int8": (None, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz]),
@@ -700,13 +702,21 @@ def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, sc
 
 
 def attention_decode_fused(q, k, v, q_weight, k_weight, k_cache, v_cache, k_scales, v_scales, cache_lens, positions,
-                           max_position, eps, theta, scale=0.0, group_size=128, out=None):
+                           max_position, eps, theta, scale=0.0, group_size=128, out=None, out_q=None, out_scales=None):
     """One new token per sequence, from the projections' rows to the attention output in one launch: q [B, Hq, D],
     k / v [B, Hkv, D] fp16; per-head norm + RoPE at positions[b], K / V appended at slot cache_lens[b] of the caches
-    int8 [B, slots, Hkv, D] / fp32 [B, slots, Hkv, G], attention over the cached tokens and the new one."""
+    int8 [B, slots, Hkv, D] / fp32 [B, slots, Hkv, G], attention over the cached tokens and the new one.
+    out_q int8 [B, Hq * D] / out_scales fp32 [B]: the output rows are also left quantized for the output projection."""
     B, Hq, D = q.shape[0], q.shape[-2], q.shape[-1]
     Hkv, slots, G = k.shape[-2], k_cache.shape[1], k_scales.shape[-1]
     out = out if out is not None else torch.empty((B, 1, Hq, D), dtype=torch.float16, device=q.device)
+    if out_q is not None:
+        _check(lib.cactus_hip_attention_decode_fused_quant_f16_dev(
+            _p(q), _p(k), _p(v), _p(q_weight), _p(k_weight), _p(k_cache), _p(v_cache), _p(k_scales), _p(v_scales),
+            _p(out), _p(out_q), _p(out_scales), B, _p(cache_lens), _p(positions), int(max_position), Hq, Hkv, D,
+            float(eps), float(theta), float(scale), group_size, slots * Hkv * D, slots * Hkv * G, slots, slots,
+            _stream()))
+        return out
     _check(lib.cactus_hip_attention_decode_fused_f16_dev(
         _p(q), _p(k), _p(v), _p(q_weight), _p(k_weight), _p(k_cache), _p(v_cache), _p(k_scales), _p(v_scales), _p(out),
         B, _p(cache_lens), _p(positions), int(max_position), Hq, Hkv, D, float(eps), float(theta), float(scale),

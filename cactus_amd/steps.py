@@ -148,6 +148,7 @@ class Qwen3Decode:
         self.logits = _half(b, V)
         self.xq, self.xs, self.xq2, self.xs2 = _i8(b, Hd), _f32(b), _i8(b, Hd), _f32(b)
         self.aq, self.asc = _i8(b, F), _f32(b)
+        self.oq, self.osc = _i8(b, Hq * D), _f32(b)      # attention output rows, quantized for the output projection
         self.small = batch <= 4
         Ls = weights["layers"]
         head = weights["emb"]
@@ -200,10 +201,13 @@ class Qwen3Decode:
             # a full window is about to drop
             # Without a window all of it - norm, RoPE, cache append, attention - is one launch (head_dim 64 / 128 / 256).
             fused_append = kv.window == 0
+            # batches above 4 rows: the attention launch also leaves its rows quantized for the output projection
+            o_quant = fused_append and D == 128 and not self.small   # (head_dim 64: the wider workgroups cost more than the launch)
             if fused_append and D in (64, 128, 256):
                 H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
                                          L["q_norm"], L["k_norm"], kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li],
-                                         kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao)
+                                         kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao,
+                                         out_q=self.oq if o_quant else None, out_scales=self.osc if o_quant else None)
             else:
                 H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta,
                                    kv.positions, self.max_position, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], 0, 0,
@@ -213,7 +217,10 @@ class Qwen3Decode:
             if not fused_append:
                 H.kv_append_windowed(kr4, v4, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], kv.positions, kv.window,
                                      kv.sink)
-            H.matmul_f16act(self.ao.view(b, Hq * D), L["o"][0], L["o"][1], 128, int4=_is4(L["o"]), out=self.oo)
+            if o_quant:
+                (H.matmul_int4 if _is4(L["o"]) else H.matmul_int8)(self.oq, self.osc, L["o"][0], L["o"][1], 128, out=self.oo)
+            else:
+                H.matmul_f16act(self.ao.view(b, Hq * D), L["o"][0], L["o"][1], 128, int4=_is4(L["o"]), out=self.oo)
             nxt = Ls[li + 1]["in_norm"] if li + 1 < NL else self.w["final_norm"]
             if self.small:
                 for mp in self.gu[li]:

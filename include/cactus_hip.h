@@ -484,6 +484,19 @@ int cactus_hip_attention_decode_fused_f16_dev(
     float scale, size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
     size_t max_cache_len, void* stream);
 
+/* The launch above that also leaves the output rows quantized for the output projection, as
+ * cactus_hip_quantize_activations_dev would (graph_ops_nn.cpp:35-66 on the attention node's output, bit for bit):
+ * output_q int8[B, Hq * D] (8-byte aligned), output_scales float[B]; output is written as well.  With 8 kv heads of
+ * head_dim 128 and one key range per sequence a workgroup holds a whole row and no extra launch is made;
+ * other shapes run the row quantization kernel behind the attention. */
+int cactus_hip_attention_decode_fused_quant_f16_dev(
+    const cactus_half_t* q, const cactus_half_t* k, const cactus_half_t* v, const cactus_half_t* q_weight,
+    const cactus_half_t* k_weight, int8_t* k_cache, int8_t* v_cache, float* k_scales, float* v_scales,
+    cactus_half_t* output, int8_t* output_q, float* output_scales, size_t batch_size, const int32_t* cache_lens,
+    const int32_t* positions, size_t max_position, size_t num_q_heads, size_t num_kv_heads, size_t head_dim, float eps,
+    float theta, float scale, size_t group_size, size_t cache_batch_stride, size_t scale_batch_stride, size_t max_slots,
+    size_t max_cache_len, void* stream);
+
 /* The same launch for ONE sequence whose cache length and position the host knows, with nothing appended to the
  * cache: CactusGraph::execute hands it the run rms_norm -> rope (on the q and k projections) ->
  * attention_int8_hybrid of a decode step (model_qwen.cpp:63-99).  The normalized, rotated key rows are also

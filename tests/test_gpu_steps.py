@@ -465,3 +465,41 @@ def test_attention_decode_fused_equals_norm_rope_append_then_attention(ST, B, Hq
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     for a, b_ in ((kc, kc2), (vc, vc2), (ks, ks2), (vs, vs2)):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,slots,lens", [
+    (3, 16, 8, 128, 80, (5, 40, 79)),                 # one key range per item: quantized inside the launch
+    (130, 16, 8, 128, 600, tuple(range(1, 131))),     # Qwen3 heads, more than a thousand items
+    (5, 32, 8, 64, 90, (0, 1, 33, 64, 89)),           # LFM2 heads; a sequence with nothing cached yet
+    (2, 32, 8, 64, 4200, (4100, 33)),                 # key ranges split: the row kernel runs behind the attention
+    (3, 4, 1, 256, 300, (256, 31, 299)),              # one kv head: likewise
+])
+def test_attention_decode_fused_quantized_rows(ST, B, Hq, Hkv, D, slots, lens):
+    """The fused decode attention that also leaves its rows quantized for the output projection == the fused launch
+    followed by the activation quantization: fp16 rows, INT8 rows, scales and appended cache rows bit for bit."""
+    import cactus_amd.hip as H
+    gen = torch.Generator(device="cuda").manual_seed(B + D + 1)
+    half = lambda *sh: ((torch.rand(sh, device="cuda", generator=gen) * 2 - 1) * 3).half()
+    q, k, v = half(B, Hq, D), half(B, Hkv, D), half(B, Hkv, D)
+    qw = (1.0 + 0.1 * torch.randn(D, device="cuda", generator=gen)).half()
+    kw = (1.0 + 0.1 * torch.randn(D, device="cuda", generator=gen)).half()
+    kc = torch.randint(-127, 128, (B, slots, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    vc = torch.randint(-127, 128, (B, slots, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+    ks = torch.rand((B, slots, Hkv, (D + 127) // 128), device="cuda", generator=gen) * 0.02 + 1e-3
+    vs = torch.rand((B, slots, Hkv, (D + 127) // 128), device="cuda", generator=gen) * 0.02 + 1e-3
+    cl = torch.tensor(lens[:B], dtype=torch.int32, device="cuda")
+    pos = cl + 2
+    eps, theta, maxpos = 1e-6, 1e6, slots + 8
+    kc2, vc2, ks2, vs2 = (t.clone() for t in (kc, vc, ks, vs))
+    want = H.attention_decode_fused(q, k, v, qw, kw, kc, vc, ks, vs, cl, pos, maxpos, eps, theta)
+    want_q, want_s = H.quantize_activations(want.view(B, Hq * D))
+    got_q = torch.full((B, Hq * D), 77, dtype=torch.int8, device="cuda")
+    got_s = torch.full((B,), -1.0, dtype=torch.float32, device="cuda")
+    got = H.attention_decode_fused(q, k, v, qw, kw, kc2, vc2, ks2, vs2, cl, pos, maxpos, eps, theta,
+                                   out_q=got_q, out_scales=got_s)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(got_s.view(torch.int32), want_s.view(torch.int32))
+    assert torch.equal(got_q, want_q)
+    for a, b_ in ((kc, kc2), (vc, vc2), (ks, ks2), (vs, vs2)):
+        assert torch.equal(a, b_)
