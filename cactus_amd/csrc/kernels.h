@@ -83,6 +83,8 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
                                         size_t M, size_t K, size_t N, hipStream_t st);
 
 // matmul_gemm.hip: any M, group_size == 128, MFMA tiles staged through LDS.
+bool launch_matmul_f16_tiles(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K, size_t N,
+                             hipStream_t st, hipError_t* err);
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,
                               const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                               size_t K, size_t N, hipStream_t st);

@@ -100,6 +100,9 @@ hipError_t launch_transpose_f16(const uint16_t* src, uint16_t* dst, size_t R, si
 
 hipError_t launch_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K,
                              size_t N, hipStream_t st) {
+    // the pipelined tile kernel (matmul_gemm.hip) when the rows are whole 128-byte groups; else the plain kernel below
+    hipError_t te = hipSuccess;
+    if (launch_matmul_f16_tiles(a, bT, c, M, K, N, st, &te)) return te;
     const int vec_ok = (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
                        ((reinterpret_cast<uintptr_t>(bT) & 15) == 0);
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), block(256);

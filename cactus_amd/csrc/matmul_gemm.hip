@@ -283,7 +283,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // NJ: 16-column MFMA tiles per compute wave along n (2: 128-column workgroup tile; 1: 64 columns, for launches of
 // few rows whose 128-column tiles would leave most CUs without a workgroup -- the weight stream of a small batch is
 // bound by how many CUs pull on it).
-template <bool INT4, int NI, int NJ>
+// F16: both operands are binary16 (cactus_matmul_f16, kernel_gemm.cpp:17-126, with fp32 accumulation on the matrix
+// cores): a 128-byte tile row is 64 halves, the ring, the swizzle and the fragment chunks are the INT8 kernel's, K and
+// the pointers are in bytes, there are no scales, and the loop is MFMAs (v_mfma_f32_16x16x32_f16) and reads only.
+template <bool INT4, int NI, int NJ, bool F16 = false>
 __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales, const uint8_t* __restrict__ B_arg,
     const uint16_t* __restrict__ B_scales_arg, uint16_t* __restrict__ C_arg, int M, int K, int N_arg, int G, int nbm,
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         if (G > 1) issue_tile(1);
         if (G > 2) issue_tile(2);
         if (G > 3) issue_tile(3);
-        stage_scales();
+        if constexpr (!F16) stage_scales();
         wait_later(min(3, G - 1));
         barrier();
         int kt = 0;
@@ -539,6 +542,59 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
     constexpr int NT = NJ * NI;                      // MFMAs per slab
     constexpr int RPS = (NJ + NI + NT - 1) / NT;     // fragment reads issued behind each MFMA
 
+    if constexpr (F16) {
+        v4f facc[NI][NJ];
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) facc[i][j] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+        barrier();   // tile 0 visible
+#pragma unroll
+        for (int x = 0; x < NJ + NI; x++) read_one(g2_lds, 0, x, f0a, f0b);
+        for (int kt = 0; kt < G; kt++) {
+            const uint8_t* st = g2_lds + (kt % G2_STAGES) * G2_STAGE;
+            const uint8_t* stn = g2_lds + ((kt + 1) % G2_STAGES) * G2_STAGE;   // past the last tile: a finished stage, values unused
+            fence();
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                const int i = x / NJ, j = x % NJ;
+                facc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f0a[i]), __builtin_bit_cast(v8h, f0b[j]),
+                                                                    facc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int y = 0; y < RPS; y++) read_one(st, 1, x * RPS + y, f1a, f1b);
+            }
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPS, 0);
+            }
+            fence();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are complete
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            fence();
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                const int i = x / NJ, j = x % NJ;
+                facc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, f1a[i]), __builtin_bit_cast(v8h, f1b[j]),
+                                                                    facc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int y = 0; y < RPS; y++) read_one(stn, 0, x * RPS + y, f0a, f0b);
+            }
+#pragma unroll
+            for (int x = 0; x < NT; x++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RPS, 0);
+            }
+            fence();
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) run[i][j][e] = facc[i][j][e];
+    } else {
     stage_scales();
     barrier();   // scale panel and tile 0 visible
 #pragma unroll
@@ -638,8 +694,9 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
         for (int j = 0; j < NJ; j++)
 #pragma unroll
             for (int e = 0; e < 4; e++) run[i][j][e] = __builtin_fmaf((float)acc[i][j][e], sprev[j], run[i][j][e]);
+    }
 
-    // Output: half(running * A_scale[m]), through LDS so that it leaves as 16-byte row segments.
+    // Output: half(running * A_scale[m]) (F16: half(sum)), through LDS so that it leaves as 16-byte row segments.
     if (vec_store) {
         constexpr int CS = BN + 8;
         uint16_t* ct = reinterpret_cast<uint16_t*>(g2_lds);
@@ -649,7 +706,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int lm = wm * (16 * NI) + i * 16 + q * 4 + e;
-                const float as = A_scales[min(m0 + lm, M - 1)];
+                const float as = F16 ? 1.0f : A_scales[min(m0 + lm, M - 1)];
 #pragma unroll
                 for (int j = 0; j < NJ; j++) ct[lm * CS + wn * (16 * NJ) + j * 16 + r] = f2h_mul(run[i][j][e], as);
             }
@@ -669,7 +726,7 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
             for (int e = 0; e < 4; e++) {
                 const int m = m0 + wm * (16 * NI) + i * 16 + q * 4 + e;
                 if (m >= M) continue;
-                const float as = A_scales[m];
+                const float as = F16 ? 1.0f : A_scales[m];
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
                     const int n = n0 + wn * (16 * NJ) + j * 16 + r;
@@ -680,13 +737,13 @@ __global__ __launch_bounds__(G3_THREADS) void gemm3_kernel(
 }
 
 // more than 64 KB of dynamic LDS has to be allowed once per device
-template <bool INT4, int NI, int NJ>
+template <bool INT4, int NI, int NJ, bool F16 = false>
 static hipError_t gemm3_allow_lds() {
     static bool attr_set[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<INT4, NI, NJ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<INT4, NI, NJ, F16>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
@@ -694,14 +751,14 @@ static hipError_t gemm3_allow_lds() {
     return hipSuccess;
 }
 
-template <bool INT4, int NI, int NJ>
+template <bool INT4, int NI, int NJ, bool F16 = false>
 static hipError_t launch_gemm3(const int8_t* A, const float* A_scales, const uint8_t* B, const uint16_t* B_scales,
                                uint16_t* C, int M, int K, int N, int G, int nwg, const GemmBatch& bt, hipStream_t st) {
-    hipError_t e = gemm3_allow_lds<INT4, NI, NJ>();
+    hipError_t e = gemm3_allow_lds<INT4, NI, NJ, F16>();
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (size_t)G * (64 * NJ) * sizeof(uint16_t);
+    const size_t lds = (size_t)G2_STAGES * G2_STAGE + (F16 ? 0 : (size_t)G * (64 * NJ) * sizeof(uint16_t));
     const int nbm = (M + 32 * NI - 1) / (32 * NI);
-    gemm3_kernel<INT4, NI, NJ><<<dim3((unsigned)nwg), dim3(G3_THREADS), lds, st>>>(A, A_scales, B, B_scales, C, M, K, N,
+    gemm3_kernel<INT4, NI, NJ, F16><<<dim3((unsigned)nwg), dim3(G3_THREADS), lds, st>>>(A, A_scales, B, B_scales, C, M, K, N,
                                                                                   G, nbm, nwg, bt);
     return hipGetLastError();
 }
@@ -785,6 +842,28 @@ hipError_t launch_matmul_gemm_batch(bool int4, const int8_t* A, const float* A_s
     }
     return int4 ? launch_gemm3_any<true>(A, A_scales, nullptr, nullptr, nullptr, M, K, 0, G, tl, nbn, bt, st)
                 : launch_gemm3_any<false>(A, A_scales, nullptr, nullptr, nullptr, M, K, 0, G, tl, nbn, bt, st);
+}
+
+// FP16 x FP16^T through the tile kernel: K a multiple of 64 halves, 16-byte aligned operands; false: not this shape
+bool launch_matmul_f16_tiles(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K, size_t N,
+                             hipStream_t st, hipError_t* err) {
+    if (K == 0 || K % 64 != 0 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bT)) & 15) != 0 ||
+        K >= (size_t(1) << 29) || N >= (size_t(1) << 30) || M >= (size_t(1) << 30))
+        return false;
+    const GemmTile tl = gemm3_tile(M, &N, 1);
+    const size_t nbn = (N + tl.cols - 1) / tl.cols, nwg = ((M + tl.rows - 1) / tl.rows) * nbn;
+    if (nwg == 0 || nwg >= (size_t(1) << 30)) return false;
+    GemmBatch none;
+    memset(&none, 0, sizeof none);
+    const int8_t* A = reinterpret_cast<const int8_t*>(a);
+    const uint8_t* B = reinterpret_cast<const uint8_t*>(bT);
+    const int m = (int)M, kb = (int)(2 * K), n = (int)N, G = (int)(2 * K / 128), g = (int)nwg;
+    if (tl.rows == 32 && tl.cols == 64) *err = launch_gemm3<false, 1, 1, true>(A, nullptr, B, nullptr, c, m, kb, n, G, g, none, st);
+    else if (tl.rows == 32) *err = launch_gemm3<false, 1, 2, true>(A, nullptr, B, nullptr, c, m, kb, n, G, g, none, st);
+    else if (tl.rows == 64 && tl.cols == 64) *err = launch_gemm3<false, 2, 1, true>(A, nullptr, B, nullptr, c, m, kb, n, G, g, none, st);
+    else if (tl.rows == 64) *err = launch_gemm3<false, 2, 2, true>(A, nullptr, B, nullptr, c, m, kb, n, G, g, none, st);
+    else *err = launch_gemm3<false, 4, 2, true>(A, nullptr, B, nullptr, c, m, kb, n, G, g, none, st);
+    return true;
 }
 
 hipError_t launch_matmul_gemm(bool int4, const int8_t* A, const float* A_scales, const void* B,

@@ -513,7 +513,8 @@ def test_matmul_weights_of_two_gib_take_the_tile_kernel(H):
 
 
 # ------------------------------------------------------------------ FP16 matmul
-@pytest.mark.parametrize("M,K,N", [(1, 1024, 64), (4, 100, 33), (70, 256, 130), (2, 3, 2), (256, 1024, 256)])
+@pytest.mark.parametrize("M,K,N", [(1, 1024, 64), (4, 100, 33), (70, 256, 130), (2, 3, 2), (256, 1024, 256),
+                                   (40, 128, 300), (300, 64, 520), (130, 192, 1000), (17, 2048, 1200), (64, 320, 2050)])
 def test_matmul_f16_tolerance(H, M, K, N):
     """fp32-accumulating MFMA vs the reference's fp16-lane accumulation: both are compared with
     the fp64 product; the GPU error must not exceed the reference's own error (+1 fp16 ulp)."""
@@ -525,6 +526,22 @@ def test_matmul_f16_tolerance(H, M, K, N):
     ref_err = np.abs(f16(O.matmul_f16(a, b)) - exact).max()
     ulp = np.abs(exact).max() * 2.0 ** -10
     assert np.abs(got - exact).max() <= max(ref_err, 0.0) + ulp
+
+
+@pytest.mark.parametrize("M,K,N", [(512, 4096, 4096), (1, 4096, 12288), (33, 8192, 520), (1000, 1024, 777),
+                                   (128, 2048, 151936 // 8), (70, 4160, 136), (5, 72, 19)])
+def test_matmul_f16_close_to_fp32_product(H, M, K, N):
+    """Larger shapes than the CPU restatement finishes quickly, every tile of the pipelined kernel and the plain kernel
+    (K not a multiple of 64): within one fp16 ulp of the fp32 product rounded to fp16 (tolerance: 2^-10 relative to the
+    exact value plus the fp32 accumulation error K * 2^-24 * sum |a||b| bound, taken here as 2^-10 of the row's
+    absolute product sum)."""
+    gen = torch.Generator(device="cuda").manual_seed(M + K + N)
+    a = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
+    b = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).half()
+    got = H.matmul_f16(a, b).double()
+    exact = a.double() @ b.double().T
+    bound = exact.abs() * 2.0 ** -10 + (a.double().abs() @ b.double().abs().T) * (K * 2.0 ** -24) + 2.0 ** -24
+    assert bool(((got - exact).abs() <= bound).all())
 
 
 def test_matmul_f16_reference_kat(H):
