@@ -55,6 +55,11 @@ __device__ __forceinline__ float pf_weight(float s, float bmax, bool poly) {
 #ifndef PF_WAVES_PER_EU
 #define PF_WAVES_PER_EU 2
 #endif
+// Timing experiments only (wrong results): 1 no staging and no barriers, 2 no weight polynomial, 4 no P.V MFMAs,
+// 8 no score MFMAs, 16 no low-part MFMAs, 32 no rescale of the running output
+#ifndef PF_TIMING
+#define PF_TIMING 0
+#endif
 // head_dim 256: the Q rows and the output accumulators of a lane alone are 192 registers, so that variant runs one
 // wave per SIMD with the whole register file
 template <int D>
@@ -148,10 +153,12 @@ void attn_prefill_kernel(const AttnArgs a) {
 
     if (nblk > 0) fetch(0);
     for (int blk = 0; blk < nblk; blk++) {
+        if (!(PF_TIMING & 1)) {
         __syncthreads();                 // the previous block's fragments have been read
         stash();
         __syncthreads();                 // this block is in LDS
         if (blk + 1 < nblk) fetch(blk + 1);
+        }
 
         const int kb = blk * PF_BLOCK;
         if (kb >= kv_end_wave) continue;   // wave-uniform: nothing this wave's queries can see
@@ -169,7 +176,8 @@ void attn_prefill_kernel(const AttnArgs a) {
 #pragma unroll
             for (int st = 0; st < NST; st++) {
                 const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+                if (!(PF_TIMING & 8)) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+                else sacc[st] += (float)kf[0];
             }
 
             // This lane's 16 keys: in-block index ib = 8*(r/4) + 4*g + r%4.  A key is visible when
@@ -200,6 +208,7 @@ void attn_prefill_kernel(const AttnArgs a) {
                 l_run *= corr;
                 typedef float v2f __attribute__((ext_vector_type(2)));
                 const v2f c2 = {corr, corr};
+                if (!(PF_TIMING & 32))
 #pragma unroll
                 for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
@@ -222,6 +231,7 @@ void attn_prefill_kernel(const AttnArgs a) {
                 float y = fmaf(xf, 0.6931472f, 1.0f);
                 y = fmaf(xf * xf, 0.2402265f, y);
                 float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
+                if (PF_TIMING & 2) wv = sc[r];
                 if constexpr (!FULL) {
                     if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(sc[r] - bm);
                     wv = (sc[r] == -INFINITY) ? 0.0f : wv;
@@ -253,8 +263,9 @@ void attn_prefill_kernel(const AttnArgs a) {
                     const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
                     const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
                     const v8hf vf = __builtin_bit_cast(v8hf, packed);
+                    if (PF_TIMING & 4) { o[dt][ks] += (float)vf[0] * (float)phi[ks][dt] + (float)plo[ks][dt]; continue; }
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
+                    if (!(PF_TIMING & 16)) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
                 }
             }
         };
@@ -278,6 +289,349 @@ void attn_prefill_kernel(const AttnArgs a) {
             }
             *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * r4 + 4 * g) = make_uint2(lo, hi);
         }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same arithmetic for head_dim 64 and 128, arranged so that the matrix cores and the vector ALU of a SIMD work at
+// the same time.  A 512-thread workgroup = 128 queries x two GROUPS of four waves; a group takes one half of the
+// tile's key blocks and keeps its own (m, l, O^T) state and its own K/V block in LDS.  Waves w and w + 4 - the same
+// 32 queries in the two groups - share a SIMD, and the groups run half a period apart:
+//     group 0:  M(0) | V(0) | M(1) | V(1) | ...          M(i): P(i-1).V(i-1) and K(i).Q^T on the matrix cores
+//     group 1:       | M(0) | V(0) | M(1) | ...          V(i): softmax of block i on the vector ALU
+// with a workgroup barrier at every '|', so one wave of each SIMD is in its MFMA phase while the other is in its VALU
+// phase (left to themselves two waves of a SIMD drift into the SAME phase and each unit idles half of the time).
+// The barriers are also what orders the staging: block i+1 of K and block i of V are loaded into registers at the
+// start of M(i) and written to LDS at the start of V(i), after every wave of the group has finished M(i) (the
+// registers are free during the softmax, where the kernel needs the most).
+// V rows stay row-major in LDS; the V^T operand is read with the transposing ds_read_b64_tr_b16.
+// The two partial states of a query combine exactly as the reference's chain of rescales does across the cut:
+// O = O0 * exp(m0 - m1) + O1 with m0, m1 the block maxima at which the halves ended (:160-169).
+// Lanes l and l ^ 32 combine a value without a trip through LDS: v_permlane32_swap exchanges the upper 32 lanes of its
+// first operand with the lower 32 of its second, so from two copies of x one result holds the lower half's values in
+// every lane and the other the upper half's.
+__device__ __forceinline__ float halves_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Benchmarks only (-DPF_TRACE): per-phase shader-clock totals of the waves of workgroups 0 and 1.
+#ifdef PF_TRACE
+__device__ unsigned long long g_pf_trace[16 * 8];
+#define PF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define PF_T(var)
+#endif
+
+template <int D>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void attn_prefill_pp_kernel(const AttnArgs a) {
+    constexpr int KROW = D + 8;      // halves per K row: banks shift by 4 per row, the 16-byte row reads are conflict-free
+    constexpr int VROW = D + 32;     // halves per V row: banks shift by 16 per row, the 4-row transposed reads are conflict-free
+    constexpr int NDT = D / 32, NST = D / 16;
+    constexpr int PPT = (PF_BLOCK * D / 8) / 256;            // 16-byte pieces per thread of a group per operand
+    constexpr int GRP_BYTES = PF_BLOCK * (KROW + VROW) * 2;  // one group's K and V block
+    constexpr int NVAL = NDT * 16 + 2;                        // merged values per lane: O^T, m, l
+    extern __shared__ __attribute__((aligned(16))) uint8_t pp_lds[];
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lds_v4s;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w >> 2, wq = w & 3, gtid = tid & 255;
+    const int jq = lane & 31, g = lane >> 5;
+    const int S = (int)a.S, KV = (int)a.new_len, Hq = (int)a.Hq, Hkv = (int)a.Hkv;
+    // Heaviest tiles first (one workgroup fills a CU; the dispatcher hands the next one to whichever CU finishes).
+    // Workgroup ids go round the 8 XCDs: when the heads divide by 8 each XCD keeps its own heads, so a kv head's
+    // rows stay in one L2.
+    const int nt = (S + PF_QTILE - 1) / PF_QTILE, hb = Hq * (int)a.B;
+    const int id = (int)blockIdx.x;
+    int qt, hbi;
+    if (hb % 8 == 0) {
+        const int hpc = hb / 8, x = id & 7, y = id >> 3;
+        qt = nt - 1 - y / hpc;
+        hbi = x * hpc + y % hpc;
+    } else {
+        qt = nt - 1 - id / hb;
+        hbi = id % hb;
+    }
+    const int h = hbi % Hq, b = hbi / Hq;
+    const int kvh = h / (Hq / Hkv);
+    const int q_first = qt * PF_QTILE + wq * 32;
+    const int qi = q_first + jq;
+    const bool q_live = qi < S;
+    const long long off = (long long)a.position_offset;
+    const long long qabs = off + qi;
+    float scale = a.scale;
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);
+
+    const int q_last_wg = min(S, (qt + 1) * PF_QTILE) - 1, q_last_wave = min(S - 1, q_first + 31);
+    const int kv_end_wg = a.is_causal ? (int)min((long long)KV, off + q_last_wg + 1) : KV;
+    const int kv_end_wave = a.is_causal ? (int)min((long long)KV, off + q_last_wave + 1) : KV;
+    const int nblk = (kv_end_wg + PF_BLOCK - 1) / PF_BLOCK;
+    const int nb0 = (nblk + 1) / 2;                    // group 0: blocks [0, nb0), group 1: [nb0, nblk)
+    const int iters = nb0;
+    const int blk0 = grp ? nb0 : 0, blk_end = grp ? nblk : nb0;
+
+    uint16_t* sK = reinterpret_cast<uint16_t*>(pp_lds + grp * GRP_BYTES);
+    uint16_t* sV = sK + PF_BLOCK * KROW;
+    float* mrg = reinterpret_cast<float*>(pp_lds + 2 * GRP_BYTES);
+
+    v8hf qf[NST];
+    {
+        const uint16_t* qrow = a.q + (((size_t)b * S + min(qi, S - 1)) * Hq + h) * D;
+#pragma unroll
+        for (int st = 0; st < NST; st++) qf[st] = *reinterpret_cast<const v8hf*>(qrow + st * 16 + g * 8);
+    }
+    const uint16_t* Kb = a.k_new + (size_t)b * KV * Hkv * D + (size_t)kvh * D;
+    const uint16_t* Vb = a.v_new + (size_t)b * KV * Hkv * D + (size_t)kvh * D;
+    const size_t kv_stride = (size_t)Hkv * D;
+
+    // staging by the group's 256 threads: piece = (key, 8 halves); a block index past the group's range reads a clamped row
+    // (a whole block inside the rows: a wave-uniform base and the thread's constant 32-bit offsets, no address arithmetic)
+    v4i kst[PPT], vst[PPT];
+    unsigned piece_off[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; p++) {
+        const int idx = p * 256 + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
+        piece_off[p] = (unsigned)(key * (int)kv_stride + d8 * 8) * 2u;
+    }
+    auto fetch_rows = [&](const uint16_t* base, int blk, v4i (&r)[PPT]) {
+        if ((blk + 1) * PF_BLOCK <= KV) {
+            const uint8_t* bp = reinterpret_cast<const uint8_t*>(base + (size_t)blk * PF_BLOCK * kv_stride);
+#pragma unroll
+            for (int p = 0; p < PPT; p++) r[p] = *reinterpret_cast<const v4i*>(bp + piece_off[p]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PPT; p++) {
+                const int idx = p * 256 + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
+                const int kp = max(0, min(blk * PF_BLOCK + key, KV - 1));
+                r[p] = *reinterpret_cast<const v4i*>(base + (size_t)kp * kv_stride + d8 * 8);
+            }
+        }
+    };
+    auto stash_rows = [&](uint16_t* dst, int row_halves, const v4i (&r)[PPT]) {
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            const int idx = p * 256 + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
+            *reinterpret_cast<v4i*>(dst + key * row_halves + d8 * 8) = r[p];
+        }
+    };
+    auto barrier = [&]() {   // LDS writes of this wave are complete; loads into registers stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    // transposed V reads: lane (16-lane group gi, q = row of the 4-key block, p = 4-column piece) supplies the
+    // address of key 4g + q, halves 16*(gi & 1) + 4p ..+3 and receives d = 16*(gi & 1) + lane % 16 of 4 keys
+    const int gi = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+    const uint16_t* vtr = sV + (4 * g + tq) * VROW + 16 * (gi & 1) + 4 * tp;
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    v16f o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
+    v8hf phi[2], plo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) { phi[ks][e] = (_Float16)0.0f; plo[ks][e] = (_Float16)0.0f; }
+    v16f sacc;
+    bool pv_pending = false;
+
+    auto scores = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < NST; st++) {
+            const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
+            if (PF_TIMING & 8) { sacc[st] += (float)kf[0]; continue; }
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+        }
+    };
+    auto weighted_values = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(vtr + (16 * ks) * VROW + 32 * dt));
+                const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(vtr + (16 * ks + 8) * VROW + 32 * dt));
+                typedef short v8s __attribute__((ext_vector_type(8)));
+                const v8s both = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const v8hf vf = __builtin_bit_cast(v8hf, both);
+                if (PF_TIMING & 4) { o[dt][ks] += (float)vf[0]; continue; }
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
+                if (!(PF_TIMING & 16)) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
+            }
+        }
+    };
+    // softmax of one block from sacc (kernel_attention.cpp:160-204): updates m_run, l_run, rescales O, leaves the
+    // weights as hi + lo binary16 parts.  FULL: all 32 keys visible to all 32 queries of the wave.
+    auto softmax = [&](auto full_tag, int kb, int ke) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int vec = ((ke - kb) / 4) * 4;
+        const int lim_blk = ke - kb;
+        const int lim = a.is_causal ? (int)max(-1LL, min((long long)lim_blk, qabs - kb + 1)) : lim_blk;
+        const int limg = lim - 4 * g;
+        float sc[16], wgt[16];
+        float bm = -INFINITY, bsum = 0.0f;
+        if constexpr (FULL) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[r] = sacc[r] * scale;
+                bm = fmaxf(bm, sc[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                sc[r] = (8 * (r >> 2) + (r & 3) < limg) ? sacc[r] * scale : -INFINITY;
+                bm = fmaxf(bm, sc[r]);
+            }
+        }
+        bm = halves_max(bm);
+        if (FULL || bm > -INFINITY) {
+            const float corr = __expf(m_run - bm);
+            l_run *= corr;
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[dt][r] *= corr;
+            m_run = bm;
+        }
+        const int vecg = vec - 4 * g;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float x = (sc[r] - bm) * 1.442695f;
+            const int xi = (int)x;
+            const float xf = x - (float)xi;
+            float y = fmaf(xf, 0.6931472f, 1.0f);
+            y = fmaf(xf * xf, 0.2402265f, y);
+            float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
+            if constexpr (!FULL) {
+                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(sc[r] - bm);
+                wv = (sc[r] == -INFINITY) ? 0.0f : wv;
+            }
+            wgt[r] = wv;
+            bsum += wv;
+        }
+        bsum = halves_sum(bsum);
+        l_run += bsum;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float wv = wgt[8 * ks + e];
+                const _Float16 hi = (_Float16)wv;
+                phi[ks][e] = hi;
+                plo[ks][e] = (_Float16)(wv - (float)hi);
+            }
+    };
+
+    // prologue: K of the group's first block into LDS
+    fetch_rows(Kb, blk0, kst);
+    stash_rows(sK, KROW, kst);
+    barrier();
+    if (grp == 1) barrier();            // group 1 runs half a period behind
+#ifdef PF_TRACE
+    unsigned long long tr[5] = {0, 0, 0, 0, 0};
+    const unsigned long long tr_c0 = clock64(), tr_r0 = wall_clock64();
+#endif
+    for (int it = 0; it < iters; it++) {
+        const int blk = blk0 + it, kb = blk * PF_BLOCK;
+        const bool live = blk < blk_end && kb < kv_end_wave;   // wave-uniform: this wave's queries see the block
+        // ---- MFMA phase
+        PF_T(t0);
+        fetch_rows(Kb, blk + 1, kst);    // written to LDS at the start of this iteration's VALU phase
+        fetch_rows(Vb, blk, vst);
+        if (pv_pending) weighted_values();
+        if (live) scores();
+#ifdef PF_TRACE
+        asm volatile("s_nop 0" :: "v"(sacc[0]), "v"(o[0][0]));
+#endif
+        PF_T(t1);
+        barrier();
+        PF_T(t2);
+        // ---- VALU phase
+        stash_rows(sK, KROW, kst);       // K of block it + 1
+        stash_rows(sV, VROW, vst);       // V of block it
+        PF_T(t3);
+        if (live) {
+            const int ke = min(KV, kb + PF_BLOCK);
+            if (ke - kb == PF_BLOCK && (!a.is_causal || off + q_first - kb + 1 >= PF_BLOCK) && q_first + 31 < S)
+                softmax(std::true_type{}, kb, ke);
+            else
+                softmax(std::false_type{}, kb, ke);
+        }
+        pv_pending = live;
+#ifdef PF_TRACE
+        asm volatile("s_nop 0" :: "v"(phi[0][0]), "v"(plo[1][7]), "v"(o[0][0]));
+#endif
+        PF_T(t4);
+        if (!(grp == 1 && it == iters - 1)) barrier();
+#ifdef PF_TRACE
+        const unsigned long long t5 = __builtin_readcyclecounter();
+        tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4;
+#endif
+    }
+#ifdef PF_TRACE
+    if (lane == 0 && blockIdx.x < 2) {
+        const int slot = blockIdx.x * 8 + w;
+        g_pf_trace[slot * 8 + 0] = clock64() - tr_c0;
+        g_pf_trace[slot * 8 + 1] = wall_clock64() - tr_r0;
+        for (int i = 0; i < 5; i++) g_pf_trace[slot * 8 + 2 + i] = tr[i];
+        g_pf_trace[slot * 8 + 7] = iters;
+    }
+#endif
+    if (grp == 0) {
+        if (pv_pending) weighted_values();
+        barrier();
+        barrier();                       // group 1's state is in LDS
+        const float m1 = mrg[((NVAL - 2) * 4 + wq) * 64 + lane], l1 = mrg[((NVAL - 1) * 4 + wq) * 64 + lane];
+        if (m1 > -INFINITY) {            // the second half saw a key of this query: the chain of rescales went on
+            const float f = __expf(m_run - m1);
+            l_run = l_run * f + l1;
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[dt][r] = o[dt][r] * f + mrg[((dt * 16 + r) * 4 + wq) * 64 + lane];
+        }
+    } else {
+        barrier();                       // V of the last block is visible to the group
+        if (pv_pending) weighted_values();
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) mrg[((dt * 16 + r) * 4 + wq) * 64 + lane] = o[dt][r];
+        mrg[((NVAL - 2) * 4 + wq) * 64 + lane] = m_run;
+        mrg[((NVAL - 1) * 4 + wq) * 64 + lane] = l_run;
+        barrier();
+        return;
+    }
+
+    if (!q_live) return;
+    uint16_t* orow = a.out + (((size_t)b * S + qi) * Hq + h) * D;
+    const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            uint32_t lo = 0, hi = 0;
+            if (l_run > 0.0f) {
+                lo = (uint32_t)f2h_mul(o[dt][4 * r4], inv) | ((uint32_t)f2h_mul(o[dt][4 * r4 + 1], inv) << 16);
+                hi = (uint32_t)f2h_mul(o[dt][4 * r4 + 2], inv) | ((uint32_t)f2h_mul(o[dt][4 * r4 + 3], inv) << 16);
+            }
+            *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * r4 + 4 * g) = make_uint2(lo, hi);
+        }
+}
+
+template <int D>
+constexpr size_t attn_prefill_pp_lds() {
+    return 2 * (size_t)PF_BLOCK * (D + 8 + D + 32) * 2 + (size_t)(D / 32 * 16 + 2) * 256 * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -569,6 +923,12 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
 
 }  // namespace
 
+#ifdef PF_TRACE
+extern "C" int cactus_hip_debug_pf_trace(unsigned long long* out128) {
+    return (int)hipMemcpyFromSymbol(out128, HIP_SYMBOL(g_pf_trace), sizeof(unsigned long long) * 128);
+}
+#endif
+
 bool attn_prefill_hybrid_ok(const AttnArgs& a) {
     return !a.f16_mode && a.S >= 32 && (((a.D == 64 || a.D == 128) && a.qgs >= a.D) || (a.D == 256 && a.qgs == 128)) &&
            a.Hkv > 0 && a.Hq % a.Hkv == 0 &&
@@ -632,9 +992,27 @@ hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st) {
     const size_t total = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B;
     if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)total), block(256);
-    if (a.D == 256) attn_prefill_kernel<256><<<grid, block, 0, st>>>(a);
-    else if (a.D == 128) attn_prefill_kernel<128><<<grid, block, 0, st>>>(a);
-    else attn_prefill_kernel<64><<<grid, block, 0, st>>>(a);
+    if (a.D == 256) {
+        attn_prefill_kernel<256><<<grid, block, 0, st>>>(a);
+    } else {
+        // more dynamic LDS than the default limit: allowed once per device
+        static bool allowed[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!allowed[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefill_pp_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_prefill_pp_lds<128>());
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefill_pp_kernel<64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_prefill_pp_lds<64>());
+            if (e != hipSuccess) return e;
+            allowed[dev] = true;
+        }
+        if (a.D == 128) attn_prefill_pp_kernel<128><<<grid, dim3(512), attn_prefill_pp_lds<128>(), st>>>(a);
+        else attn_prefill_pp_kernel<64><<<grid, dim3(512), attn_prefill_pp_lds<64>(), st>>>(a);
+    }
     return hipGetLastError();
 }
 

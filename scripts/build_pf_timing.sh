@@ -1,0 +1,15 @@
+#!/bin/bash
+# Timing-experiment variants of the prefill attention (wrong results by design):
+#   scripts/build_pf_timing.sh name "-DPF_TIMING=2" (bits: cactus_amd/csrc/attention_prefill.hip) [name2 "flags2" ...]
+# -> scripts/variants/libcactus_hip_<name>.so
+set -e
+cd "$(dirname "$0")/.."
+python cactus_amd/build.py > /dev/null
+mkdir -p scripts/variants
+objs=$(ls cactus_amd/build/*.hip.o cactus_amd/build/graph.cpp.o | grep -v attention_prefill | grep -v gemv_bench)
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -c cactus_amd/csrc/attention_prefill.hip -o scripts/variants/pf_$name.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/variants/libcactus_hip_$name.so $objs scripts/variants/pf_$name.o
+  echo built $name
+done
