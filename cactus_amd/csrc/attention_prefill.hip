@@ -52,6 +52,20 @@ __device__ __forceinline__ float pf_weight(float s, float bmax, bool poly) {
     return y * __uint_as_float(e);
 }
 
+// Lanes l and l ^ 32 combine a value without a trip through LDS: v_permlane32_swap exchanges the upper 32 lanes of its
+// first operand with the lower 32 of its second, so from two copies of x one result holds the lower half's values in
+// every lane and the other the upper half's.
+__device__ __forceinline__ float halves_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 #ifndef PF_WAVES_PER_EU
 #define PF_WAVES_PER_EU 2
 #endif
@@ -202,7 +216,7 @@ void attn_prefill_kernel(const AttnArgs a) {
                     bm = fmaxf(bm, sc[r]);
                 }
             }
-            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            bm = halves_max(bm);
             if (FULL || bm > -INFINITY) {    // :160-169, the running maximum is replaced
                 const float corr = __expf(m_run - bm);
                 l_run *= corr;
@@ -239,7 +253,7 @@ void attn_prefill_kernel(const AttnArgs a) {
                 wgt[r] = wv;
                 bsum += wv;
             }
-            bsum += __shfl_xor(bsum, 32);
+            bsum = halves_sum(bsum);
             l_run += bsum;
 
             // P^T operands: the lane's weights r = 8*ks .. 8*ks+7, as hi + lo binary16 parts
@@ -306,20 +320,6 @@ void attn_prefill_kernel(const AttnArgs a) {
 // V rows stay row-major in LDS; the V^T operand is read with the transposing ds_read_b64_tr_b16.
 // The two partial states of a query combine exactly as the reference's chain of rescales does across the cut:
 // O = O0 * exp(m0 - m1) + O1 with m0, m1 the block maxima at which the halves ended (:160-169).
-// Lanes l and l ^ 32 combine a value without a trip through LDS: v_permlane32_swap exchanges the upper 32 lanes of its
-// first operand with the lower 32 of its second, so from two copies of x one result holds the lower half's values in
-// every lane and the other the upper half's.
-__device__ __forceinline__ float halves_max(float x) {
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float halves_sum(float x) {
-    const unsigned u = __float_as_uint(x);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // Benchmarks only (-DPF_TRACE): per-phase shader-clock totals of the waves of workgroups 0 and 1.
 #ifdef PF_TRACE
 __device__ unsigned long long g_pf_trace[16 * 8];
@@ -665,13 +665,15 @@ __device__ __forceinline__ uint2 i8x4_to_f16x4(uint32_t x) {
 template <int D>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : PF_WAVES_PER_EU, D == 256 ? 1 : PF_WAVES_PER_EU)))
 void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int nsplit) {
-    constexpr int KROW = D + 8, VROW = PF_BLOCK + 4, NDT = D / 32, NST = D / 16;
+    constexpr int KROW = D + 8, VROW = D + 32, NDT = D / 32, NST = D / 16;   // V rows: banks shift by 16 per row
     constexpr int D16 = D / 16;            // 16-element pieces per row: a thread stages (key, d16)
     constexpr int NP = (D16 + 7) / 8;      // staging passes: 8 pieces per key and pass
     constexpr int NG = D == 256 ? 2 : 1;   // scale groups per cached row
     __shared__ __attribute__((aligned(16))) uint16_t sK[PF_BLOCK * KROW];
-    __shared__ __attribute__((aligned(16))) uint16_t sVt[D * VROW];
+    __shared__ __attribute__((aligned(16))) uint16_t sV[PF_BLOCK * VROW];   // row-major; read transposed (ds_read_b64_tr_b16)
     __shared__ __attribute__((aligned(16))) float sKs[NG][PF_BLOCK], sVs[NG][PF_BLOCK];
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s* lds_v4s;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int jq = lane & 31, g = lane >> 5;
@@ -769,9 +771,7 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     *reinterpret_cast<v4i*>(sK + skey * KROW + d0 + u * 8) = kh[u];
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        sVt[(d0 + u * 8 + e) * VROW + skey] = (uint16_t)(((uint32_t)vh[u][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+                    *reinterpret_cast<v4i*>(sV + skey * VROW + d0 + u * 8) = vh[u];
                 }
             }
         }
@@ -834,7 +834,7 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
                 sc[r] = (FULL || 8 * (r >> 2) + (r & 3) < limg) ? sv : -INFINITY;
                 bm = fmaxf(bm, sc[r]);
             }
-            bm = fmaxf(bm, __shfl_xor(bm, 32));
+            bm = halves_max(bm);
             const float mn = fmaxf(m_run, bm);
             // :395-414.  Once the running maximum has settled no lane's changes, the factor is exactly 1 in every
             // lane and the accumulators are left alone (a wave-uniform test).
@@ -858,7 +858,7 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
                 wgt[r] = (!FULL && sc[r] == -INFINITY) ? 0.0f : __expf(sc[r] - mn);
                 bsum += wgt[r];
             }
-            bsum += __shfl_xor(bsum, 32);
+            bsum = halves_sum(bsum);
             l_run += bsum;
 
             v8hf phi[NG][2], plo[NG][2];
@@ -877,11 +877,14 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
             for (int dt = 0; dt < NDT; dt++) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) {
-                    const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
-                    const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
-                    const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
-                    const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
-                    const v8hf vf = __builtin_bit_cast(v8hf, packed);
+                    // lane (16-lane group, row q of a 4-key block, 4-column piece p) supplies the address of key
+                    // 16 ks (+ 8) + 4 g + q, halves 32 dt + 16 (group & 1) + 4 p and receives its d of those 4 keys
+                    const uint16_t* vr = sV + (16 * ks + 4 * g + ((lane >> 2) & 3)) * VROW + dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+                    const v4s v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(vr));
+                    const v4s v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(vr + 8 * VROW));
+                    typedef short v8s __attribute__((ext_vector_type(8)));
+                    const v8s both = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    const v8hf vf = __builtin_bit_cast(v8hf, both);
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[dt * NG / NDT][ks], o[dt], 0, 0, 0);
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[dt * NG / NDT][ks], o[dt], 0, 0, 0);
                 }
