@@ -677,6 +677,18 @@ def extra_table(H, gen, big):
             rows[f"K{K}_N{N}"] = {"us": round(ms * 1e3, 1), "TOPS": round(tops, 1),
                                   "frac_int8_mfma_peak": round(tops / INT8_MFMA_PEAK_TOPS, 4)}
         ex["gemm_%s_M512" % ("int4" if int4 else "int8")] = rows
+    # FP16 x FP16^T (cactus_matmul_f16), fp32 accumulation on the matrix cores
+    rows = {}
+    for M, K, N in ((512, 4096, 4096), (512, 8192, 8192), (1, 4096, 4096)):
+        a16 = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
+        b16 = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).half()
+        o = torch.empty((M, N), dtype=torch.float16, device="cuda")
+        ms = time_events(lambda i: H.matmul_f16(a16, b16, out=o), 20, warm=3)
+        tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+        rows[f"M{M}_K{K}_N{N}"] = {"us": round(ms * 1e3, 1), "TFLOPs": round(tf, 1),
+                                   "frac_fp16_mfma_peak": round(tf / 2500.0, 4)}
+        del a16, b16
+    ex["matmul_f16"] = rows
     # decode attention over the INT8 KV cache
     rows = {}
     for name, Hq, Hkv, D, cache, Bn in (("qwen3_c512", 16, 8, 128, 512, 1), ("qwen3_c4096", 16, 8, 128, 4096, 1),

@@ -705,6 +705,11 @@ F16ATT = [
     (1, 200, 200, 4, 1, 128, 0, 512, True, False),   # a window longer than the prompt cuts nothing: matrix-core kernel
     (1, 64, 300, 4, 1, 128, 236, 512, True, False),  # ... with an offset, still inside the window
     (1, 64, 600, 4, 1, 128, 536, 512, True, False),  # the window cuts: the VALU kernel
+    (2, 300, 300, 8, 2, 128, 0, 0, True, False),     # two sequences, heads x sequences a multiple of 8 (heads pinned to XCDs)
+    (2, 200, 260, 4, 2, 64, 60, 0, True, False),
+    (1, 128, 96, 8, 8, 128, 0, 0, False, False),     # 3 key blocks: the two wave groups take 2 and 1
+    (1, 50, 32, 2, 1, 64, 0, 0, False, False),       # 1 key block: the second group has nothing
+    (1, 2048, 2048, 2, 1, 128, 0, 0, True, False),   # 32 iterations per group on the last tile
     (1, 300, 300, 4, 1, 256, 0, 512, True, False),   # Gemma heads, a local layer's window longer than the prompt
     (2, 130, 200, 8, 4, 256, 70, 0, True, False),    # ... a global layer, offset
     (1, 75, 75, 4, 1, 256, 0, 0, False, False),      # ... non-causal, tail of 3
@@ -728,6 +733,25 @@ def test_attention_f16_vs_oracle(H, B, S, KV, Hq, Hkv, D, off, win, causal, use_
                                position_offset=off, window_size=win, is_causal=causal))
     d = np.abs(f16(got) - f16(want))
     assert (d <= 2e-3 + 4e-3 * np.abs(f16(want))).all(), d.max()
+
+
+def test_attention_f16_full_size(H):
+    """A 4096-token causal prefill with Qwen3-0.6B heads: (a) query heads 0 and 9 against the oracle (their kv heads
+    only), same tolerance as above; (b) the first 2048 queries see only the first 2048 keys, so they equal a 2048-token
+    call bit for bit (same tiles, same block order)."""
+    S, Hq, Hkv, D = 4096, 16, 8, 128
+    rng = np.random.default_rng(4096)
+    q = rng.uniform(-1, 1, (1, S, Hq, D)).astype(np.float16)
+    k = rng.uniform(-1, 1, (1, S, Hkv, D)).astype(np.float16)
+    v = rng.uniform(-1, 1, (1, S, Hkv, D)).astype(np.float16)
+    got = bits(H.attention_f16(dev(q), dev(k), dev(v), 0.0, is_causal=True))
+    for h in (0, 9):
+        kvh = h // (Hq // Hkv)
+        want = O.attention_f16(q[:, :, h:h + 1], k[:, :, kvh:kvh + 1], v[:, :, kvh:kvh + 1], 0.0, is_causal=True)
+        d = np.abs(f16(got[:, :, h:h + 1]) - f16(want))
+        assert (d <= 2e-3 + 4e-3 * np.abs(f16(want))).all(), d.max()
+    half = bits(H.attention_f16(dev(q[:, :2048]), dev(k[:, :2048]), dev(v[:, :2048]), 0.0, is_causal=True))
+    assert np.array_equal(half, got[:, :2048])
 
 
 def test_attention_long_context_properties(H):
