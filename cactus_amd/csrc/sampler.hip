@@ -9,9 +9,14 @@
 //   1. scaled = half(logit * half(1/temperature))                     (:482-496; the bias written
 //      at :473-480 is overwritten by both branches and never has an effect)
 //   2. repetition penalty 1.1 for every occurrence of a token in the history (:502-513)
-//   3. top-k: values below the k-th largest drop out (:515-535) -- the k-th largest of 16-bit
-//      values comes from two 256-bin histograms of an order-preserving key (exact, no sort; the
-//      first histogram is filled by the pass that applies the temperature)
+//   3. top-k: values below the k-th largest drop out (:515-535).  The k-th largest of 16-bit values is a
+//      selection by two 256-bin histograms of an order-preserving key (exact, no sort) - but not over the row:
+//      a whole row's keys crowd into a few bins and the LDS atomics serialize.  Every thread keeps the largest
+//      key it saw in the temperature pass; the (k + history length)-th largest of those 1024 maxima is a lower
+//      bound of the k-th largest value (at most `history length` maxima are stale, lowered by the penalty), the
+//      few elements not below it are gathered, and the exact selection runs over them.  Rows where that does
+//      not work (k + history > 1024, a bound at or below -inf, more candidates than LDS holds) take the
+//      selection over the whole row.
 //   4. the survivors are gathered in index order (at most SAMPLE_CAP of them)
 //   5. top-p over the survivors in descending order (:537-588): fp32 exp / sum / cumulative sum in
 //      that order; entries from the first position > 0 whose cumulative mass exceeds top_p are cut.
@@ -29,12 +34,32 @@ constexpr int SAMPLE_HISTORY = 128;     // kernel_nn.cpp:499
 constexpr size_t SAMPLE_WIDE_GROUPS = 32;   // workgroups (histograms) of the kernel that finishes rows with more survivors
 constexpr uint16_t H_NEG_INF = 0xFC00;
 
+// Benchmarks only (-DSAMPLE_TRACE): shader-clock stamps of row 0's workgroup at the numbered steps of sample_kernel
+#ifdef SAMPLE_TRACE
+__device__ unsigned long long g_sample_trace[16];
+#define SMP_T(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sample_trace[i] = clock64(); } while (0)
+#else
+#define SMP_T(i) do { } while (0)
+#endif
+
 // larger value <=> larger key; -0 and +0 share a key
 __device__ __forceinline__ uint32_t order_key(uint16_t b) {
     if (b == 0x8000) b = 0;
     return (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
 }
 __device__ __forceinline__ uint16_t hmul(uint16_t a, uint16_t b) { return f2h(h2f(a) * h2f(b)); }
+// two binary16 products / two signed 16-bit maxima per register (v_pk_mul_f16, v_pk_max_i16)
+__device__ __forceinline__ int pk_mul_f16(int a, int b) {
+    typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+    const h2v r = __builtin_bit_cast(h2v, a) * __builtin_bit_cast(h2v, b);
+    return __builtin_bit_cast(int, r);
+}
+__device__ __forceinline__ int pk_max_i16(int a, int b) {
+    typedef short s2v __attribute__((ext_vector_type(2)));
+    const s2v r = __builtin_elementwise_max(__builtin_bit_cast(s2v, a), __builtin_bit_cast(s2v, b));
+    return __builtin_bit_cast(int, r);
+}
+__device__ __forceinline__ int pk_top_i16(int a) { return max((int)(short)(a & 0xFFFF), a >> 16); }   // the larger half
 __device__ __forceinline__ float exp_f(float x) { return (float)exp((double)x); }
 
 __global__ __launch_bounds__(1024) void sample_kernel(
@@ -49,7 +74,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(
     __shared__ uint16_t order[SAMPLE_CAP];
     __shared__ float pr[SAMPLE_CAP];
     __shared__ float wmax[16];
-    __shared__ int s_hb, s_k2, s_kth, s_cut, s_token, s_push;
+    __shared__ int s_hb, s_k2, s_kth, s_cut, s_token, s_push, s_ncand;
+    __shared__ uint32_t s_hist[SAMPLE_HISTORY];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const size_t row = blockIdx.x;
@@ -72,163 +98,334 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         }
     };
     const bool use_topk = top_k > 0 && top_k < vocab;
-
-    // 1. temperature, and the histogram of the high key byte for the top-k selection
-    if (t < 256) hist[t] = 0;
-    __syncthreads();
-    for (int c = t; c < nchunk; c += 1024) {
-        uint16_t v[8];
-        load8(L, c, v);
-        if (use_temp) {
+    auto unpack8 = [](const v4i& x, uint16_t (&v)[8]) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = hmul(v[e], inv_temp);
+        for (int e = 0; e < 8; e++) v[e] = (uint16_t)(((uint32_t)x[e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+    };
+    // every chunk of an aligned row as its 16 bytes, thread t the chunks t, t + 1024, ...; four loads in flight per
+    // thread, and the next four are requested before the current four are handed out, so that what body() stores
+    // is issued behind those loads and does not stand between them and their wait
+    auto for_raw_chunks = [&](const uint16_t* src, auto&& body) {
+        auto fetch4 = [&](int c0, v4i (&x)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                x[u] = *reinterpret_cast<const v4i*>(src + (size_t)min(c0 + u * 1024, nchunk - 1) * 8);
+        };
+        auto hand4 = [&](int c0, const v4i (&x)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (c0 + u * 1024 < nchunk) body(c0 + u * 1024, x[u]);
+        };
+        v4i xa[4], xb[4];
+        if (t < nchunk) fetch4(t, xa);
+        for (int c0 = t; c0 < nchunk; c0 += 8192) {
+            if (c0 + 4096 < nchunk) fetch4(c0 + 4096, xb);
+            hand4(c0, xa);
+            if (c0 + 4096 < nchunk) {
+                if (c0 + 8192 < nchunk) fetch4(c0 + 8192, xa);
+                hand4(c0 + 4096, xb);
+            }
         }
+    };
+    // ... element by element, any row
+    auto for_chunks = [&](const uint16_t* src, auto&& body) {
         if (vec) {
-            v4i x;
-#pragma unroll
-            for (int e = 0; e < 4; e++) x[e] = (int)((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16));
-            *reinterpret_cast<v4i*>(F + (size_t)c * 8) = x;
+            for_raw_chunks(src, [&](int c, const v4i& x) {
+                uint16_t v[8];
+                unpack8(x, v);
+                body(c, v);
+            });
         } else {
+            for (int c = t; c < nchunk; c += 1024) {
+                uint16_t v[8];
+                load8(src, c, v);
+                body(c, v);
+            }
+        }
+    };
+    SMP_T(0);
+    // 1. temperature; every thread keeps a witness: the key of one of its elements, the largest where that is cheap.
+    // Aligned rows stay packed: the product of two binary16 values rounded once is what hmul() computes
+    // (v_pk_mul_f16), and the largest bit pattern as a signed integer (v_pk_max_i16) is the largest value whenever a
+    // thread has a positive one - and some element of the thread in any case, which is all the bound needs.
+    uint32_t tmax = 0;
+    if (vec) {
+        const int it2 = (int)((uint32_t)inv_temp | ((uint32_t)inv_temp << 16));
+        int wit = (int)0x80008000u;
+        for_raw_chunks(L, [&](int c, const v4i& xin) {
+            const int x0 = use_temp ? pk_mul_f16(xin[0], it2) : xin[0], x1 = use_temp ? pk_mul_f16(xin[1], it2) : xin[1];
+            const int x2 = use_temp ? pk_mul_f16(xin[2], it2) : xin[2], x3 = use_temp ? pk_mul_f16(xin[3], it2) : xin[3];
+            *reinterpret_cast<v4i*>(F + (size_t)c * 8) = v4i{x0, x1, x2, x3};
+            if (use_topk) wit = pk_max_i16(pk_max_i16(wit, pk_max_i16(x0, x1)), pk_max_i16(x2, x3));
+        });
+        if (use_topk && t < nchunk) tmax = order_key((uint16_t)pk_top_i16(wit));
+    } else {
+        for_chunks(L, [&](int c, uint16_t (&v)[8]) {
+            if (use_temp) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = hmul(v[e], inv_temp);
+            }
 #pragma unroll
             for (int e = 0; e < 8; e++)
                 if (c * 8 + e < vocab) F[(size_t)c * 8 + e] = v[e];
-        }
-        if (use_topk) {
+            if (use_topk) {
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-                if (c * 8 + e < vocab) atomicAdd(&hist[order_key(v[e]) >> 8], 1u);
-        }
+                for (int e = 0; e < 8; e++)
+                    if (c * 8 + e < vocab) tmax = max(tmax, order_key(v[e]));
+            }
+        });
     }
     __syncthreads();
 
-    // 2. repetition penalty: the first occurrence of a token applies it once per occurrence (and
-    // moves the token between histogram bins)
+    SMP_T(1);
+    // 2. repetition penalty: the first occurrence of a token applies it once per occurrence (the history goes
+    // through LDS: 128 dependent reads of global memory per thread would cost more than the passes over the row)
+    if (t < hc) s_hist[t] = H[t];
+    __syncthreads();
     if (t < hc) {
-        const uint32_t tok = H[t];
+        const uint32_t tok = s_hist[t];
         bool first = true;
         int cnt = 0;
+#pragma unroll 8
         for (int j = 0; j < hc; j++) {
-            const bool same = H[j] == tok;
+            const bool same = s_hist[j] == tok;
             if (same && j < t) first = false;
             cnt += same;
         }
         if (first && tok < (uint32_t)vocab) {
             const uint16_t pinv = f2h(1.0f / 1.1f), pen = f2h(1.1f);
-            const uint16_t v0 = F[tok];
-            uint16_t v = v0;
+            uint16_t v = F[tok];
             for (int c = 0; c < cnt; c++) v = (h2f(v) > 0.0f) ? hmul(v, pinv) : hmul(v, pen);
             F[tok] = v;
-            if (use_topk) {
-                atomicSub(&hist[order_key(v0) >> 8], 1u);
-                atomicAdd(&hist[order_key(v) >> 8], 1u);
-            }
         }
     }
     __syncthreads();
 
-    // 3. top-k threshold: the key of the k-th largest value (0: everything passes)
-    uint32_t kth = 0;
-    if (use_topk) {
-        if (t == 0) {
-            uint32_t cum = 0;
-            int b = 255;
-            for (; b > 0; b--) {
-                if (cum + hist[b] >= (uint32_t)top_k) break;
-                cum += hist[b];
-            }
-            s_hb = b;
-            s_k2 = top_k - (int)cum;     // rank wanted inside bin b (>= 1)
+    // Walking the histogram from bin 255 down, the bin at which the count reaches `rank` (bin 0 if it never does) and
+    // the count above that bin: one wave, 4 bins per lane, suffix sums over the lanes (a lane walking 256 bins alone
+    // pays an LDS round trip per bin)
+    auto top_bin = [&](uint32_t rank, int& above) -> int {
+        uint32_t h4[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) h4[e] = hist[lane * 4 + e];
+        const uint32_t own = h4[0] + h4[1] + h4[2] + h4[3];
+        uint32_t incl = own;                       // own + every higher lane
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t dn = __shfl_down(incl, o, 64);
+            if (lane + o < 64) incl += dn;
+        }
+        uint32_t sfx = incl - own;                 // count in the bins above this lane's
+        int best = -1;
+        uint32_t best_above = 0;
+#pragma unroll
+        for (int e = 3; e >= 0; e--) {
+            if (best < 0 && sfx + h4[e] >= rank) { best = lane * 4 + e; best_above = sfx; }
+            sfx += h4[e];
+        }
+        // the highest such bin over the wave
+        int top = best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o, 64));
+        if (top < 1) {                             // never reached (or at bin 0): bin 0, everything above it
+            above = (int)(__shfl(incl, 0, 64) - __shfl(h4[0], 0, 64));
+            return 0;
+        }
+        above = (int)__shfl(best_above, top >> 2, 64);
+        return top;
+    };
+
+    // the key of the rank-th largest of the keys `visit` hands out (every thread calls visit(f) and f(key) for
+    // each key it owns): 256-bin histogram of the high byte, then of the low byte inside the selected bin
+    auto kth_select = [&](auto&& visit, int rank) -> uint32_t {
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        visit([&](uint32_t k) { atomicAdd(&hist[k >> 8], 1u); });
+        __syncthreads();
+        if (w == 0) {
+            int cum;
+            const int b = top_bin((uint32_t)rank, cum);
+            if (lane == 0) { s_hb = b; s_k2 = rank - cum; }   // rank wanted inside bin b (>= 1)
         }
         __syncthreads();
         const int hb = s_hb;
         if (t < 256) hist[t] = 0;
         __syncthreads();
-        for (int c = t; c < nchunk; c += 1024) {
-            uint16_t v[8];
-            load8(F, c, v);
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint32_t k = order_key(v[e]);
-                if (c * 8 + e < vocab && (int)(k >> 8) == hb) atomicAdd(&hist[k & 255], 1u);
-            }
+        visit([&](uint32_t k) { if ((int)(k >> 8) == hb) atomicAdd(&hist[k & 255], 1u); });
+        __syncthreads();
+        if (w == 0) {
+            int cum;
+            const int b = top_bin((uint32_t)s_k2, cum);
+            if (lane == 0) s_kth = (hb << 8) | b;
         }
         __syncthreads();
-        if (t == 0) {
-            uint32_t cum = 0;
-            int b = 255;
-            for (; b > 0; b--) {
-                if (cum + hist[b] >= (uint32_t)s_k2) break;
-                cum += hist[b];
-            }
-            s_kth = (hb << 8) | b;
-        }
-        __syncthreads();
-        kth = (uint32_t)s_kth;
-    }
-
-    // 4. survivors (not below the k-th value, not -inf) in index order: wave w owns one contiguous
-    // range of chunks, a lane 8 consecutive elements of each 512-element step
-    auto alive_mask = [&](int c) -> uint32_t {
-        if (c >= nchunk) return 0u;
-        uint16_t v[8];
-        load8(F, c, v);
-        uint32_t m = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++)
-            m |= (uint32_t)(c * 8 + e < vocab && v[e] != H_NEG_INF && order_key(v[e]) >= kth) << e;
-        return m;
+        return (uint32_t)s_kth;
     };
-    const int cper = (((nchunk + 15) / 16) + 63) & ~63;
-    const int clo = w * cper, chi = min(nchunk, clo + cper);
-    {
-        uint32_t c = 0;
-        for (int c0 = clo; c0 < chi; c0 += 64) c += (uint32_t)__popc(alive_mask(c0 + lane < chi ? c0 + lane : nchunk));
-        c = (uint32_t)wave_sum((float)c);      // < 2^24: exact
-        if (lane == 0) wcount[w] = c;
-    }
-    __syncthreads();
-    uint32_t base = 0, n_all = 0;
-    for (int j = 0; j < 16; j++) {
-        if (j < w) base += wcount[j];
-        n_all += wcount[j];
-    }
-    if (n_all > (uint32_t)SAMPLE_CAP) {      // uniform over the workgroup: the row goes to sample_wide_kernel
-        if (t == 0) {
-            out[row] = 0xFFFFFFFFu;
-            if (wide_kth) wide_kth[row] = kth;
-            else if (status) atomicExch(status, 1);
-        }
-        return;
-    }
-    const int n = (int)n_all;
-    for (int c0 = clo; c0 < chi; c0 += 64) {
-        const int c = c0 + lane < chi ? c0 + lane : nchunk;
-        const uint32_t m = alive_mask(c);
-        const uint32_t cnt = (uint32_t)__popc(m);
-        // exclusive prefix of cnt over the lanes of the wave
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        const uint32_t total = __shfl(incl, 63, 64);
-        if (m) {
-            uint16_t v[8];
-            load8(F, c, v);
-            uint32_t pos = base + incl - cnt;
+    auto visit_row = [&](auto&& f) {
+        for_chunks(F, [&](int c, uint16_t (&v)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; e++)
-                if (m & (1u << e)) {
-                    sv_bits[pos] = v[e];
-                    sv_idx[pos] = (uint32_t)(c * 8 + e);
-                    pos++;
-                }
-        }
-        base += total;
-    }
-    __syncthreads();
+                if (c * 8 + e < vocab) f(order_key(v[e]));
+        });
+    };
 
+    SMP_T(2);
+    // 3. top-k threshold: the key of the k-th largest value (0: everything passes), or - `exact` false - a lower
+    // bound of it that few elements reach
+    uint32_t kth = 0;
+    bool exact = true;
+    if (use_topk) {
+        const int m = top_k + hc;
+        if (m <= 1024) {
+            kth = kth_select([&](auto&& f) { f(tmax); }, m);
+            exact = false;
+        }
+        if (exact || kth <= order_key(H_NEG_INF)) {   // -inf elements count in the ranks but are no candidates
+            kth = kth_select(visit_row, top_k);
+            exact = true;
+        }
+    }
+    SMP_T(3);
+    // 3b. from a bound: the candidates in one pass and any order (LDS counter), the exact selection among them, and
+    // those that stay placed by the number of others before them in the row
+    bool gathered = false;
+    int n_fast = 0;
+    if (!exact) {
+        uint32_t* cidx = reinterpret_cast<uint32_t*>(pr);      // candidates: bits in order[], index in pr[] (both free until top-p)
+        if (t == 0) s_ncand = 0;
+        __syncthreads();
+        auto take = [&](int c, uint16_t (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (c * 8 + e < vocab && v[e] != H_NEG_INF && order_key(v[e]) >= kth) {
+                    const int p = atomicAdd(&s_ncand, 1);
+                    if (p < 1024) { order[p] = v[e]; cidx[p] = (uint32_t)(c * 8 + e); }
+                }
+        };
+        if (vec && kth > 0x8000u) {
+            // a bound above +0: a value reaches it exactly when its bit pattern, as a signed integer, reaches the
+            // bound's - the largest pattern of a chunk (three v_pk_max_i16) rules almost every chunk out
+            const int tb = (int)(kth & 0x7FFFu);
+            for_raw_chunks(F, [&](int c, const v4i& x) {
+                if (pk_top_i16(pk_max_i16(pk_max_i16(x[0], x[1]), pk_max_i16(x[2], x[3]))) >= tb) {
+                    uint16_t v[8];
+                    unpack8(x, v);
+                    take(c, v);
+                }
+            });
+        } else {
+            for_chunks(F, take);
+        }
+        __syncthreads();
+        SMP_T(9);
+        const int n_cand = s_ncand;
+        if (n_cand > 1024) {                 // many equal values at the bound: the selection over the row, then step 4
+            kth = kth_select(visit_row, top_k);
+            exact = true;
+        } else {
+            kth = kth_select([&](auto&& f) { if (t < n_cand) f(order_key(order[t])); }, top_k);
+            SMP_T(10);
+            // those that stay move to a second list (any order), then each finds its place by counting the others
+            // before it in the row
+            const bool keep = t < n_cand && order_key(order[t]) >= kth;
+            if (t == 0) s_ncand = 0;
+            __syncthreads();
+            if (keep) {
+                const int p = atomicAdd(&s_ncand, 1);
+                order[1024 + p] = order[t];
+                cidx[1024 + p] = cidx[t];
+            }
+            __syncthreads();
+            const int n_keep = s_ncand;
+            if (t < n_keep) {
+                const uint16_t my_bits = order[1024 + t];
+                const uint32_t my_idx = cidx[1024 + t];
+                int rank = 0;
+#pragma unroll 8
+                for (int j = 0; j < n_keep; j++) rank += cidx[1024 + j] < my_idx;
+                sv_bits[rank] = my_bits;
+                sv_idx[rank] = my_idx;
+            }
+            __syncthreads();
+            n_fast = s_ncand;
+            gathered = true;
+        }
+    }
+
+    SMP_T(4);
+    int n_kept = n_fast;
+    if (!gathered) {
+        // 4. survivors (not below the k-th value, not -inf) in index order: wave w owns one contiguous
+        // range of chunks, a lane 8 consecutive elements of each 512-element step
+        auto alive_mask = [&](int c) -> uint32_t {
+            if (c >= nchunk) return 0u;
+            uint16_t v[8];
+            load8(F, c, v);
+            uint32_t m = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                m |= (uint32_t)(c * 8 + e < vocab && v[e] != H_NEG_INF && order_key(v[e]) >= kth) << e;
+            return m;
+        };
+        const int cper = (((nchunk + 15) / 16) + 63) & ~63;
+        const int clo = w * cper, chi = min(nchunk, clo + cper);
+        uint32_t base = 0, n_all = 0;
+        auto count_alive = [&]() {
+            uint32_t c = 0;
+#pragma unroll 4
+            for (int c0 = clo; c0 < chi; c0 += 64) c += (uint32_t)__popc(alive_mask(c0 + lane < chi ? c0 + lane : nchunk));
+            c = (uint32_t)wave_sum((float)c);      // < 2^24: exact
+            __syncthreads();                       // the previous count has been read
+            if (lane == 0) wcount[w] = c;
+            __syncthreads();
+            base = 0; n_all = 0;
+            for (int j = 0; j < 16; j++) {
+                if (j < w) base += wcount[j];
+                n_all += wcount[j];
+            }
+        };
+        count_alive();
+        if (n_all > (uint32_t)SAMPLE_CAP) {      // uniform over the workgroup: the row goes to sample_wide_kernel
+            if (t == 0) {
+                out[row] = 0xFFFFFFFFu;
+                if (wide_kth) wide_kth[row] = kth;
+                else if (status) atomicExch(status, 1);
+            }
+            return;
+        }
+        n_kept = (int)n_all;
+        for (int c0 = clo; c0 < chi; c0 += 64) {
+            const int c = c0 + lane < chi ? c0 + lane : nchunk;
+            const uint32_t m = alive_mask(c);
+            const uint32_t cnt = (uint32_t)__popc(m);
+            // exclusive prefix of cnt over the lanes of the wave
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += up;
+            }
+            const uint32_t total = __shfl(incl, 63, 64);
+            if (m) {
+                uint16_t v[8];
+                load8(F, c, v);
+                uint32_t pos = base + incl - cnt;
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    if (m & (1u << e)) {
+                        sv_bits[pos] = v[e];
+                        sv_idx[pos] = (uint32_t)(c * 8 + e);
+                        pos++;
+                    }
+            }
+            base += total;
+        }
+        __syncthreads();
+    }
+    SMP_T(5);
+    const int n = n_kept;
+
+    SMP_T(6);
     // 5. top-p
     if (top_p > 0.0f && top_p < 1.0f && n > 0) {
         for (int s = t; s < n; s += 1024) {
@@ -244,14 +441,16 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         const float mx = h2f(sv_bits[order[0]]);
         for (int r = t; r < n; r += 1024) pr[r] = exp_f(h2f(sv_bits[order[r]]) - mx);
         __syncthreads();
-        if (t == 0) {
+        if (t == 0) {        // the reference's sums, in its order; no early exit so that the LDS reads run ahead
             float sum = 0.0f;
+#pragma unroll 8
             for (int r = 0; r < n; r++) sum += pr[r];
             float cum = 0.0f;
             int cut = n;
+#pragma unroll 8
             for (int r = 0; r < n; r++) {
                 cum += pr[r] / sum;
-                if (cum > top_p && r > 0) { cut = r; break; }
+                if (cut == n && cum > top_p && r > 0) cut = r;
             }
             s_cut = cut;
         }
@@ -261,6 +460,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         __syncthreads();
     }
 
+    SMP_T(7);
     // 6. softmax in index order and the draw
     float m = -INFINITY;
     for (int s = t; s < n; s += 1024)
@@ -277,6 +477,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         int token = 0, push = 0;
         if (n > 0 && m != -INFINITY) {
             float sum = 0.0f;
+#pragma unroll 8
             for (int s = 0; s < n; s++) sum += pr[s];
             if (sum != 0.0f) {
                 const float sample = draws[row];
@@ -286,10 +487,13 @@ __global__ __launch_bounds__(1024) void sample_kernel(
                     found = 0;               // the running sum is >= 0 at element 0 already
                 } else {
                     float cum = 0.0f;
+                    int hit = -1;
+#pragma unroll 8
                     for (int s = 0; s < n; s++) {
                         cum += pr[s] / sum;
-                        if (cum >= sample) { found = (int)sv_idx[s]; break; }
+                        if (hit < 0 && cum >= sample) hit = s;
                     }
+                    if (hit >= 0) found = (int)sv_idx[hit];
                     if (found < 0) {
                         for (int s = n - 1; s >= 0; s--)
                             if (pr[s] / sum > 0.0f) { found = (int)sv_idx[s]; break; }
@@ -304,6 +508,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(
         s_push = push;
     }
     __syncthreads();
+    SMP_T(8);
     if (H && s_push) {     // kernel_nn.cpp:627-630: append, dropping the oldest beyond 128
         const uint32_t tok = (uint32_t)s_token;
         if (hc < SAMPLE_HISTORY) {
@@ -332,6 +537,12 @@ constexpr int WIDE_CHUNK = 4096;
 __device__ __forceinline__ uint16_t key_value(uint32_t k) {      // inverse of order_key
     return (k & 0x8000u) ? (uint16_t)(k & 0x7FFFu) : (uint16_t)(~k & 0xFFFFu);
 }
+#ifdef SAMPLE_TRACE
+extern "C" int cactus_hip_debug_sample_trace(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sample_trace), sizeof(unsigned long long) * 16);
+}
+#endif
+
 __global__ __launch_bounds__(1024) void sample_wide_kernel(
     const uint16_t* __restrict__ work, uint32_t* __restrict__ out, int rows, int vocab, float top_p,
     const float* __restrict__ draws, uint32_t* __restrict__ history, uint32_t* __restrict__ hist_counts,

@@ -37,6 +37,14 @@ def logits_rows(rng, rows, vocab, kind):
         x[:, 7 % vocab] = np.float16(30.0)
     elif kind == "flat":
         x[:] = np.float16(0.5)
+    elif kind == "clustered":     # the large logits sit next to each other, the rest is one value
+        hi = (np.abs(x[:, :400].astype(np.float32)) + 3).astype(np.float16)
+        x[:] = np.float16(0.5)
+        x[:, :400] = hi
+    elif kind == "sparse":        # fewer finite logits than top_k
+        keep = x[:, :30].copy()
+        x[:] = np.float16(-np.inf)
+        x[:, 5::(vocab // 30)][:, :30] = keep
     elif kind == "neginf":
         x[:, ::3] = np.float16(-np.inf)
         x[:, 1] = np.float16(-0.0)
@@ -64,6 +72,14 @@ CASES = [
     (2, 20000, 0.0, 0.97, 6000, "neginf"),   # top_k above 4096, -inf entries
     (40, 9000, 1.1, 0.8, 0, "peaked"),       # more rows than the second kernel has workgroups
     (2, 10000, 1.0, 0.9, 0, "flat"),         # every logit equal
+    # the top-k threshold: bound from the threads' maxima, then the exact selection over the candidates
+    (3, 151936, 0.6, 0.95, 20, "peaked"),    # the sampled token repeats: the penalty lowers a thread's maximum
+    (2, 151936, 0.9, 0.9, 1000, "normal"),   # k + history reaches 1024 threads after a few steps: selection over the row
+    (2, 40000, 0.8, 0.9, 1024, "normal"),    # ... from the first step
+    (2, 3000, 0.8, 0.9, 50, "sparse"),       # the bound falls at -inf: selection over the row
+    (2, 151936, 1.0, 0.9, 300, "clustered"), # few threads hold the large logits: every element reaches the bound, more
+                                             # candidates than LDS holds, selection over the row
+    (2, 70000, 0.7, 0.95, 200, "ties"),      # many equal values around the k-th place
 ]
 
 
@@ -100,6 +116,26 @@ def test_sampler_history_window_and_penalty_over_many_steps(H):
             assert got[r] == want, (step, r)
     for r in range(rows):
         assert len(hist[r]) == 128 and smp.history_of(r) == hist[r]
+
+
+def test_sampler_scaled_row_is_the_same_on_aligned_and_unaligned_rows(H):
+    """The temperature pass keeps aligned rows packed (two binary16 products per instruction); a row whose length is
+    not a multiple of 8 takes the element-wise path.  Same logits, same scaled values, bit for bit - over every finite
+    binary16 pattern, both infinities and the subnormals."""
+    allbits = np.arange(65536, dtype=np.uint16)
+    vals = allbits.view(np.float16)
+    vals = vals[~np.isnan(vals)]                       # 63490 values
+    n = (len(vals) // 8) * 8
+    a = vals[:n].reshape(1, n).copy()
+    b = np.concatenate([a[0], np.array([1.0], np.float16)]).reshape(1, n + 1)
+    draws = dev(np.array([0.5], np.float32))
+    for temperature in (0.6, 1.3, 2.5):
+        sa, sb = H.Sampler(1, n), H.Sampler(1, n + 1)
+        sa.sample(dev(a), temperature, 0.9, 20, draws)
+        sb.sample(dev(b), temperature, 0.9, 20, draws)
+        wa = sa.work.cpu().view(torch.int16).numpy()[0]
+        wb = sb.work.cpu().view(torch.int16).numpy()[0, :n]
+        assert np.array_equal(wa, wb)
 
 
 def test_sampler_edge_draws_and_no_history(H):
