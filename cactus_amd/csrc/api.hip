@@ -1001,7 +1001,10 @@ int cactus_hip_logits_entropy_f16_dev(const cactus_half_t* logits, float* output
     if (rows == 0) return CACTUS_HIP_OK;
     if (!logits || !output) return fail(CACTUS_HIP_EINVAL, "logits_entropy: null operand");
     if (vocab_size == 0) return fail(CACTUS_HIP_EINVAL, "logits_entropy: empty row");
-    hipError_t e = launch_entropy(logits, output, rows, vocab_size, S(stream));
+    void* scratch = nullptr;   // slice results when a row is spread over several workgroups (grow-only workspace)
+    int rc = ::workspace(entropy_scratch_bytes(rows, vocab_size), &scratch);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_entropy(logits, output, rows, vocab_size, scratch, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "logits_entropy launch", e);
     return CACTUS_HIP_OK;
 }

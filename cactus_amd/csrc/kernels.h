@@ -234,7 +234,8 @@ size_t sample_wide_scratch_bytes(size_t rows);
 hipError_t launch_sample(const uint16_t* logits, uint16_t* work, uint32_t* out, int* status, size_t rows,
                          size_t vocab, float temperature, float top_p, size_t top_k, const float* draws,
                          uint32_t* history, uint32_t* hist_counts, void* wide_scratch, hipStream_t st);
-hipError_t launch_entropy(const uint16_t* logits, float* out, size_t rows, size_t vocab, hipStream_t st);
+size_t entropy_scratch_bytes(size_t rows, size_t vocab);
+hipError_t launch_entropy(const uint16_t* logits, float* out, size_t rows, size_t vocab, void* scratch, hipStream_t st);
 hipError_t launch_indices_to_i32(const void* src, bool is_f32, int32_t* dst, size_t n, hipStream_t st);
 hipError_t launch_embedding_f16(const uint16_t* emb, const int32_t* indices, uint16_t* out, size_t num_indices,
                                 size_t vocab, size_t hidden, int* bad, hipStream_t st);

@@ -794,6 +794,90 @@ __global__ __launch_bounds__(1024) void entropy_kernel(const uint16_t* __restric
     if (t == 0) out[blockIdx.x] = (float)(ent / log((double)vocab));
 }
 
+// The same figure with a row spread over `parts` workgroups (one workgroup per row leaves a single CU to evaluate
+// 2 x vocab double-precision exponentials): slice maxima and sums first, then - every workgroup combines the row's
+// slice results itself - the entropy terms of a slice, then one thread per row adds the slices' terms.
+struct EntropyPart { double se; float m; float pad; };
+
+__device__ __forceinline__ double entropy_block_sum(double v, double* red) {   // 256 threads
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void entropy_slice_sums_kernel(const uint16_t* __restrict__ logits,
+                                                                 EntropyPart* __restrict__ parts, int vocab, int nparts) {
+    __shared__ double red[4];
+    __shared__ float wmax[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int row = blockIdx.x / nparts, g = blockIdx.x % nparts;
+    const int len = (vocab + nparts - 1) / nparts, lo = min(vocab, g * len), hi = min(vocab, lo + len);
+    const uint16_t* L = logits + (size_t)row * vocab;
+    float m = -INFINITY;
+    for (int i = lo + t; i < hi; i += 256) m = fmaxf(m, h2f(L[i]));
+    m = wave_max(m);
+    if (lane == 0) wmax[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    double se = 0.0;
+    for (int i = lo + t; i < hi; i += 256) se += exp((double)(h2f(L[i]) - m));
+    se = entropy_block_sum(se, red);
+    if (t == 0) parts[(size_t)row * nparts + g] = EntropyPart{lo < hi ? se : 0.0, m, 0.0f};
+}
+
+__global__ __launch_bounds__(256) void entropy_slice_terms_kernel(const uint16_t* __restrict__ logits,
+                                                                  const EntropyPart* __restrict__ parts,
+                                                                  double* __restrict__ terms, int vocab, int nparts) {
+    __shared__ double red[4];
+    __shared__ double s_lse;
+    const int t = threadIdx.x;
+    const int row = blockIdx.x / nparts, g = blockIdx.x % nparts;
+    const int len = (vocab + nparts - 1) / nparts, lo = min(vocab, g * len), hi = min(vocab, lo + len);
+    const uint16_t* L = logits + (size_t)row * vocab;
+    if (t < 64) {            // the row's maximum and sum from its slices (at most 64), a slice per lane
+        const EntropyPart* P = parts + (size_t)row * nparts;
+        const float mj = t < nparts ? P[t].m : -INFINITY;
+        const float m = wave_max(mj);
+        double se = (t < nparts && mj > -INFINITY) ? P[t].se * exp((double)(mj - m)) : 0.0;
+        for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+        if (t == 0) s_lse = (double)m + log(se);
+    }
+    __syncthreads();
+    const double lse = s_lse;
+    double ent = 0.0;
+    for (int i = lo + t; i < hi; i += 256) {
+        const double lp = (double)h2f(L[i]) - lse;
+        const double p = exp(lp);
+        if (p > 1e-10) ent -= p * lp;
+    }
+    ent = entropy_block_sum(ent, red);
+    if (t == 0) terms[(size_t)row * nparts + g] = ent;
+}
+
+__global__ __launch_bounds__(256) void entropy_finish_kernel(const double* __restrict__ terms, float* __restrict__ out,
+                                                             int rows, int vocab, int nparts) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    double ent = 0.0;
+    for (int j = 0; j < nparts; j++) ent += terms[(size_t)row * nparts + j];
+    out[row] = (float)(ent / log((double)vocab));
+}
+
+// slices per row: about 1024 workgroups in all, at most 64 per row, at least 1024 logits per slice
+int entropy_parts(size_t rows, size_t vocab) {
+    size_t g = rows ? 1024 / rows : 1;
+    if (g > 64) g = 64;
+    if (g > vocab / 1024) g = vocab / 1024;
+    return g < 2 ? 1 : (int)g;
+}
+size_t entropy_scratch_bytes(size_t rows, size_t vocab) {
+    const size_t g = (size_t)entropy_parts(rows, vocab);
+    return g < 2 ? 0 : rows * g * (sizeof(EntropyPart) + sizeof(double));
+}
+
 size_t sample_wide_scratch_bytes(size_t rows) {
     const size_t groups = rows < SAMPLE_WIDE_GROUPS ? rows : SAMPLE_WIDE_GROUPS;
     return ((rows * sizeof(uint32_t) + 255) & ~size_t(255)) + groups * 65536 * (sizeof(uint32_t) + sizeof(uint2));
@@ -826,10 +910,20 @@ hipError_t launch_sample(const uint16_t* logits, uint16_t* work, uint32_t* out, 
     return hipGetLastError();
 }
 
-hipError_t launch_entropy(const uint16_t* logits, float* out, size_t rows, size_t vocab, hipStream_t st) {
+// scratch: entropy_scratch_bytes(rows, vocab) bytes, or null (then one workgroup per row)
+hipError_t launch_entropy(const uint16_t* logits, float* out, size_t rows, size_t vocab, void* scratch, hipStream_t st) {
     if (rows == 0) return hipSuccess;
     if (vocab == 0 || vocab > 0x7FFFFFFFull || rows > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    entropy_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, out, (int)vocab);
+    const int g = entropy_parts(rows, vocab);
+    if (g < 2 || scratch == nullptr || rows * (size_t)g > 0x7FFFFFFFull) {
+        entropy_kernel<<<dim3((unsigned)rows), dim3(1024), 0, st>>>(logits, out, (int)vocab);
+        return hipGetLastError();
+    }
+    EntropyPart* parts = static_cast<EntropyPart*>(scratch);
+    double* terms = reinterpret_cast<double*>(parts + rows * g);
+    entropy_slice_sums_kernel<<<dim3((unsigned)(rows * g)), dim3(256), 0, st>>>(logits, parts, (int)vocab, g);
+    entropy_slice_terms_kernel<<<dim3((unsigned)(rows * g)), dim3(256), 0, st>>>(logits, parts, terms, (int)vocab, g);
+    entropy_finish_kernel<<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st>>>(terms, out, (int)rows, (int)vocab, g);
     return hipGetLastError();
 }
 
