@@ -64,7 +64,8 @@ int   cactus_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stre
 int   cactus_hip_synchronize(void* stream);
 
 /* The library keeps one grow-only device workspace per device (split-KV records of the attention
- * kernels, quantized activation rows of the FP16-activation matmuls with more than 4 rows).  It
+ * kernels, quantized activation rows of the FP16-activation matmuls with more than 4 rows, the
+ * slice results of cactus_hip_logits_entropy_f16_dev: 24 bytes per row and slice, at most 64 slices).  It
  * grows by allocating, which HIP stream capture forbids: reserve the largest size a captured
  * sequence needs beforehand (or run the sequence once uncaptured).  An outgrown workspace stays
  * allocated, so graphs captured earlier remain valid.  No counterpart in the reference. */
@@ -389,7 +390,9 @@ float cactus_hip_sample_uniform(uint32_t seed);   /* host computation, no device
 
 /* The confidence figure of Model::decode (engine_model.cpp:255-290): entropy of softmax(row) in
  * double precision divided by log(vocab_size), one float per row.  The reference adds in element
- * order; partial sums are combined as a tree here (the float result may differ in the last bit). */
+ * order; partial sums are combined as a tree here (the float result may differ in the last bit).
+ * A row is spread over up to 64 workgroups whose slice results pass through the library workspace
+ * (calls on one device share a stream, as for the attention records). */
 int cactus_hip_logits_entropy_f16_dev(const cactus_half_t* logits, float* output, size_t rows,
                                       size_t vocab_size, void* stream);
 
