@@ -894,6 +894,45 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
         else block_math(std::false_type{});
     }
 
+    if constexpr (D <= 128) {
+        if (nsplit > 1) {
+            // (max, sum, unnormalised output) of this key range: attn_merge_kernel's record of D + 2 floats per
+            // query.  A lane holds a query's values - written from there every store would touch 64 records - so
+            // the wave turns 64 dims of its 32 records around in its own piece of LDS and writes two records' worth
+            // of 256-byte runs per store.
+            constexpr int RP = 64 + 4;
+            __shared__ __attribute__((aligned(16))) float sRec[4 * 32 * RP];
+            float* mine = sRec + w * (32 * RP);
+            const int rows = min(32, S - q_first);            // wave-uniform; <= 0: nothing of this wave's is live
+#pragma unroll
+            for (int half = 0; half < D / 64; half++) {
+#pragma unroll
+                for (int dd = 0; dd < 2; dd++)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; r4++) {
+                        const int dt = half * 2 + dd;
+                        *reinterpret_cast<v4f*>(mine + jq * RP + dd * 32 + 8 * r4 + 4 * g) =
+                            v4f{o[dt][4 * r4], o[dt][4 * r4 + 1], o[dt][4 * r4 + 2], o[dt][4 * r4 + 3]};
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int r0 = 0; r0 < rows; r0 += 2) {
+                    const int r = r0 + g;
+                    if (r < rows) {
+                        float* rec = ws + ((((size_t)b * S + q_first + r) * Hq + h) * nsplit + split) * (size_t)(D + 2);
+                        *reinterpret_cast<float2*>(rec + 2 + half * 64 + jq * 2) =
+                            *reinterpret_cast<const float2*>(mine + r * RP + jq * 2);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // read back before the next half overwrites
+            }
+            if (q_live && g == 0) {
+                float* rec = ws + ((((size_t)b * S + qi) * Hq + h) * nsplit + split) * (size_t)(D + 2);
+                rec[0] = m_run;
+                rec[1] = l_run;
+            }
+            return;
+        }
+    }
     if (!q_live) return;
     const size_t orow = ((size_t)b * S + qi) * Hq + h;
     if (nsplit == 1) {
