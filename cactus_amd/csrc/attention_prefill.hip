@@ -328,13 +328,19 @@ __device__ unsigned long long g_pf_trace[16 * 8];
 #define PF_T(var)
 #endif
 
-template <int D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// NWQ: waves (32 queries each) per group.  4: the 512-thread workgroup above.  2: 256 threads and 64 queries, for
+// launches that would not fill the chip with the larger workgroups - a tile's chain of key blocks is as long, but the
+// four waves then have a SIMD each when the launch is at most one workgroup per CU.  (Register budget as for
+// NWQ = 4: with the whole file the compiler parks the output accumulators in AGPRs and moves them around every rescale.)
+template <int D, int NWQ>
+__global__ __launch_bounds__(2 * NWQ * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attn_prefill_pp_kernel(const AttnArgs a) {
+    constexpr int GT = NWQ * 64;     // threads of a group
+    constexpr int QT = NWQ * 32;     // queries of a workgroup
     constexpr int KROW = D + 8;      // halves per K row: banks shift by 4 per row, the 16-byte row reads are conflict-free
     constexpr int VROW = D + 32;     // halves per V row: banks shift by 16 per row, the 4-row transposed reads are conflict-free
     constexpr int NDT = D / 32, NST = D / 16;
-    constexpr int PPT = (PF_BLOCK * D / 8) / 256;            // 16-byte pieces per thread of a group per operand
+    constexpr int PPT = (PF_BLOCK * D / 8) / GT;             // 16-byte pieces per thread of a group per operand
     constexpr int GRP_BYTES = PF_BLOCK * (KROW + VROW) * 2;  // one group's K and V block
     constexpr int NVAL = NDT * 16 + 2;                        // merged values per lane: O^T, m, l
     extern __shared__ __attribute__((aligned(16))) uint8_t pp_lds[];
@@ -342,13 +348,13 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     typedef __attribute__((address_space(3))) v4s* lds_v4s;
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = w >> 2, wq = w & 3, gtid = tid & 255;
+    const int grp = w / NWQ, wq = w % NWQ, gtid = tid % GT;
     const int jq = lane & 31, g = lane >> 5;
     const int S = (int)a.S, KV = (int)a.new_len, Hq = (int)a.Hq, Hkv = (int)a.Hkv;
     // Heaviest tiles first (one workgroup fills a CU; the dispatcher hands the next one to whichever CU finishes).
     // Workgroup ids go round the 8 XCDs: when the heads divide by 8 each XCD keeps its own heads, so a kv head's
     // rows stay in one L2.
-    const int nt = (S + PF_QTILE - 1) / PF_QTILE, hb = Hq * (int)a.B;
+    const int nt = (S + QT - 1) / QT, hb = Hq * (int)a.B;
     const int id = (int)blockIdx.x;
     int qt, hbi;
     if (hb % 8 == 0) {
@@ -361,7 +367,7 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     }
     const int h = hbi % Hq, b = hbi / Hq;
     const int kvh = h / (Hq / Hkv);
-    const int q_first = qt * PF_QTILE + wq * 32;
+    const int q_first = qt * QT + wq * 32;
     const int qi = q_first + jq;
     const bool q_live = qi < S;
     const long long off = (long long)a.position_offset;
@@ -369,7 +375,7 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     float scale = a.scale;
     if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);
 
-    const int q_last_wg = min(S, (qt + 1) * PF_QTILE) - 1, q_last_wave = min(S - 1, q_first + 31);
+    const int q_last_wg = min(S, (qt + 1) * QT) - 1, q_last_wave = min(S - 1, q_first + 31);
     const int kv_end_wg = a.is_causal ? (int)min((long long)KV, off + q_last_wg + 1) : KV;
     const int kv_end_wave = a.is_causal ? (int)min((long long)KV, off + q_last_wave + 1) : KV;
     const int nblk = (kv_end_wg + PF_BLOCK - 1) / PF_BLOCK;
@@ -397,7 +403,7 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     unsigned piece_off[PPT];
 #pragma unroll
     for (int p = 0; p < PPT; p++) {
-        const int idx = p * 256 + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
+        const int idx = p * GT + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
         piece_off[p] = (unsigned)(key * (int)kv_stride + d8 * 8) * 2u;
     }
     auto fetch_rows = [&](const uint16_t* base, int blk, v4i (&r)[PPT]) {
@@ -408,7 +414,7 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
         } else {
 #pragma unroll
             for (int p = 0; p < PPT; p++) {
-                const int idx = p * 256 + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
+                const int idx = p * GT + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
                 const int kp = max(0, min(blk * PF_BLOCK + key, KV - 1));
                 r[p] = *reinterpret_cast<const v4i*>(base + (size_t)kp * kv_stride + d8 * 8);
             }
@@ -417,7 +423,7 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     auto stash_rows = [&](uint16_t* dst, int row_halves, const v4i (&r)[PPT]) {
 #pragma unroll
         for (int p = 0; p < PPT; p++) {
-            const int idx = p * 256 + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
+            const int idx = p * GT + gtid, key = idx / (D / 8), d8 = idx % (D / 8);
             *reinterpret_cast<v4i*>(dst + key * row_halves + d8 * 8) = r[p];
         }
     };
@@ -536,7 +542,8 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     fetch_rows(Kb, blk0, kst);
     stash_rows(sK, KROW, kst);
     barrier();
-    if (grp == 1) barrier();            // group 1 runs half a period behind
+    constexpr bool LAG = NWQ == 4;      // waves that share SIMDs take turns; with a SIMD each the groups run in step
+    if (LAG && grp == 1) barrier();     // group 1 runs half a period behind
 #ifdef PF_TRACE
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
     const unsigned long long tr_c0 = clock64(), tr_r0 = wall_clock64();
@@ -572,7 +579,7 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
         asm volatile("s_nop 0" :: "v"(phi[0][0]), "v"(plo[1][7]), "v"(o[0][0]));
 #endif
         PF_T(t4);
-        if (!(grp == 1 && it == iters - 1)) barrier();
+        if (!(LAG && grp == 1 && it == iters - 1)) barrier();
 #ifdef PF_TRACE
         const unsigned long long t5 = __builtin_readcyclecounter();
         tr[0] += t1 - t0; tr[1] += t2 - t1; tr[2] += t3 - t2; tr[3] += t4 - t3; tr[4] += t5 - t4;
@@ -591,14 +598,14 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
         if (pv_pending) weighted_values();
         barrier();
         barrier();                       // group 1's state is in LDS
-        const float m1 = mrg[((NVAL - 2) * 4 + wq) * 64 + lane], l1 = mrg[((NVAL - 1) * 4 + wq) * 64 + lane];
+        const float m1 = mrg[((NVAL - 2) * NWQ + wq) * 64 + lane], l1 = mrg[((NVAL - 1) * NWQ + wq) * 64 + lane];
         if (m1 > -INFINITY) {            // the second half saw a key of this query: the chain of rescales went on
             const float f = __expf(m_run - m1);
             l_run = l_run * f + l1;
 #pragma unroll
             for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) o[dt][r] = o[dt][r] * f + mrg[((dt * 16 + r) * 4 + wq) * 64 + lane];
+                for (int r = 0; r < 16; r++) o[dt][r] = o[dt][r] * f + mrg[((dt * 16 + r) * NWQ + wq) * 64 + lane];
         }
     } else {
         barrier();                       // V of the last block is visible to the group
@@ -606,9 +613,9 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < NDT; dt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) mrg[((dt * 16 + r) * 4 + wq) * 64 + lane] = o[dt][r];
-        mrg[((NVAL - 2) * 4 + wq) * 64 + lane] = m_run;
-        mrg[((NVAL - 1) * 4 + wq) * 64 + lane] = l_run;
+            for (int r = 0; r < 16; r++) mrg[((dt * 16 + r) * NWQ + wq) * 64 + lane] = o[dt][r];
+        mrg[((NVAL - 2) * NWQ + wq) * 64 + lane] = m_run;
+        mrg[((NVAL - 1) * NWQ + wq) * 64 + lane] = l_run;
         barrier();
         return;
     }
@@ -629,9 +636,9 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
         }
 }
 
-template <int D>
+template <int D, int NWQ>
 constexpr size_t attn_prefill_pp_lds() {
-    return 2 * (size_t)PF_BLOCK * (D + 8 + D + 32) * 2 + (size_t)(D / 32 * 16 + 2) * 256 * sizeof(float);
+    return 2 * (size_t)PF_BLOCK * (D + 8 + D + 32) * 2 + (size_t)(D / 32 * 16 + 2) * (NWQ * 64) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1044,16 +1051,32 @@ hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
         if (!allowed[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefill_pp_kernel<128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_prefill_pp_lds<128>());
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefill_pp_kernel<64>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_prefill_pp_lds<64>());
-            if (e != hipSuccess) return e;
+            const void* fns[4] = {reinterpret_cast<const void*>(attn_prefill_pp_kernel<128, 4>),
+                                  reinterpret_cast<const void*>(attn_prefill_pp_kernel<64, 4>),
+                                  reinterpret_cast<const void*>(attn_prefill_pp_kernel<128, 2>),
+                                  reinterpret_cast<const void*>(attn_prefill_pp_kernel<64, 2>)};
+            const size_t lds[4] = {attn_prefill_pp_lds<128, 4>(), attn_prefill_pp_lds<64, 4>(), attn_prefill_pp_lds<128, 2>(),
+                                   attn_prefill_pp_lds<64, 2>()};
+            for (int i = 0; i < 4; i++) {
+                e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds[i]);
+                if (e != hipSuccess) return e;
+            }
             allowed[dev] = true;
         }
-        if (a.D == 128) attn_prefill_pp_kernel<128><<<grid, dim3(512), attn_prefill_pp_lds<128>(), st>>>(a);
-        else attn_prefill_pp_kernel<64><<<grid, dim3(512), attn_prefill_pp_lds<64>(), st>>>(a);
+        // 128-query workgroups when they fill the chip well; else 64-query workgroups, twice as many (S = 2048, 16
+        // heads = 256 of the large ones: 78 us against 66; S = 4096 = 512: 183 against 196)
+#ifndef PF_SMALL_TILE_BELOW
+#define PF_SMALL_TILE_BELOW 384
+#endif
+        if (total >= PF_SMALL_TILE_BELOW) {
+            if (a.D == 128) attn_prefill_pp_kernel<128, 4><<<grid, dim3(512), attn_prefill_pp_lds<128, 4>(), st>>>(a);
+            else attn_prefill_pp_kernel<64, 4><<<grid, dim3(512), attn_prefill_pp_lds<64, 4>(), st>>>(a);
+        } else {
+            const size_t total64 = ((a.S + 63) / 64) * a.Hq * a.B;
+            const dim3 grid64((unsigned)total64);
+            if (a.D == 128) attn_prefill_pp_kernel<128, 2><<<grid64, dim3(256), attn_prefill_pp_lds<128, 2>(), st>>>(a);
+            else attn_prefill_pp_kernel<64, 2><<<grid64, dim3(256), attn_prefill_pp_lds<64, 2>(), st>>>(a);
+        }
     }
     return hipGetLastError();
 }

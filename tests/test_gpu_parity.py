@@ -710,6 +710,8 @@ F16ATT = [
     (1, 128, 96, 8, 8, 128, 0, 0, False, False),     # 3 key blocks: the two wave groups take 2 and 1
     (1, 50, 32, 2, 1, 64, 0, 0, False, False),       # 1 key block: the second group has nothing
     (1, 2048, 2048, 2, 1, 128, 0, 0, True, False),   # 32 iterations per group on the last tile
+    (4, 130, 130, 32, 8, 128, 0, 0, True, False),    # 256 tiles of 128 queries: the 512-thread workgroups (fewer take 64-query ones)
+    (2, 200, 260, 64, 8, 64, 60, 0, True, False),    # ... head_dim 64, offset
     (1, 300, 300, 4, 1, 256, 0, 512, True, False),   # Gemma heads, a local layer's window longer than the prompt
     (2, 130, 200, 8, 4, 256, 70, 0, True, False),    # ... a global layer, offset
     (1, 75, 75, 4, 1, 256, 0, 0, False, False),      # ... non-causal, tail of 3
@@ -738,7 +740,8 @@ def test_attention_f16_vs_oracle(H, B, S, KV, Hq, Hkv, D, off, win, causal, use_
 def test_attention_f16_full_size(H):
     """A 4096-token causal prefill with Qwen3-0.6B heads: (a) query heads 0 and 9 against the oracle (their kv heads
     only), same tolerance as above; (b) the first 2048 queries see only the first 2048 keys, so they equal a 2048-token
-    call bit for bit (same tiles, same block order)."""
+    call - which runs 64-query workgroups, so the cut between the two wave groups' key ranges falls elsewhere and the
+    fp32 sums differ in order: at most one fp16 ulp apart, and equal in 99 % of the outputs."""
     S, Hq, Hkv, D = 4096, 16, 8, 128
     rng = np.random.default_rng(4096)
     q = rng.uniform(-1, 1, (1, S, Hq, D)).astype(np.float16)
@@ -751,7 +754,8 @@ def test_attention_f16_full_size(H):
         d = np.abs(f16(got[:, :, h:h + 1]) - f16(want))
         assert (d <= 2e-3 + 4e-3 * np.abs(f16(want))).all(), d.max()
     half = bits(H.attention_f16(dev(q[:, :2048]), dev(k[:, :2048]), dev(v[:, :2048]), 0.0, is_causal=True))
-    assert np.array_equal(half, got[:, :2048])
+    assert ulp_diff_f16(half, got[:, :2048]).max() <= 1
+    assert (half == got[:, :2048]).mean() >= 0.99
 
 
 def test_attention_long_context_properties(H):
