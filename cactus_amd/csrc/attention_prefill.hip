@@ -542,7 +542,10 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     fetch_rows(Kb, blk0, kst);
     stash_rows(sK, KROW, kst);
     barrier();
-    constexpr bool LAG = NWQ == 4;      // waves that share SIMDs take turns; with a SIMD each the groups run in step
+#ifndef PF_LAG
+#define PF_LAG 1
+#endif
+    constexpr bool LAG = NWQ == 4 && PF_LAG;   // waves that share SIMDs take turns; with a SIMD each the groups run in step
     if (LAG && grp == 1) barrier();     // group 1 runs half a period behind
 #ifdef PF_TRACE
     unsigned long long tr[5] = {0, 0, 0, 0, 0};
