@@ -78,7 +78,33 @@ __device__ __forceinline__ uint2 lds_read_tr16(uint32_t addr) {
     return r;
 }
 
-__device__ __forceinline__ float xor_lanes(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// Lanes l, l ^ 16 (and l ^ 32) combine a value on the vector ALU: v_permlane16_swap / v_permlane32_swap exchange the
+// odd 16-lane rows (upper 32 lanes) of the first operand with the even rows (lower 32) of the second, so from two
+// copies of x one result holds the even rows' values in both rows of a pair and the other the odd rows' - no trip
+// through the LDS crossbar as a shuffle takes.  Sum and maximum are symmetric, so both lanes get the same bits.
+__device__ __forceinline__ float pair16_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair32_max(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair16_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pair32_sum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// the four lanes l % 16 + {0, 16, 32, 48}
+__device__ __forceinline__ float quad_rows_max(float x) { return pair32_max(pair16_max(x)); }
+__device__ __forceinline__ float quad_rows_sum(float x) { return pair32_sum(pair16_sum(x)); }
 
 struct DecodeParams {
     AttnArgs a;
@@ -224,8 +250,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         }
 #pragma unroll
         for (int n = 0; n < NG; n++) {
-            qsum[n] += xor_lanes(qsum[n], 16);
-            qsum[n] += xor_lanes(qsum[n], 32);
+            qsum[n] = quad_rows_sum(qsum[n]);
         }
     }
     float nqsum[NG];        // per scale group: the group's scores are rescaled separately
@@ -372,8 +397,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         // ---- online softmax, per head (lane % 16); a head's 32 keys sit in its 4 lanes (q = 0..3)
         float bm = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
                          fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-        bm = fmaxf(bm, xor_lanes(bm, 16));
-        bm = fmaxf(bm, xor_lanes(bm, 32));
+        bm = quad_rows_max(bm);
         // the V image's transposed reads: in flight while the weights are computed
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -495,8 +519,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     }
 
     // ---- this wave's state -> LDS (the ring is idle now), then the workgroup's merge
-    l_part += xor_lanes(l_part, 16);
-    l_part += xor_lanes(l_part, 32);
+    l_part = quad_rows_sum(l_part);
 #pragma unroll
     for (int c = 0; c < NC; c++)
 #pragma unroll
@@ -520,8 +543,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 #pragma unroll
             for (int e = 0; e < 8; e++) part = fmaf((float)qreg[st][e], (float)kv[e], part);
         }
-        part += xor_lanes(part, 16);
-        part += xor_lanes(part, 32);
+        part = quad_rows_sum(part);
         const float s2 = part * scale2;
         const float mn = fmaxf(m_run, s2 - 6.0f);
         const float corr = __builtin_amdgcn_exp2f(m_run - mn), pt = __builtin_amdgcn_exp2f(s2 - mn);
