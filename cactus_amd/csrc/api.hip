@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -113,7 +114,26 @@ int noalloc_scratch(void** out) {
 // byte offsets whose top bit marks "out of range": the whole matrix must lie below 2 GiB.  Larger
 // ones take the tile kernel (64-bit tile bases).
 bool skinny_addressable(bool int4, size_t K, size_t N) {
-    return N * (int4 ? K / 2 : K) < (size_t(1) << 31);
+    return ((N + 15) & ~size_t(15)) * (int4 ? K / 2 : K) < (size_t(1) << 31);
+}
+
+// Tile-major twins of row-major weight matrices (cactus_hip_weights_pack_dev): the streaming kernels read the
+// twin when the matrix a call names has one of the call's shape.  Keyed by the row-major device pointer.
+struct PackedTwin {
+    void* ptr;
+    size_t N, K;
+    bool int4;
+};
+std::mutex g_pk_mu;
+std::unordered_map<const void*, PackedTwin> g_pk;
+std::atomic<size_t> g_pk_count{0};
+
+const void* packed_twin(const void* B, bool int4, size_t K, size_t N) {
+    if (g_pk_count.load(std::memory_order_relaxed) == 0) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    auto it = g_pk.find(B);
+    if (it == g_pk.end() || it->second.int4 != int4 || it->second.K != K || it->second.N != N) return nullptr;
+    return it->second.ptr;
 }
 
 int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const cactus_half_t* Bs,
@@ -139,8 +159,10 @@ int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const c
     // streaming kernel, where every 16 weight rows re-read the activations (measured: N = 12288, K = 4096 12.6
     // against 15.9 us; N = 151936, K = 1024 44.4 against 51.4 us; narrower matrices and fewer rows the other way)
     const bool wide_rows = !int4 && M >= 12 && N >= 12288 && gsums == nullptr && C != nullptr;
-    if (tiled_ok && M <= 16 && !wide_rows && (!int4 || K % 256 == 0) && skinny_addressable(int4, K, N))
-        e = launch_matmul_skinny(int4, A, As, B, Bs, C, gsums, M, K, N, S(stream));
+    if (tiled_ok && M <= 16 && !wide_rows && (!int4 || K % 256 == 0) && skinny_addressable(int4, K, N)) {
+        const void* twin = packed_twin(B, int4, K, N);
+        e = launch_matmul_skinny(int4, A, As, twin ? twin : B, Bs, C, gsums, M, K, N, S(stream), twin != nullptr);
+    }
     else if (tiled_ok)
         e = launch_matmul_gemm(int4, A, As, B, Bs, C, gsums, M, K, N, S(stream));
     else
@@ -158,7 +180,8 @@ int matmul_q_f16act(bool int4, const cactus_half_t* X, const void* B, const cact
     if (gs == 128 && K % 128 == 0 && aligned(X, 16) && aligned(B, 16) && aligned(Bs, 2) &&
         K < (size_t(1) << 30) && N < (size_t(1) << 30) && skinny_addressable(int4, K, N) &&
         skinny_fused_quant_ok(int4, M, K)) {
-        hipError_t e = launch_matmul_skinny_fq(int4, X, nullptr, B, Bs, C, M, K, N, S(stream));
+        const void* twin = packed_twin(B, int4, K, N);
+        hipError_t e = launch_matmul_skinny_fq(int4, X, nullptr, twin ? twin : B, Bs, C, M, K, N, S(stream), twin != nullptr);
         if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_f16act launch", e);
         return CACTUS_HIP_OK;
     }
@@ -186,7 +209,8 @@ int matmul_q_f16act_batch(bool int4, const cactus_hip_matmul_problem* pr, size_t
                         q.K < (size_t(1) << 30) && q.N < (size_t(1) << 30) && skinny_addressable(int4, q.K, q.N) &&
                         skinny_fused_quant_ok(int4, q.M, q.K);
         if (ok) {
-            fused.push_back(SkinnyProblem{q.X, q.B, q.B_scales, q.C, q.M, q.K, q.N});
+            const void* twin = packed_twin(q.B, int4, q.K, q.N);
+            fused.push_back(SkinnyProblem{q.X, twin ? twin : q.B, q.B_scales, q.C, q.M, q.K, q.N, twin != nullptr});
         } else {
             int rc = matmul_q_f16act(int4, q.X, q.B, q.B_scales, q.C, q.M, q.K, q.N, gs, stream);
             if (rc != CACTUS_HIP_OK) return rc;
@@ -269,6 +293,62 @@ int cactus_hip_synchronize(void* stream) {
 int cactus_hip_workspace_reserve(size_t bytes) {
     void* ws = nullptr;
     return workspace(bytes, &ws);
+}
+
+int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int int4, void* stream) {
+    if (!B || N == 0 || K == 0) return fail(CACTUS_HIP_EINVAL, "weights_pack: null or empty matrix");
+    if (K % (int4 ? 256 : 128) != 0) return fail(CACTUS_HIP_EINVAL, "weights_pack: K must be a multiple of 128 (INT4: 256)");
+    if (!aligned(B, 16)) return fail(CACTUS_HIP_EINVAL, "weights_pack: matrix must be 16-byte aligned");
+    if (!skinny_addressable(int4 != 0, K, N)) return fail(CACTUS_HIP_EINVAL, "weights_pack: matrix of 2 GiB or more");
+    const size_t bytes = ((N + 15) & ~size_t(15)) * (int4 ? K / 2 : K);
+    void* twin = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        auto it = g_pk.find(B);
+        if (it != g_pk.end() && it->second.N == N && it->second.K == K && it->second.int4 == (int4 != 0))
+            twin = it->second.ptr;                    // packed before: refresh the twin in place
+        else if (it != g_pk.end())
+            return fail(CACTUS_HIP_EINVAL, "weights_pack: this address is packed with another shape; release it first");
+    }
+    const bool fresh = twin == nullptr;
+    if (fresh && hipMalloc(&twin, bytes) != hipSuccess) return fail(CACTUS_HIP_ENOMEM, "weights_pack hipMalloc");
+    hipError_t e = launch_pack_weights(int4 != 0, B, twin, K, N, S(stream));
+    if (e != hipSuccess) {
+        if (fresh) (void)hipFree(twin);
+        return fail(CACTUS_HIP_ERUNTIME, "weights_pack launch", e);
+    }
+    if (fresh) {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        g_pk[B] = PackedTwin{twin, N, K, int4 != 0};
+        g_pk_count.store(g_pk.size(), std::memory_order_relaxed);
+    }
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_weights_release_packed_dev(const void* B) {
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pk_mu);
+        if (B == nullptr) {
+            for (auto& kv : g_pk) drop.push_back(kv.second.ptr);
+            g_pk.clear();
+        } else {
+            auto it = g_pk.find(B);
+            if (it != g_pk.end()) {
+                drop.push_back(it->second.ptr);
+                g_pk.erase(it);
+            }
+        }
+        g_pk_count.store(g_pk.size(), std::memory_order_relaxed);
+    }
+    if (!drop.empty()) HIP_TRY(hipDeviceSynchronize());   // launches that read a twin may still be in flight
+    for (void* p : drop) (void)hipFree(p);
+    return CACTUS_HIP_OK;
+}
+
+int cactus_hip_weights_is_packed_dev(const void* B) {
+    std::lock_guard<std::mutex> lk(g_pk_mu);
+    return g_pk.find(B) != g_pk.end() ? 1 : 0;
 }
 
 int cactus_hip_matmul_int8_dev(const int8_t* A, const float* A_scales, const int8_t* B,
@@ -378,7 +458,10 @@ int matmul_q_produced(bool int4, int kind, const cactus_half_t* x, const cactus_
         fused = wt[i].N > 0 && wt[i].N < (size_t(1) << 30) && aligned(wt[i].B, 16) && skinny_addressable(int4, K, wt[i].N);
     if (fused) {
         SkinnyProblem pr[16];
-        for (size_t i = 0; i < count; i++) pr[i] = SkinnyProblem{x, wt[i].B, wt[i].B_scales, wt[i].C, M, K, wt[i].N};
+        for (size_t i = 0; i < count; i++) {
+            const void* twin = packed_twin(wt[i].B, int4, K, wt[i].N);
+            pr[i] = SkinnyProblem{x, twin ? twin : wt[i].B, wt[i].B_scales, wt[i].C, M, K, wt[i].N, twin != nullptr};
+        }
         hipError_t e = launch_matmul_skinny_fq_batch_pro(int4, kind, pr, count, x2, w, kind == 1 && x2 ? sum_out : nullptr,
                                                          eps, S(stream));
         if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul with produced activations launch", e);

@@ -47,16 +47,19 @@ hipError_t launch_unpack_int4(const uint8_t* packed, int8_t* unpacked, size_t co
 
 // matmul_skinny.hip: M <= 16, group_size == 128.  B is int8[N,K] or packed uint8[N,K/2].
 // If gsums != nullptr the kernel also writes the INT32 group sums [M,N,G]; C may then be null.
+// packed: B is the tile-major twin that launch_pack_weights made of the row-major matrix (matmul_skinny.hip).
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
-                                size_t K, size_t N, hipStream_t st);
+                                size_t K, size_t N, hipStream_t st, bool packed = false);
+// packed must hold ((N + 15) & ~15) * (int4 ? K / 2 : K) bytes; K a multiple of 128 (INT4: 256)
+hipError_t launch_pack_weights(bool int4, const void* B, void* packed, size_t K, size_t N, hipStream_t st);
 
 // FP16 activations quantized inside the GEMV kernel (one launch).  Only for shapes
 // skinny_fused_quant_ok accepts (M <= 4, activations + group sums fit LDS); scales_out may be null.
 bool skinny_fused_quant_ok(bool int4, size_t M, size_t K);
 hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
                                    const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
-                                   hipStream_t st);
+                                   hipStream_t st, bool packed = false);
 
 // One launch for up to 16 independent FP16-activation matmuls (each skinny_fused_quant_ok).
 struct SkinnyProblem {
@@ -65,6 +68,7 @@ struct SkinnyProblem {
     const uint16_t* Bs;
     uint16_t* C;
     size_t M, K, N;
+    bool packed = false;   // B is the tile-major twin
 };
 hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* problems, size_t count, hipStream_t st);
 

@@ -60,6 +60,27 @@ __device__ __forceinline__ v4i buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned vo
     return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
 
+// the same with a wave-uniform byte offset in an SGPR (added after the range check of voff: callers only add it to
+// offsets of whole units that lie inside the buffer)
+template <int AUX>
+__device__ __forceinline__ v4i buf_load_s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, AUX);
+    return v4i{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+}
+
+// Tile-major weights ("packed twin", pack_weights_kernel below).  Row-major [N, K] makes every wave instruction of
+// the stream touch 16 separate 64-byte segments, one per weight row.  The twin stores tile t = rows 16 t .. 16 t + 15
+// as one contiguous run of K / 128 units (INT4: K / 256) of 2 KB; a unit is two 1 KB halves, and the 16-byte piece of
+// lane l = 16 q + r in half h is row r's bytes [128 u + 64 h + 16 q, + 16) - exactly what that lane feeds the MFMA -
+// so a wave instruction reads 1 KB of consecutive bytes and a workgroup walks one contiguous stretch of memory
+// (measured on a read-only kernel over 240 MB: 6.7 TB/s in this shape against 5.3-5.5 in 16-row units).  Rows past N
+// are zero rows of the last tile.  The kernels take `pk` at run time: it only changes three address terms.
+struct PkAddr {
+    unsigned ustride;   // bytes from one unit of a lane's stream to the next
+    unsigned half;      // bytes from the first to the second load of a unit
+};
+__device__ __forceinline__ PkAddr pk_addr(bool pk) { return pk ? PkAddr{2048u, 1024u} : PkAddr{128u, 64u}; }
+
 template <bool INT4, bool ALDS>
 struct UnitRegs {
     v4i b[2];
@@ -75,7 +96,7 @@ __device__ __forceinline__ void skinny_body(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales,
     const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
     uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
-    int ablate, int tile) {
+    int ablate, int tile, bool pk) {
     constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
     extern __shared__ __attribute__((aligned(16))) float sk_lds[];
     // Rows are padded by 4 floats: 16-byte aligned for the chain's ds_read_b128, and the 16
@@ -93,12 +114,15 @@ __device__ __forceinline__ void skinny_body(
     const int q = lane >> 4;   // k block of the MFMA operand
     const int n0 = tile * SK_TN;
     const unsigned row_bytes = INT4 ? (unsigned)K / 2 : (unsigned)K;
+    const PkAddr pa = pk_addr(pk);
+    const unsigned nrows = pk ? (unsigned)((N + 15) & ~15) : (unsigned)N;   // the twin holds whole tiles
     const __amdgpu_buffer_rsrc_t brsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)(nrows * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t arsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(A), 0, M * K, 0x00020000);
     // per-lane byte offsets; rows past the end are pushed out of range and read as zero
-    const unsigned boff = (n0 + r < N) ? (unsigned)(n0 + r) * row_bytes + q * 16 : SK_OOB;
+    const unsigned boff = pk ? ((unsigned)n0 < nrows ? (unsigned)n0 * row_bytes + lane * 16 : SK_OOB)
+                             : ((n0 + r < N) ? (unsigned)(n0 + r) * row_bytes + q * 16 : SK_OOB);
     const unsigned aoff = (r < M) ? (unsigned)r * K + (INT4 ? q * 32 : q * 16) : SK_OOB;
     const int arow = min(r, M - 1);
     const int8_t* aptr_lds = lds_a + (size_t)arow * K + (INT4 ? q * 32 : q * 16);
@@ -109,9 +133,9 @@ __device__ __forceinline__ void skinny_body(
 
     // u: unit index in the row; units >= nunits are read as zeros (no memory traffic)
     auto load_unit = [&](int u, UnitRegs<INT4, ALDS>& R) {
-        const unsigned uo = (u < nunits) ? (unsigned)u * 128u : SK_OOB;
+        const unsigned uo = (u < nunits) ? (unsigned)u * pa.ustride : SK_OOB;
         R.b[0] = buf_load<2>(brsrc, boff + uo, 0);
-        R.b[1] = buf_load<2>(brsrc, boff + uo, 64);
+        R.b[1] = buf_load_s<2>(brsrc, boff + uo, pa.half);
         if constexpr (!ALDS) {
             const unsigned ao = (u < nunits) ? (unsigned)u * (INT4 ? 256u : 128u) : SK_OOB;
             if constexpr (INT4) {
@@ -319,9 +343,9 @@ __global__ __launch_bounds__(W * 64) void skinny_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ A_scales,
     const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
     uint16_t* __restrict__ C, int32_t* __restrict__ gsums, int M, int K, int N, int G, int SC,
-    int ablate) {
+    int ablate, int pk) {
     skinny_body<INT4, W, P, ALDS, GS>(A, A_scales, B, B_scales, C, gsums, M, K, N, G, SC, ablate,
-                                          (int)blockIdx.x);
+                                          (int)blockIdx.x, pk != 0);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -391,7 +415,7 @@ template <bool INT4, int W, int P, int CT, int PRO = 0, bool WT = false>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
                                         uint16_t* __restrict__ C, int M, int K, int N, int tl,
-                                        int t, float* __restrict__ sk_lds, const FqPro pro = FqPro()) {
+                                        int t, float* __restrict__ sk_lds, bool pk, const FqPro pro = FqPro()) {
     // t: thread index among the W waves that share the tile; sk_lds: their LDS region.  A workgroup
     // may hold several such wave groups (tiles of one problem, same barrier sequence).
     constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
@@ -413,8 +437,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     const int r = lane & 15, q = lane >> 4;
     const int wtile = WT ? tl * W + w : tl;       // the tile whose weights this wave reads
     const unsigned row_bytes = INT4 ? (unsigned)K / 2 : (unsigned)K;
+    const PkAddr pa = pk_addr(pk);
+    const unsigned nrows = pk ? (unsigned)((N + 15) & ~15) : (unsigned)N;   // the twin holds whole tiles
     const __amdgpu_buffer_rsrc_t brsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)((unsigned)N * row_bytes), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(B), 0, (int)(nrows * row_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(X), 0, 2 * M * K, 0x00020000);
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -435,14 +461,16 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
         const int n = wtile * TR + ct * SK_TN + r;
-        boff.o[ct] = (n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB;
+        const unsigned nt0 = (unsigned)(wtile * TR + ct * SK_TN);
+        boff.o[ct] = pk ? (nt0 < nrows ? nt0 * row_bytes + lane * 16 : SK_OOB)
+                        : ((n < N) ? (unsigned)n * row_bytes + q * 16 : SK_OOB);
     }
     auto load_unit = [&](int u, const Boff& bo, Unit& R) {
-        const unsigned uo = (u < nunits) ? (unsigned)u * 128u : SK_OOB;
+        const unsigned uo = (u < nunits) ? (unsigned)u * pa.ustride : SK_OOB;
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             R.b[ct][0] = buf_load<2>(brsrc, bo.o[ct] + uo, 0);
-            R.b[ct][1] = buf_load<2>(brsrc, bo.o[ct] + uo, 64);
+            R.b[ct][1] = buf_load_s<2>(brsrc, bo.o[ct] + uo, pa.half);
         }
     };
     // this thread's chunks of 8 scales of the tile (fast path: chunk t + j*W*64), else out of range
@@ -774,9 +802,9 @@ __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __res
                                                           float* __restrict__ scales_out,
                                                           const uint8_t* __restrict__ B,
                                                           const uint16_t* __restrict__ B_scales,
-                                                          uint16_t* __restrict__ C, int M, int K, int N) {
+                                                          uint16_t* __restrict__ C, int M, int K, int N, int pk) {
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
-    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, (int)blockIdx.x, (int)threadIdx.x, fq_lds);
+    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, (int)blockIdx.x, (int)threadIdx.x, fq_lds, pk != 0);
 }
 
 // Several independent FP16-activation matmuls (M <= 4 each) in one launch: the projections
@@ -795,6 +823,7 @@ struct SkinnyBatch {
     const uint16_t* Bs[SK_MAXB];
     uint16_t* C[SK_MAXB];
     int M[SK_MAXB], K[SK_MAXB], N[SK_MAXB];
+    unsigned pk_mask;               // bit i: problem i's B is the tile-major twin
     FqPro pro;                      // producer prologue operands (shared by every problem of the launch)
 };
 
@@ -818,7 +847,7 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
     fq_body<INT4, W, P, CT>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                         reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
-                        bt.N[pi], tile, (int)threadIdx.x, fq_lds);
+                        bt.N[pi], tile, (int)threadIdx.x, fq_lds, (bt.pk_mask >> pi) & 1u);
 }
 
 // The batched launch with wave tiles: a workgroup of 4 waves quantizes its problem's activation rows once
@@ -832,7 +861,7 @@ __global__ __launch_bounds__(256) void skinny_batch_wave_kernel(const SkinnyBatc
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
     fq_body<INT4, 4, INT4 ? 4 : 8, 1, 0, true>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                                     reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi],
-                                    bt.K[pi], bt.N[pi], tile4, (int)threadIdx.x, fq_lds);
+                                    bt.K[pi], bt.N[pi], tile4, (int)threadIdx.x, fq_lds, (bt.pk_mask >> pi) & 1u);
 }
 
 // The same launch with a workgroup of 4 waves split into 4 / wt wave groups, each on its own tile:
@@ -855,9 +884,36 @@ __global__ __launch_bounds__(256) void skinny_batch_sub_kernel(const SkinnyBatch
     float* lds = fq_lds + (size_t)sub * bt.lds_floats[pi];
     const uint16_t* X = reinterpret_cast<const uint16_t*>(bt.X[pi]);
     const uint8_t* B = reinterpret_cast<const uint8_t*>(bt.B[pi]);
-    if (wt == 1) fq_body<INT4, 1, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, bt.pro);
-    else if (wt == 2) fq_body<INT4, 2, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, bt.pro);
-    else fq_body<INT4, 4, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, bt.pro);
+    const bool pk = (bt.pk_mask >> pi) & 1u;
+    if (wt == 1) fq_body<INT4, 1, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro);
+    else if (wt == 2) fq_body<INT4, 2, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro);
+    else fq_body<INT4, 4, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro);
+}
+
+// Row-major weights -> the tile-major twin (layout above); one thread per 16-byte piece.  rows16: rows of the twin
+// (N rounded up to 16); pieces of rows past N are zeros.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                           size_t N, size_t rows16, size_t row_bytes) {
+    const size_t units = row_bytes / 128;
+    const size_t total = rows16 * row_bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t lane = i & 63, h = (i >> 6) & 1, u = (i >> 7) % units, tile = (i >> 7) / units;
+        const size_t r = lane & 15, q = lane >> 4, n = tile * 16 + r;
+        v4i v = {0, 0, 0, 0};
+        if (n < N) v = *reinterpret_cast<const v4i*>(src + n * row_bytes + u * 128 + h * 64 + q * 16);
+        *reinterpret_cast<v4i*>(dst + i * 16) = v;
+    }
+}
+
+hipError_t launch_pack_weights(bool int4, const void* B, void* packed, size_t K, size_t N, hipStream_t st) {
+    const size_t row_bytes = int4 ? K / 2 : K;
+    if (row_bytes == 0 || row_bytes % 128 != 0 || N == 0) return hipErrorInvalidValue;
+    const size_t rows16 = (N + 15) & ~size_t(15);
+    const size_t total = rows16 * row_bytes / 16;
+    const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+    pack_weights_kernel<<<grid, 256, 0, st>>>(static_cast<const uint8_t*>(B), static_cast<uint8_t*>(packed), N, rows16,
+                                              row_bytes);
+    return hipGetLastError();
 }
 
 int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
@@ -870,12 +926,12 @@ namespace {
 
 template <bool INT4, int W, int P, bool ALDS>
 hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, const uint16_t* B_scales,
-                      uint16_t* C, int32_t* gsums, size_t M, size_t K, size_t N, hipStream_t st) {
+                      uint16_t* C, int32_t* gsums, size_t M, size_t K, size_t N, hipStream_t st, bool pk = false) {
     const float* A_scales = A_scales_c;
     const int G = (int)(K / 128);
     constexpr int GPU_ = INT4 ? 2 : 1;
     if (INT4 && (G & 1)) return hipErrorInvalidValue;   // packed units hold two groups
-    if (N * (INT4 ? K / 2 : K) > (size_t(1) << 31) || M * K > (size_t(1) << 31)) return hipErrorInvalidValue;
+    if (((N + 15) & ~size_t(15)) * (INT4 ? K / 2 : K) > (size_t(1) << 31) || M * K > (size_t(1) << 31)) return hipErrorInvalidValue;
     // chunk of groups whose sums fit a 16 KB (M <= 4) / 32 KB LDS budget: a multiple of W units
     const int step = W * GPU_;
 #ifndef SK_GS_KB
@@ -905,10 +961,10 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, c
     }
     if (gsums != nullptr)
         skinny_kernel<INT4, W, P, ALDS, true><<<grid, block, lds, st>>>(
-            A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
+            A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate, (int)pk);
     else
         skinny_kernel<INT4, W, P, ALDS, false><<<grid, block, lds, st>>>(
-            A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate);
+            A, A_scales, (const uint8_t*)B, B_scales, C, gsums, (int)M, (int)K, (int)N, G, SC, g_skinny_ablate, (int)pk);
     return hipGetLastError();
 }
 
@@ -957,9 +1013,10 @@ static void fq_shape(bool int4, size_t kmax, size_t rows16, int* W_out, int* ct_
 int g_skinny_ct = 1;    // benchmarks only: column tiles per tile of the 2xxxx variants
 
 static hipError_t launch_fq(bool int4, int W, int ct, const uint16_t* X, float* scales_out, const void* B,
-                            const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N, hipStream_t st) {
+                            const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N, hipStream_t st,
+                            bool pk = false) {
     if (!skinny_fused_quant_ok(int4, M, K)) return hipErrorInvalidValue;
-    if (N * (int4 ? K / 2 : K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+    if (((N + 15) & ~size_t(15)) * (int4 ? K / 2 : K) > (size_t(1) << 31)) return hipErrorInvalidValue;
     if (ct != SK_CT || W < 2 || fq_lds_bytes(int4, W, ct, M, K) > 64 * 1024) ct = 1;
     const size_t lds = fq_lds_bytes(int4, W, ct, M, K);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
@@ -967,7 +1024,7 @@ static hipError_t launch_fq(bool int4, int W, int ct, const uint16_t* X, float* 
     const dim3 grid((unsigned)tiles), block(W * 64);
 #define FQ_LAUNCH(I4, WW, CC)                                                                                     \
     skinny_fq_kernel<I4, WW, 4, CC><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C,       \
-                                                             (int)M, (int)K, (int)N)
+                                                             (int)M, (int)K, (int)N, (int)pk)
 #define FQ_CASE(WW)                                                        \
     case WW:                                                                \
         if (ct == 2 && WW >= 2) {                                           \
@@ -993,14 +1050,16 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
                                         size_t M, size_t K, size_t N, hipStream_t st) {
 #define SK_CASE(WW, PP)                                                                                \
     case WW * 100 + PP:                                                                                 \
-        return int4 ? launch_cfg<true, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)  \
-                    : launch_cfg<false, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st); \
+        return int4 ? launch_cfg<true, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st, pk)  \
+                    : launch_cfg<false, WW, PP, false>(A, A_scales, B, B_scales, C, gsums, M, K, N, st, pk); \
     case 10000 + WW * 100 + PP:                                                                         \
-        return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st)   \
-                    : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st);
+        return int4 ? launch_cfg<true, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st, pk)   \
+                    : launch_cfg<false, WW, PP, true>(A, A_scales, B, B_scales, C, gsums, M, K, N, st, pk);
+    bool pk = false;                           // + 40000: B is the tile-major twin
+    if (variant >= 40000 && variant < 80000) { pk = true; variant -= 40000; }
     if (variant >= 20000 && variant < 30000)   // fused quantization: A holds FP16 activations; W from the code
         return launch_fq(int4, (variant - 20000) / 100, g_skinny_ct, reinterpret_cast<const uint16_t*>(A), nullptr, B,
-                         B_scales, C, M, K, N, st);
+                         B_scales, C, M, K, N, st, pk);
     switch (variant) {
         SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
         SK_CASE(16, 2) SK_CASE(16, 4) SK_CASE(2, 4) SK_CASE(2, 8) SK_CASE(8, 1) SK_CASE(4, 1) SK_CASE(2, 2)
@@ -1020,14 +1079,14 @@ static bool wave_tiles_pay(bool int4, size_t K, size_t tiles) {
 
 hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_out, const void* B,
                                    const uint16_t* B_scales, uint16_t* C, size_t M, size_t K, size_t N,
-                                   hipStream_t st) {
+                                   hipStream_t st, bool packed) {
     if (scales_out == nullptr && wave_tiles_pay(int4, K, (N + SK_TN - 1) / SK_TN)) {
-        const SkinnyProblem one{X, B, B_scales, C, M, K, N};     // wave tiles (the batched launch decides)
+        const SkinnyProblem one{X, B, B_scales, C, M, K, N, packed};     // wave tiles (the batched launch decides)
         return launch_matmul_skinny_fq_batch(int4, &one, 1, st);
     }
     int W, ct;
     fq_shape(int4, K, (N + SK_TN - 1) / SK_TN, &W, &ct);
-    return launch_fq(int4, W, ct, X, scales_out, B, B_scales, C, M, K, N, st);
+    return launch_fq(int4, W, ct, X, scales_out, B, B_scales, C, M, K, N, st, packed);
 }
 
 // Batched fused launch: every problem must satisfy skinny_fused_quant_ok and the alignment the
@@ -1059,7 +1118,8 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     for (size_t i = 0; i < count; i++) {
         const SkinnyProblem& q = pr[order[i]];
         if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
-        if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+        if (((q.N + 15) & ~size_t(15)) * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+        if (q.packed) bt.pk_mask |= 1u << i;
         const size_t l = fq_lds_bytes(int4, W, ct, q.M, q.K);
         if (l > 64 * 1024) return hipErrorInvalidValue;
         if (l > lds) lds = l;
@@ -1166,7 +1226,8 @@ hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyPr
         const SkinnyProblem& q = pr[order[i]];
         if (q.X != pr[0].X || q.M != pr[0].M || q.K != pr[0].K) return hipErrorInvalidValue;   // one activation matrix
         if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
-        if (q.N * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+        if (((q.N + 15) & ~size_t(15)) * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
+        if (q.packed) bt.pk_mask |= 1u << i;
         const size_t kb = int4 ? q.K / 2 : q.K;
         const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
         size_t l = fq_lds_bytes(int4, wt, 1, q.M, q.K) + 16;            // + the rows' 1 / rms
@@ -1206,7 +1267,7 @@ bool skinny_fq_pro_ok(bool int4, int kind, size_t M, size_t K) {
 
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
-                                size_t K, size_t N, hipStream_t st) {
+                                size_t K, size_t N, hipStream_t st, bool packed) {
     // Measured on MI355X (scripts/gemv_bench): ring depth 4 everywhere; about 4 units per wave,
     // i.e. short rows get few waves per tile (more, smaller workgroups in flight) and long rows 8.
     const size_t nu = K / (int4 ? 256 : 128);
@@ -1216,8 +1277,8 @@ hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scale
     const size_t G = K / 128;
     const size_t lds_alds = (M * 16 * (G + 8 + 4) + 16 * (G + 8)) * sizeof(float) + M * K;
     const bool alds = M <= 4 && lds_alds <= 60 * 1024;
-    return launch_matmul_skinny_variant((alds ? 10000 : 0) + W * 100 + 4, int4, A, A_scales, B, B_scales, C,
-                                        gsums, M, K, N, st);
+    return launch_matmul_skinny_variant((alds ? 10000 : 0) + W * 100 + 4 + (packed ? 40000 : 0), int4, A, A_scales, B,
+                                        B_scales, C, gsums, M, K, N, st);
 }
 
 }  // namespace cactus_hip

@@ -33,6 +33,9 @@ SIGNATURES = {
     "cactus_hip_synchronize": (_i, [_vp]),
     "cactus_hip_release_weights": (None, [_vp]),
     "cactus_hip_workspace_reserve": (_i, [_sz]),
+    "cactus_hip_weights_pack_dev": (_i, [_vp, _sz, _sz, _i, _vp]),
+    "cactus_hip_weights_release_packed_dev": (_i, [_vp]),
+    "cactus_hip_weights_is_packed_dev": (_i, [_vp]),
     "cactus_hip_matmul_int8_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -154,6 +157,27 @@ def _dev(t, dtype):
 
 def init(device=0):
     _check(lib.cactus_hip_init(device))
+
+
+def pack_weights(B):
+    """Give the device-resident weight matrix B (int8 [N, K] or packed uint8 [N, K/2]) a tile-major twin: every
+    later matmul with M <= 16 that names B streams the twin (cactus_hip_weights_pack_dev).  B must stay alive and
+    unchanged until release_packed(B)."""
+    int4 = B.dtype == torch.uint8
+    _dev(B, torch.uint8 if int4 else torch.int8)
+    N = B.shape[0]
+    K = B.shape[1] * (2 if int4 else 1)
+    _check(lib.cactus_hip_weights_pack_dev(_p(B), N, K, int(int4), _stream()))
+    return B
+
+
+def release_packed(B=None):
+    """Drop B's twin (all twins when B is None)."""
+    _check(lib.cactus_hip_weights_release_packed_dev(_p(B)))
+
+
+def is_packed(B):
+    return bool(lib.cactus_hip_weights_is_packed_dev(_p(B)))
 
 
 def quantize_activations(x, out_q=None, out_scales=None):

@@ -75,6 +75,21 @@ int   cactus_hip_workspace_reserve(size_t bytes);
  * registered under host_ptr on the current device). */
 void cactus_hip_release_weights(const void* host_ptr);
 
+/* Tile-major twins of device-resident weights.  No counterpart in the reference, whose weights stay in the
+ * row-major [N, K] layout of its files (graph_io.cpp:49-73); the matmul entries below keep taking that layout.
+ * Call this once when a quantized weight matrix (B int8[N, K], or packed uint8[N, K/2] with int4 != 0) has been
+ * made resident: the library allocates a second copy in which every 16 rows x 128 bytes unit of the streaming
+ * kernels is one contiguous 2 KB run (a whole 16-row tile is one contiguous stretch), and every later call with
+ * M <= 16 rows that names B with the same N and K (the _dev matmuls, their _f16act, _batch, _norm / _silu /
+ * _gelu forms) reads the twin instead: same integer sums, same fp32 chain, same bits, about a fifth less
+ * time.  Launches with more rows read B itself, which must stay as it is.  B must not change while it has a
+ * twin: call again to refresh the twin after rewriting B, or release it.  The call allocates (not under stream
+ * capture); K a multiple of 128 (INT4: 256), B 16-byte aligned and below 2 GiB.  release(NULL) drops every twin;
+ * release synchronizes the device before it frees. */
+int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int int4, void* stream);
+int cactus_hip_weights_release_packed_dev(const void* B);
+int cactus_hip_weights_is_packed_dev(const void* B);
+
 /* ------------------------------------------------- device-resident hot path */
 
 /* cactus_matmul_int8 (kernel.h:41-43; kernel_gemm.cpp:128-327).
