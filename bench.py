@@ -49,12 +49,17 @@ def gemv_bytes(M, K, N, int4=False, fused_quant=True):
     return w + 2 * N * (K // 128) + act + 2 * M * N
 
 
-def make_weights(K, N, int4, gen):
+def make_weights(K, N, int4, gen, pack=False):
+    """Row-major weights as the reference's files hold them; pack: also the tile-major twin the library keeps for
+    the decode-shaped launches (cactus_hip_weights_pack_dev, made once when a weight becomes resident)."""
     if int4:
         B = torch.randint(0, 256, (N, K // 2), dtype=torch.uint8, device="cuda", generator=gen)
     else:
         B = torch.randint(-127, 128, (N, K), dtype=torch.int8, device="cuda", generator=gen)
     Bs = (0.01 + torch.rand((N, K // 128), device="cuda", generator=gen) * 0.05).half()
+    if pack:
+        import cactus_amd.hip as H
+        H.pack_weights(B)
     return B, Bs
 
 
@@ -257,6 +262,19 @@ def main():
             for j in range(nsteps):
                 step(first + j, batched)
         return g
+
+    # The same step on the row-major weights alone (no twins yet), for the record; then every weight gets its
+    # tile-major twin, as a host does once when it loads a model, and all timed steps below stream the twins.
+    row_major_ms = None
+    if not args.traffic_child:
+        g_rm = capture(True, CHUNK, 0)
+        row_major_ms = time_events(lambda i: g_rm.replay(), 3, warm=1) / CHUNK
+        del g_rm
+    for ws in sets:
+        for B, _ in ws.values():
+            H.pack_weights(B)
+    step(0); step(1)
+    torch.cuda.synchronize()
     graphs = [capture(True, 1, 0), capture(True, 1, 1)]
     chunk_graph = capture(True, CHUNK, 0)        # CHUNK is even: every chunk starts on set 0
 
@@ -310,13 +328,13 @@ def main():
                 traffic, traffic_source = pm.get("hbm_bytes_per_launch"), "profiles/pmc_traffic.json (an earlier run of this command)"
         except (OSError, ValueError):
             pass
-    roofline = {"bound": "hbm", "kernel": "skinny_batch_sub_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch)",
+    roofline = {"bound": "hbm", "kernel": "skinny_batch_sub_kernel<INT8> (16 fused row-quant GEMVs, M=1, one launch, tile-major weights)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "bytes_per_launch": step_bytes, "us_per_launch": round(ev_ms * 1e3, 2)}
     # the largest single shape launched alone (8 rotating weight buffers, 512 MB > Infinity Cache)
     K = N = 8192
-    big = [sets[0][(K, N)], sets[1][(K, N)]] + [make_weights(K, N, False, gen) for _ in range(6)]
+    big = [sets[0][(K, N)], sets[1][(K, N)]] + [make_weights(K, N, False, gen, pack=True) for _ in range(6)]
     o = outs[(K, N)]
     x8 = acts[K]
     ms = time_events(lambda i: H.matmul_f16act(x8, big[i % 8][0], big[i % 8][1], 128, out=o), 80, warm=8)
@@ -349,8 +367,10 @@ def main():
             "config": {"workload": "INT8-weight x FP16-activation matmul sweep, M=1, K,N in {1024,2048,4096,8192} "
                                    "(16 shapes/step: fused row quant + grouped INT8 GEMV, group 128); "
                                    "two alternating weight sets (450 MB); one step = one batched launch, "
-                                   f"{CHUNK} steps per HIP graph",
+                                   f"{CHUNK} steps per HIP graph; weights resident row-major [N,K] with the "
+                                   "library's tile-major twins (cactus_hip_weights_pack_dev, made once at load)",
                        "bytes_per_step": step_bytes,
+                       "row_major_only_ms_per_step": None if row_major_ms is None else round(row_major_ms, 4),
                        "separate_launches_ms_per_step": round(seq_ms, 4),
                        "parallelism": f"replicas x{world} (independent sequences)"},
             "roofline": roofline,
@@ -408,28 +428,36 @@ def nsplit_8b(H, world, rank, cache=32768):
     gather, events on the launching stream, the slowest rank's."""
     import torch.distributed as dist
     from cactus_amd import sharding as S
+    comm = S.device_comm()                # the library's own RCCL communicator (cactus_hip_comm_init)
     gen = torch.Generator(device="cuda").manual_seed(4242)       # identical on every rank
-    out = {"ranks": world, "matmul_int4": {}, "note": "rows split by row_shard, HIP kernel per rank, one all-gather; "
-           "per call = local kernel + gather, max over ranks"}
+    out = {"ranks": world, "matmul_int4": {}, "note": "rows split by cactus_hip_row_shard; cactus_hip_matmul_int4_nsplit_dev "
+           "= HIP kernel on the rank's rows + one RCCL exchange on the same stream (M = 1 in place, M = 512 through "
+           "rank-major slots and one copy kernel); per call, max over ranks"}
     ok_all = True
     for (N, K) in ((12288, 4096), (4096, 12288), (4096, 4096)):
         B, Bs = make_weights(K, N, True, gen)
+        start, end = S.row_shard(N, world, rank)
+        Bl, Bsl = B[start:end].contiguous(), Bs[start:end].contiguous()      # the rank's own rows
+        if end > start:
+            H.pack_weights(Bl)
         for M in (1, 512):
             x = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
             q, sc = H.quantize_activations(x)
-            local = lambda b, bs: H.matmul_int4(q, sc, b, bs, 128)
-            got = S.matmul_nsplit(local, B, Bs, N)
+            full = torch.empty((M, N), dtype=torch.float16, device="cuda")
+            got = comm.matmul_nsplit(q, sc, Bl, Bsl, N, out=full)
             same = True
             if rank == 0:
                 same = bool(torch.equal(got.view(torch.int16), H.matmul_int4(q, sc, B, Bs, 128).view(torch.int16)))
-            ms = time_events(lambda i: S.matmul_nsplit(local, B, Bs, N), 10, warm=2)
-            start, end = S.row_shard(N, world, rank)
-            ms_local = time_events(lambda i: local(B[start:end], Bs[start:end]), 10, warm=2)
-            tt = torch.tensor([ms, ms_local, 0.0 if same else 1.0], dtype=torch.float64, device="cuda")
+            ms = time_events(lambda i: comm.matmul_nsplit(q, sc, Bl, Bsl, N, out=full), 10, warm=2)
+            ms_p2p = time_events(lambda i: comm.matmul_nsplit(q, sc, Bl, Bsl, N, out=full, algo=2), 10, warm=2) if M == 1 else 0.0
+            ms_local = time_events(lambda i: H.matmul_int4(q, sc, Bl, Bsl, 128), 10, warm=2) if end > start else 0.0
+            tt = torch.tensor([ms, ms_local, 0.0 if same else 1.0, ms_p2p], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ms, ms_local, bad = (float(v) for v in tt.tolist())
+            ms, ms_local, bad, ms_p2p = (float(v) for v in tt.tolist())
             ok_all = ok_all and bad == 0.0
             row = {"us": round(ms * 1e3, 2), "us_local_kernel": round(ms_local * 1e3, 2), "bit_identical_to_unsplit": bad == 0.0}
+            if M == 1:
+                row["us_all_pairs_send_recv"] = round(ms_p2p * 1e3, 2)
             if M == 1:
                 row["GBps"] = round(gemv_bytes(M, K, N, True, fused_quant=False) / (ms * 1e-3) / 1e9, 1)
             else:
@@ -451,9 +479,12 @@ def nsplit_8b(H, world, rank, cache=32768):
         lks, lvs = ks[:, k0:k1].contiguous(), vs[:, k0:k1].contiguous()
         lq, lkn, lvn = qh[:, :, q0:q1].contiguous(), kn[:, :, k0:k1].contiguous(), vn[:, :, k0:k1].contiguous()
 
+        gathered = torch.empty((1, Hq * D), dtype=torch.float16, device="cuda")
+        mine = gathered[:, q0 * D:q1 * D].view(1, 1, q1 - q0, D)     # the rank's heads: written in place, then exchanged
+
         def sharded(i=0):
-            part = H.attention_hybrid(lq, lk, lv, lks, lvs, lkn, lvn, 0.0, position_offset=cache)
-            return S.all_gather_columns(part.view(1, -1), Hq * D, multiple=(q1 - q0) * D)
+            H.attention_hybrid(lq, lk, lv, lks, lvs, lkn, lvn, 0.0, position_offset=cache, out=mine)
+            return comm.allgather_columns(gathered, multiple=(q1 - q0) * D)
         got = sharded()
         diff = 0.0
         if rank == 0:
@@ -468,6 +499,7 @@ def nsplit_8b(H, world, rank, cache=32768):
         out["attn_decode_int8kv_c32768_kv_head_shard"] = {"us": round(ms * 1e3, 2), "GBps": round(byts / (ms * 1e-3) / 1e9, 1),
                                                           "max_abs_diff_vs_unsplit": diff}
     out["all_checks_passed"] = ok_all
+    comm.close()
     return out
 
 
@@ -653,7 +685,7 @@ def extra_table(H, gen, big):
             for K, N in ((1024, 1024), (4096, 4096), (8192, 8192), (1024, 151936)):
                 nb = max(2, int(600e6 // max(1, (N * K // (2 if int4 else 1)))) + 1)
                 nb = min(nb, 64)
-                ws = [make_weights(K, N, int4, gen) for _ in range(nb)]
+                ws = [make_weights(K, N, int4, gen, pack=True) for _ in range(nb)]
                 x = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
                 o = torch.empty((M, N), dtype=torch.float16, device="cuda")
                 ms = time_graph(lambda i: H.matmul_f16act(x, ws[i % nb][0], ws[i % nb][1], 128, int4=int4, out=o),
@@ -661,7 +693,7 @@ def extra_table(H, gen, big):
                 gb = gemv_bytes(M, K, N, int4) / (ms * 1e-3) / 1e9
                 rows[f"K{K}_N{N}"] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1),
                                       "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
-                del ws
+                del ws            # (a packed tensor's twin goes with it)
             ex[f"gemv_{tag}_M{M}"] = rows
     # M = 512 GEMM: MFMA rate
     for int4 in (False, True):

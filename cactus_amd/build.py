@@ -9,7 +9,7 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libcactus_hip.so")
 
 SOURCES = ["quant_kernels.hip", "matmul_skinny.hip", "matmul_gemm.hip", "matmul_generic.hip",
-           "matmul_f16.hip", "attention.hip", "attention_decode.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "api.hip", "graph.cpp"]
+           "matmul_f16.hip", "attention.hip", "attention_decode.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "comm.hip", "api.hip", "graph.cpp"]
 HEADERS = ["common.hip.h", "block_math.hip.h", "kernels.h", "graph.h", os.path.join("..", "..", "include", "cactus_hip.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), so the
@@ -52,11 +52,14 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
     if force or procs or _stale(SO, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    build_examples(force or bool(procs), verbose)
+    try:
+        build_examples(force or bool(procs), verbose)
+    except (subprocess.CalledProcessError, OSError) as e:    # the library itself is built: an example cannot block it
+        print(f"warning: examples did not build: {e}", file=sys.stderr)
     return SO
 
 

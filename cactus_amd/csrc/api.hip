@@ -82,6 +82,12 @@ int workspace(size_t bytes, void** out) {
     return CACTUS_HIP_OK;
 }
 
+}  // namespace
+namespace cactus_hip {
+int workspace_for_comm(size_t bytes, void** out) { return workspace(bytes, out); }   // comm.hip's staging slots
+}  // namespace cactus_hip
+namespace {
+
 // Scratch of the allocation-free attention entry point: the split-KV records (max, sum, O row per
 // query head and key range) that the library otherwise keeps in the grow-only workspace above.
 // The array lives in the code object, so every device that loads the library holds its own copy

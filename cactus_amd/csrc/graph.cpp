@@ -53,15 +53,34 @@ size_t precision_size(Precision p) {
 
 // ------------------------------------------------------------------------- DevicePool
 
+// Buffers come in power-of-two sizes from 1 KiB (the reference's BufferPool buckets the same way, graph_core.cpp:5-19),
+// so graphs of different sequence lengths share them.  Idle buffers are kept up to max_idle_bytes_; beyond that
+// trim() frees the largest buckets first.  Every release happens behind the work that used the buffer on the
+// graph's one stream, and hipFree synchronizes the device, so a freed idle buffer is never still being read.
+static size_t pool_bucket(size_t bytes) {
+    size_t b = 1024;
+    while (b < bytes) b <<= 1;
+    return b;
+}
+
 void* CactusGraph::DevicePool::acquire(size_t bytes) {
-    const size_t rounded = ((bytes ? bytes : 1) + 255) & ~size_t(255);
+    const size_t rounded = pool_bucket(bytes ? bytes : 1);
     auto it = free_.find(rounded);
     if (it != free_.end() && !it->second.empty()) {
         void* p = it->second.back();
         it->second.pop_back();
+        idle_bytes_ -= rounded;
         return p;
     }
-    void* p = dev_alloc(rounded);
+    void* p = nullptr;
+    if (hipMalloc(&p, rounded) != hipSuccess) {
+        (void)hipGetLastError();
+        const size_t keep = max_idle_bytes_;
+        max_idle_bytes_ = 0;       // out of memory: give back everything idle, then try once more
+        trim();
+        max_idle_bytes_ = keep;
+        p = dev_alloc(rounded);
+    }
     size_of_[p] = rounded;
     allocations_++;
     return p;
@@ -75,12 +94,29 @@ void CactusGraph::DevicePool::release(void* p) {
         return;
     }
     free_[it->second].push_back(p);
+    idle_bytes_ += it->second;
+}
+
+void CactusGraph::DevicePool::trim() {
+    while (idle_bytes_ > max_idle_bytes_) {
+        size_t largest = 0;
+        for (auto& kv : free_)
+            if (!kv.second.empty() && kv.first > largest) largest = kv.first;
+        if (largest == 0) break;
+        auto& v = free_[largest];
+        void* p = v.back();
+        v.pop_back();
+        size_of_.erase(p);
+        idle_bytes_ -= largest;
+        (void)hipFree(p);
+    }
 }
 
 void CactusGraph::DevicePool::clear() {
     for (auto& kv : size_of_) (void)hipFree(kv.first);
     size_of_.clear();
     free_.clear();
+    idle_bytes_ = 0;
 }
 
 // ------------------------------------------------------------------------- CactusGraph
@@ -319,6 +355,21 @@ void* CactusGraph::resident_copy(const void* host, size_t bytes) {
     return d;
 }
 
+// A grouped weight that has reached the device gets its tile-major twin (cactus_hip_weights_pack_dev): the decode
+// matmuls (M <= 16) of every later pass stream the twin, launches with more rows keep reading the row-major copy.
+// Not being able to afford the second copy is not an error.
+void CactusGraph::make_twin(BufferDesc& b) {
+    if (!streaming_twins_ || b.shape.size() != 2 || b.group_size != 128 || b.scales_device == nullptr) return;
+    const bool int4 = b.is_packed_int4();
+    const void* w = int4 ? b.packed_int4_device : b.device_data;
+    const size_t N = b.shape[0], K = b.shape[1];
+    if (w == nullptr || K % (int4 ? 256 : 128) != 0 || b.num_groups != K / 128) return;
+    if (!int4 && b.precision != Precision::INT8) return;
+    if (cactus_hip_weights_is_packed_dev(w)) return;
+    if (cactus_hip_weights_pack_dev(w, N, K, int4 ? 1 : 0, nullptr) == CACTUS_HIP_OK) twins_.push_back(w);
+    else cactus_hip_clear_error();
+}
+
 void CactusGraph::set_input(size_t node_id, const void* data, Precision) {
     auto& n = node(node_id);
     if (n.op_type != OpType::INPUT) throw std::invalid_argument("Can only set data on input nodes");
@@ -338,6 +389,7 @@ void CactusGraph::set_external_input(size_t node_id, void* data, Precision) {
     b.owns_device = false;
     b.device_valid = true;
     is_weight_[node_id] = true;
+    make_twin(b);
 }
 
 void CactusGraph::set_device_input(size_t node_id, void* device_ptr, Precision) {
@@ -357,6 +409,7 @@ void CactusGraph::set_grouped_scales(size_t node_id, size_t group_size, size_t n
     b.num_groups = num_groups;
     b.scales_device = resident_copy(scales_ptr, b.shape[0] * num_groups * sizeof(uint16_t));
     b.owns_scales = false;
+    make_twin(b);
 }
 
 void CactusGraph::set_packed_int4(size_t node_id, const void* packed, size_t packed_bytes) {
@@ -365,6 +418,7 @@ void CactusGraph::set_packed_int4(size_t node_id, const void* packed, size_t pac
     b.packed_int4_size = packed_bytes;
     b.device_valid = true;
     is_weight_[node_id] = true;
+    make_twin(b);
 }
 
 ModelConfig parse_model_config(const std::string& text) {   // engine_model.cpp:410-538
@@ -547,6 +601,7 @@ size_t CactusGraph::mmap_weights(const std::string& filename) {   // graph_io.cp
     }
     is_weight_[id] = true;
     weight_cache_[filename] = id;
+    make_twin(node(id).output_buffer);
     return id;
 }
 
@@ -1338,9 +1393,12 @@ void CactusGraph::soft_reset() {   // graph_execute.cpp:640-675: weights survive
     for (auto& kv : quant_cache_)
         if (kv.second.q) { pool_.release(kv.second.q); pool_.release(kv.second.scales); }
     quant_cache_.clear();
+    pool_.trim();
 }
 
 void CactusGraph::hard_reset() {
+    for (const void* w : twins_) (void)cactus_hip_weights_release_packed_dev(w);
+    twins_.clear();
     for (auto& up : nodes_) free_node(*up, pool_);
     nodes_.clear();
     node_index_map_.clear();
@@ -1816,6 +1874,9 @@ int cactus_hip_graph_hard_reset(void* g) {
 }
 size_t cactus_hip_graph_node_count(void* g) { return G_(g)->get_node_count(); }
 size_t cactus_hip_graph_pool_allocations(void* g) { return G_(g)->pool_device_allocations(); }
+size_t cactus_hip_graph_pool_idle_bytes(void* g) { return G_(g)->pool_idle_bytes(); }
+void cactus_hip_graph_set_pool_max_idle_bytes(void* g, size_t bytes) { G_(g)->set_pool_max_idle_bytes(bytes); }
+void cactus_hip_graph_set_streaming_twins(void* g, int on) { G_(g)->set_streaming_twins(on != 0); }
 void cactus_hip_graph_set_fusion(void* g, int on) { G_(g)->set_fusion(on != 0); }
 size_t cactus_hip_graph_fused_launches(void* g) { return G_(g)->fused_launches(); }
 

@@ -187,6 +187,11 @@ public:
     size_t get_node_count() const { return nodes_.size(); }
     // hipMalloc calls made for node buffers and scratch so far (stays flat once the pool is warm)
     size_t pool_device_allocations() const { return pool_.device_allocations(); }
+    size_t pool_idle_bytes() const { return pool_.idle_bytes(); }
+    // idle node buffers kept across soft resets (default 1 GiB); the excess is freed, largest first
+    void set_pool_max_idle_bytes(size_t bytes) { pool_.set_max_idle_bytes(bytes); pool_.trim(); }
+    // weights bound from now on get a tile-major twin for the decode matmuls (default on; costs a second copy)
+    void set_streaming_twins(bool on) { streaming_twins_ = on; }
     void hard_reset();
     void soft_reset();   // drops every node that is not a weight (external) input
     // execute() hands runs of nodes to the fused launches of the C ABI (on by default):
@@ -210,17 +215,24 @@ public:
         void* acquire(size_t bytes);
         void release(void* p);   // a pointer the pool did not hand out is freed
         void clear();
+        void trim();             // frees idle buffers, largest first, until at most max_idle_bytes() stay idle
         size_t device_allocations() const { return allocations_; }
+        size_t idle_bytes() const { return idle_bytes_; }
+        size_t max_idle_bytes() const { return max_idle_bytes_; }
+        void set_max_idle_bytes(size_t b) { max_idle_bytes_ = b; }
     private:
         std::unordered_map<size_t, std::vector<void*>> free_;   // rounded size -> idle buffers
         std::unordered_map<void*, size_t> size_of_;             // every buffer handed out -> rounded size
         size_t allocations_ = 0;
+        size_t idle_bytes_ = 0;
+        size_t max_idle_bytes_ = size_t(1) << 30;   // idle buffers kept across soft resets (1 GiB unless set)
     };
 
 private:
     GraphNode& node(size_t id);
     const GraphNode& node(size_t id) const;
     void ensure_device(BufferDesc& b);
+    void make_twin(BufferDesc& b);
     void* resident_copy(const void* host, size_t bytes);
     bool batchable_matmul(const GraphNode& n, bool* int4) const;
     bool fusable_matmul(const GraphNode& n, size_t lhs_id, bool* int4) const;
@@ -257,6 +269,8 @@ private:
     void compute_sample_node(GraphNode& n);
 
     DevicePool pool_;
+    bool streaming_twins_ = true;
+    std::vector<const void*> twins_;   // row-major weights this graph gave a twin
     std::vector<void*> retired_;   // resident copies replaced under the same host address
     bool fusion_ = true;
     size_t fused_launches_ = 0;

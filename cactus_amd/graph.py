@@ -51,6 +51,9 @@ GRAPH_SIGNATURES = {
     "cactus_hip_graph_hard_reset": (_i, [_vp]),
     "cactus_hip_graph_node_count": (_sz, [_vp]),
     "cactus_hip_graph_pool_allocations": (_sz, [_vp]),
+    "cactus_hip_graph_pool_idle_bytes": (_sz, [_vp]),
+    "cactus_hip_graph_set_pool_max_idle_bytes": (None, [_vp, _sz]),
+    "cactus_hip_graph_set_streaming_twins": (None, [_vp, C.c_int]),
     "cactus_hip_graph_set_fusion": (None, [_vp, _i]),
     "cactus_hip_graph_fused_launches": (_sz, [_vp]),
     "cactus_hip_kvcache_create": (_vp, [_sz, _sz, _sz, _sz]),
@@ -289,6 +292,17 @@ class CactusGraph:
 
     def pool_allocations(self):
         return lib.cactus_hip_graph_pool_allocations(self._g)
+
+    def pool_idle_bytes(self):
+        return lib.cactus_hip_graph_pool_idle_bytes(self._g)
+
+    def set_pool_max_idle_bytes(self, nbytes):
+        """Idle node buffers kept across soft resets (default 1 GiB); the excess is freed, largest first."""
+        lib.cactus_hip_graph_set_pool_max_idle_bytes(self._g, int(nbytes))
+
+    def set_streaming_twins(self, on):
+        """Whether weights bound from now on get a tile-major twin for the decode matmuls (default on)."""
+        lib.cactus_hip_graph_set_streaming_twins(self._g, 1 if on else 0)
 
     def set_fusion(self, on):
         """Whether execute() hands [add ->] rms_norm -> matmuls and silu/gelu -> multiply -> matmuls runs to the

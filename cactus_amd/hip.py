@@ -6,6 +6,7 @@ torch.float16 tensors; their bits are what the C ABI calls cactus_half_t.
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -36,6 +37,18 @@ SIGNATURES = {
     "cactus_hip_weights_pack_dev": (_i, [_vp, _sz, _sz, _i, _vp]),
     "cactus_hip_weights_release_packed_dev": (_i, [_vp]),
     "cactus_hip_weights_is_packed_dev": (_i, [_vp]),
+    "cactus_hip_comm_available": (_i, []),
+    "cactus_hip_comm_get_unique_id": (_i, [_vp]),
+    "cactus_hip_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "cactus_hip_comm_adopt": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "cactus_hip_comm_destroy": (_i, [_vp]),
+    "cactus_hip_comm_rank": (_i, [_vp]),
+    "cactus_hip_comm_world": (_i, [_vp]),
+    "cactus_hip_row_shard": (None, [_sz, _i, _i, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    "cactus_hip_allgather_columns_dev": (_i, [_vp, _vp, _sz, _sz, _sz, _i, _vp]),
+    "cactus_hip_matmul_int8_nsplit_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _vp]),
+    "cactus_hip_matmul_int4_nsplit_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _i, _vp]),
+    "cactus_hip_slots_to_columns_dev": (_i, [_vp, _vp, _sz, _sz, _i, _sz, _vp]),
     "cactus_hip_matmul_int8_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int4_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_matmul_int8_f16act_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp]),
@@ -162,12 +175,15 @@ def init(device=0):
 def pack_weights(B):
     """Give the device-resident weight matrix B (int8 [N, K] or packed uint8 [N, K/2]) a tile-major twin: every
     later matmul with M <= 16 that names B streams the twin (cactus_hip_weights_pack_dev).  B must stay alive and
-    unchanged until release_packed(B)."""
+    unchanged until release_packed(B); the twin is released when the tensor object goes away."""
     int4 = B.dtype == torch.uint8
     _dev(B, torch.uint8 if int4 else torch.int8)
     N = B.shape[0]
     K = B.shape[1] * (2 if int4 else 1)
+    fresh = not is_packed(B)
     _check(lib.cactus_hip_weights_pack_dev(_p(B), N, K, int(int4), _stream()))
+    if fresh:   # the twin is keyed by B's address: it must not outlive the tensor
+        weakref.finalize(B, lib.cactus_hip_weights_release_packed_dev, C.c_void_p(B.data_ptr()))
     return B
 
 
@@ -178,6 +194,64 @@ def release_packed(B=None):
 
 def is_packed(B):
     return bool(lib.cactus_hip_weights_is_packed_dev(_p(B)))
+
+
+def row_shard(N, world, rank, multiple=16):
+    """Rows [start, end) of an N-row weight owned by `rank` (cactus_hip_row_shard; host arithmetic only)."""
+    a, b = _sz(0), _sz(0)
+    lib.cactus_hip_row_shard(N, world, rank, multiple, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class Comm:
+    """An RCCL communicator of the library (cactus_hip_comm_*): one per process and GPU.  unique_id() on rank 0, the
+    128 bytes carried to the other ranks by the host program, then Comm(id, world, rank) on every rank."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _check(lib.cactus_hip_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, world, rank):
+        h = _vp()
+        _check(lib.cactus_hip_comm_init(C.byref(h), unique_id, world, rank))
+        self._h, self.world, self.rank = h, world, rank
+
+    def close(self):
+        if self._h:
+            lib.cactus_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def allgather_columns(self, Cfull, multiple=16, algo=0):
+        """Cfull fp16 [M, N], this rank's columns (row_shard) written: afterwards all columns, on every rank."""
+        _dev(Cfull, torch.float16)
+        M, N = Cfull.shape
+        _check(lib.cactus_hip_allgather_columns_dev(self._h, _p(Cfull), M, N, multiple, algo, _stream()))
+        return Cfull
+
+    def matmul_nsplit(self, A, A_scales, B_rows, B_scales_rows, N, group_size=128, multiple=16, algo=0, out=None):
+        """N-split W8A8 / W4A8 matmul: this rank's weight rows in, the full [M, N] out on every rank."""
+        int4 = B_rows.dtype == torch.uint8
+        _dev(A, torch.int8); _dev(A_scales, torch.float32); _dev(B_scales_rows, torch.float16)
+        M, K = A.shape
+        Cc = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=A.device)
+        fn = lib.cactus_hip_matmul_int4_nsplit_dev if int4 else lib.cactus_hip_matmul_int8_nsplit_dev
+        _check(fn(self._h, _p(A), _p(A_scales), _p(B_rows), _p(B_scales_rows), _p(Cc), M, K, N, group_size, multiple,
+                  algo, _stream()))
+        return Cc
+
+
+def slots_to_columns(slots, N, multiple=16, out=None):
+    """Rank-major blocks fp16 [world, M, per] -> fp16 [M, N] (the copy step of the M > 1 exchange)."""
+    _dev(slots, torch.float16)
+    world, M, per = slots.shape
+    Cc = out if out is not None else torch.empty((M, N), dtype=torch.float16, device=slots.device)
+    _check(lib.cactus_hip_slots_to_columns_dev(_p(slots), _p(Cc), M, N, world, multiple, _stream()))
+    return Cc
 
 
 def quantize_activations(x, out_q=None, out_scales=None):

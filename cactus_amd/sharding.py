@@ -28,12 +28,19 @@ def sequence_shard(num_sequences, world, rank):
 def row_shard(N, world, rank, multiple=16):
     """Rows [start, end) of an N-row weight owned by `rank`.  Slices are multiples of
     `multiple` rows (the GEMV kernel's rows per workgroup) except the last, which takes the
-    remainder; ranks past the end get an empty slice."""
-    per = -(-N // world)
-    per = -(-per // multiple) * multiple
-    start = min(N, rank * per)
-    end = min(N, start + per)
-    return start, end
+    remainder; ranks past the end get an empty slice.  (cactus_hip_row_shard: the library's own rule.)"""
+    from . import hip as H
+    return H.row_shard(N, world, rank, multiple)
+
+
+def device_comm(group=None):
+    """The library's RCCL communicator over the ranks of `group` (one process per GPU, torch.cuda's current device):
+    rank 0 draws the unique id, torch.distributed carries its 128 bytes to the others, every rank joins."""
+    from . import hip as H
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [H.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return H.Comm(box[0], world, rank)
 
 
 def kv_head_shard(num_kv_heads, num_q_heads, world, rank):
@@ -48,7 +55,9 @@ def kv_head_shard(num_kv_heads, num_q_heads, world, rank):
 
 def all_gather_columns(local, N, group=None, multiple=16):
     """Gather C[:, start:end] slices (row_shard layout) from every rank into the full [M, N].
-    `local` is this rank's [M, end - start] tensor; every rank returns the same [M, N]."""
+    `local` is this rank's [M, end - start] tensor; every rank returns the same [M, N].  The torch.distributed
+    form, for host tensors (the gloo tests of the partition arithmetic); on the GPUs the exchange is the library's
+    own (device_comm(): Comm.matmul_nsplit / Comm.allgather_columns, no padding, no permute)."""
     world = dist.get_world_size(group)
     M = local.shape[0]
     per = row_shard(N, world, 0, multiple)[1]

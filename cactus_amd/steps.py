@@ -56,6 +56,19 @@ def _f32(*shape):
     return torch.empty(shape, dtype=torch.float32, device="cuda")
 
 
+def pack_model_weights(weights):
+    """Tile-major twins for every quantized matrix of a model dict (cactus_hip_weights_pack_dev): the decode
+    matmuls of batches up to 16 rows stream them; the row-major tensors stay as they are for everything else."""
+    for L in weights["layers"]:
+        for v in L.values():
+            if isinstance(v, tuple):
+                H.pack_weights(v[0])
+    H.pack_weights(weights["emb"][0])
+    if "head" in weights:
+        H.pack_weights(weights["head"][0])
+    return weights
+
+
 def _norm_weight(gen, n):
     return (1.0 + 0.1 * torch.randn((n,), device="cuda", generator=gen)).half()
 
@@ -83,6 +96,8 @@ def weights_to_device(m):
         return torch.from_numpy(np.ascontiguousarray(x)).cuda()
     out = {"layers": [{k: up(v) for k, v in L.items()} for L in m["layers"]], "emb": up(m["emb"]),
            "final_norm": up(m["final_norm"])}
+    if "head" in m:
+        out["head"] = up(m["head"])
     return out
 
 
@@ -150,8 +165,10 @@ class Qwen3Decode:
         self.aq, self.asc = _i8(b, F), _f32(b)
         self.oq, self.osc = _i8(b, Hq * D), _f32(b)      # attention output rows, quantized for the output projection
         self.small = batch <= 4
+        if batch <= 16:        # the streaming kernels take these batches: give them the tile-major layout
+            pack_model_weights(weights)
         Ls = weights["layers"]
-        head = weights["emb"]
+        head = weights.get("head", weights["emb"])     # tied embeddings unless the model brings an lm_head of its own
 
         def groups(entries, cls):
             """entries [(weight pair, out)] split by precision: one launch object per precision."""
@@ -174,9 +191,10 @@ class Qwen3Decode:
     def step(self, advance=True):
         c, kv, b = self.cfg, self.kv, self.batch
         Hq, Hkv, D, eps, theta = c["q_heads"], c["kv_heads"], c["head_dim"], c["eps"], c["theta"]
-        Ls, head = self.w["layers"], self.w["emb"]
+        Ls, emb = self.w["layers"], self.w["emb"]
+        head = self.w.get("head", emb)
         NL = len(Ls)
-        H.embedding(head[0], kv.tok, head[1], 128, out=self.h0, check=False)
+        H.embedding(emb[0], kv.tok, emb[1], 128, out=self.h0, check=False)
         if not self.small:
             H.add_rms_norm_quant(self.h0, None, Ls[0]["in_norm"], eps, out_q=self.xq, out_scales=self.xs)
         res = self.h0
@@ -366,6 +384,8 @@ class Lfm2Decode:
         self.w, self.batch = weights, batch
         Hd, Hq, Hkv, D, F, V = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["ffn"], c["vocab"]
         Ls = weights["layers"]
+        if batch <= 16:
+            pack_model_weights(weights)
         self.attn_index = {}
         for li, L in enumerate(Ls):
             if "q" in L:

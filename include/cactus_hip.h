@@ -581,6 +581,53 @@ int cactus_hip_kv_append_windowed_dev(const cactus_half_t* k_new, const cactus_h
 int cactus_hip_kv_positions_advance_dev(int32_t* positions, int32_t* cache_lens, size_t batch_size, size_t advance,
                                         size_t window, void* stream);
 
+/* ----------------------------------------------------------- multi-GPU (RCCL over xGMI)
+ * No counterpart in the reference (a single-process CPU engine with no multi-device code).  One process per GPU;
+ * a matmul splits by weight rows: rank r owns rows cactus_hip_row_shard(N, world, r, multiple) of B[N, K] and of
+ * its scales [N, K/group_size] - a contiguous slice of the reference's layout, no repacking - and computes
+ * C[:, start:end]; ONE exchange leaves C[M, N] on every rank.  No output element's sum is split, so the result is
+ * bit-identical to the one-GPU call.  (A K-split would reorder the fp32 chain and is not offered.)  Attention over
+ * a long INT8 cache shards by kv head and gathers its output rows with the same call (N = heads * head_dim,
+ * multiple = a rank's heads * head_dim).
+ *
+ * The communicator is RCCL's: rank 0 calls cactus_hip_comm_get_unique_id, the host program hands the 128 bytes to
+ * the other ranks by its own means, and every rank calls cactus_hip_comm_init on its device (collective:
+ * ncclCommInitRank); cactus_hip_comm_adopt wraps an ncclComm_t the host already owns.  RCCL is loaded on first
+ * use; cactus_hip_comm_available() == 0 when it cannot be.  Calls enqueue on `stream`, allocate nothing beyond the
+ * library workspace (M > 1: world * M * per halves; reserve it before stream capture) and can be captured.
+ *
+ * algo: 0 the library's choice; 1 ncclAllGather where every rank owns the same count; 2 grouped ncclSend/ncclRecv
+ * to and from every peer (the direct all-pairs schedule: all xGMI links of a GPU at once; M == 1 only). */
+#define CACTUS_HIP_COMM_ID_BYTES 128
+int  cactus_hip_comm_available(void);
+int  cactus_hip_comm_get_unique_id(void* id128);
+int  cactus_hip_comm_init(void** comm_out, const void* id128, int world, int rank);
+int  cactus_hip_comm_adopt(void** comm_out, void* nccl_comm, int world, int rank);
+int  cactus_hip_comm_destroy(void* comm);
+int  cactus_hip_comm_rank(void* comm);
+int  cactus_hip_comm_world(void* comm);
+/* Rows [*start, *end) of an N-row weight that `rank` owns: ceil(N / world) rounded up to `multiple` rows per rank
+ * (16 = the streaming kernel's rows per workgroup), the last ranks take what is left (possibly nothing).  Host only. */
+void cactus_hip_row_shard(size_t N, int world, int rank, size_t multiple, size_t* start, size_t* end);
+/* C half[M, N] on every rank, each having written its own columns (row_shard of N): afterwards every rank holds
+ * all columns.  M == 1: exchanged in place.  M > 1: through rank-major slots in the workspace and one copy kernel. */
+int  cactus_hip_allgather_columns_dev(void* comm, cactus_half_t* C, size_t M, size_t N, size_t multiple, int algo,
+                                      void* stream);
+/* cactus_matmul_int8 / _int4 (kernel.h:41-47) N-split: B_rows / B_scales_rows are THIS rank's rows of the weight
+ * and of its scales, A / A_scales the full quantized activations (replicated), C half[M, N] the full output on
+ * every rank.  M > 1: the local launch writes its block straight into its slot (no padding copy). */
+int  cactus_hip_matmul_int8_nsplit_dev(void* comm, const int8_t* A, const float* A_scales, const int8_t* B_rows,
+                                       const cactus_half_t* B_scales_rows, cactus_half_t* C, size_t M, size_t K,
+                                       size_t N, size_t group_size, size_t multiple, int algo, void* stream);
+int  cactus_hip_matmul_int4_nsplit_dev(void* comm, const int8_t* A, const float* A_scales,
+                                       const uint8_t* B_rows_packed, const cactus_half_t* B_scales_rows,
+                                       cactus_half_t* C, size_t M, size_t K, size_t N, size_t group_size,
+                                       size_t multiple, int algo, void* stream);
+/* The copy kernel of the M > 1 exchange on its own: slots half[world][M][per] (per = a rank's column count as
+ * row_shard gives it) -> C half[M, N]. */
+int  cactus_hip_slots_to_columns_dev(const cactus_half_t* slots, cactus_half_t* C, size_t M, size_t N, int world,
+                                     size_t multiple, void* stream);
+
 /* ------------------------------------------------ host-pointer drop-in family
  * Same argument lists as cactus/kernel/kernel.h, host memory in and out.      */
 

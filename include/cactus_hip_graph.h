@@ -112,6 +112,16 @@ size_t cactus_hip_graph_node_count(void* graph);
  * buffers in a pool across execute() and soft_reset() (the reference's BufferPool,
  * graph_execute.cpp:640-675), so the count stops growing once a step has run. */
 size_t cactus_hip_graph_pool_allocations(void* graph);
+/* The pool hands out buffers in power-of-two sizes from 1 KiB (as the reference's BufferPool buckets them,
+ * graph_core.cpp:5-19), so passes of different sequence lengths share buffers.  soft_reset() keeps at most
+ * max_idle_bytes of idle buffers (default 1 GiB) and frees the rest, largest first; a device allocation that
+ * fails frees every idle buffer and is tried once more. */
+size_t cactus_hip_graph_pool_idle_bytes(void* graph);
+void   cactus_hip_graph_set_pool_max_idle_bytes(void* graph, size_t bytes);
+/* Grouped weights bound from now on (set_external_input / set_packed_int4 + set_grouped_scales, mmap_weights)
+ * get a tile-major twin for the decode matmuls (cactus_hip_weights_pack_dev; default on, costs a second copy of
+ * the weight in HBM); hard_reset() releases them. */
+void   cactus_hip_graph_set_streaming_twins(void* graph, int on);
 /* execute() recognizes the runs a decoder block is made of and hands each to one fused launch of
  * cactus_hip.h, with the separate nodes' results bit for bit (on by default; the reference executes node
  * by node, graph_execute.cpp:480-560, and fuses nothing):

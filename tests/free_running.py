@@ -54,6 +54,18 @@ class Shadow:
                 "distinct_tokens": len(set(self.tokens))}
 
 
+def make_model(GD, rng, layers, vocab, tied):
+    """The residual-dominated synthetic Qwen3-shape model of tests/test_gpu_greedy_decode.py.  tied: lm_head = the
+    embedding table, as Qwen3 has it - a random model then mostly predicts the token it was fed, with a large margin.
+    Not tied: an lm_head of its own - logits are a random projection of the last hidden row, nearly flat, the top two
+    a few per cent of the largest apart: the hard case for token identity."""
+    m = GD.make_model(rng, layers, vocab, 0.05)
+    if not tied:
+        from tests.helpers import rand_weights_int8
+        m["head"] = rand_weights_int8(rng, vocab, GD.HID)
+    return m
+
+
 def next_feed(history, tok, rng, vocab):
     """A synthetic model soon repeats one token: a token seen before is replaced by a fresh seeded one (the
     comparison of the step that chose it has been made).  Deterministic in the device's own history."""

@@ -682,6 +682,84 @@ def test_buffer_pool_survives_soft_reset(G):
     g.close()
 
 
+def test_buffer_pool_is_shared_by_prompts_of_different_lengths_and_bounded(G):
+    """Variable-length serving: passes over 300, 290, 310, 257 ... rows land in the same power-of-two buckets (the
+    reference's BufferPool rounds the same way, graph_core.cpp:5-19), so the allocation count stops growing after
+    the first pass; the idle bytes kept across soft resets never exceed the cap, and lowering the cap frees them."""
+    rng = np.random.default_rng(23)
+    K, N = 1024, 512
+    B, Bs = rand_weights_int8(rng, N, K)
+    g = G.CactusGraph()
+    w = g.input((N, K), G.INT8)
+    g.set_external_input(w, B)
+    g.set_grouped_scales(w, 128, K // 128, Bs)
+    counts, idle = [], []
+    for M in (300, 290, 310, 257, 300, 512):
+        x = rand_act_f16(rng, M, K)
+        xin = g.input((M, K), G.FP16)
+        y = g.matmul(xin, w, True)
+        z = g.add(y, y)
+        g.set_input(xin, x)
+        g.execute()
+        q, s = O.quantize_activations(x)
+        ref = O.matmul_int8(q, s, B, Bs, 128)
+        assert (u16(g.get_output(y)) == ref).all()
+        assert (u16(g.get_output(z)) == O.binary("add", ref, ref)).all()
+        g.soft_reset()
+        counts.append(g.pool_allocations())
+        idle.append(g.pool_idle_bytes())
+    assert counts[0] > 0 and counts[-1] == counts[0], counts          # 257..512 rows: the same buckets
+    assert idle[-1] == idle[0] and idle[0] > 0, idle
+    # twice as many rows: new buckets join, the old ones stay idle within the cap
+    xin = g.input((1024, K), G.FP16)
+    y = g.matmul(xin, w, True)
+    g.set_input(xin, rand_act_f16(rng, 1024, K))
+    g.execute()
+    g.soft_reset()
+    assert g.pool_allocations() > counts[0] and g.pool_idle_bytes() > idle[0]
+    g.set_pool_max_idle_bytes(idle[0] // 2)             # a lower cap frees idle buffers, largest first
+    assert g.pool_idle_bytes() <= idle[0] // 2
+    x = rand_act_f16(rng, 300, K)                        # and the graph keeps working
+    xin = g.input((300, K), G.FP16)
+    y = g.matmul(xin, w, True)
+    g.set_input(xin, x)
+    g.execute()
+    q, s = O.quantize_activations(x)
+    assert (u16(g.get_output(y)) == O.matmul_int8(q, s, B, Bs, 128)).all()
+    g.soft_reset()
+    assert g.pool_idle_bytes() <= idle[0] // 2
+    g.close()
+
+
+def test_graph_weights_stream_from_twins_same_bits(G):
+    """Weights bound to a graph get a tile-major twin by default (decode rows stream it); with twins off the same
+    graph gives the same bits."""
+    rng = np.random.default_rng(29)
+    K, N = 2048, 1000
+    B, Bs = rand_weights_int8(rng, N, K)
+    Bp, Bps = rand_weights_int4(rng, N, K)
+    x = rand_act_f16(rng, 1, K)
+    outs = []
+    for twins in (True, False):
+        g = G.CactusGraph()
+        g.set_streaming_twins(twins)
+        w = g.input((N, K), G.INT8)
+        g.set_external_input(w, B)
+        g.set_grouped_scales(w, 128, K // 128, Bs)
+        w4 = g.input((N, K), G.INT8)
+        g.set_packed_int4(w4, Bp)
+        g.set_grouped_scales(w4, 128, K // 128, Bps)
+        xin = g.input((1, K), G.FP16)
+        y, y4 = g.matmul(xin, w, True), g.matmul(xin, w4, True)
+        g.set_input(xin, x)
+        g.execute()
+        outs.append((u16(g.get_output(y)).copy(), u16(g.get_output(y4)).copy()))
+        g.close()
+    q, s = O.quantize_activations(x)
+    assert (outs[0][0] == O.matmul_int8(q, s, B, Bs, 128)).all() and (outs[0][1] == O.matmul_int4(q, s, Bp, Bps, 128)).all()
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all()
+
+
 # ---------------------------------------------------------------------------- fused runs
 def _decoder_mlp_block(G, g, rng, M, HID, FF, mixed, act):
     """h2 = h + o;  n = rms_norm(h2);  out = h2 + down(act(gate(n)) * up(n))  plus a second norm without an add

@@ -85,7 +85,7 @@ def oracle_forward(m, tokens, pos, caches):
         act = O.binary("multiply", O.silu(omm(n2, L["gate"])), omm(n2, L["up"]))
         h = O.binary("add", h, omm(act, L["down"]))
     last = O.rms_norm(h[S - 1:S], m["final_norm"], EPS)
-    return omm(last, m["emb"])[0]
+    return omm(last, m.get("head", m["emb"]))[0]     # "head": an lm_head of its own instead of the tied embedding
 
 
 def bind(G, g, m):
@@ -100,6 +100,7 @@ def bind(G, g, m):
         g.set_external_input(n, a)
         return n
     wn = {"layers": [], "emb": weight(m["emb"]), "final_norm": vec(m["final_norm"])}
+    wn["head"] = weight(m["head"]) if "head" in m else wn["emb"]
     for L in m["layers"]:
         wn["layers"].append({k: (weight(v) if isinstance(v, tuple) else vec(v)) for k, v in L.items()})
     return wn
@@ -132,7 +133,7 @@ def graph_forward(G, g, wn, tokens, pos, cache):
         act = g.multiply(g.silu(g.matmul(n2, L["gate"], True)), g.matmul(n2, L["up"], True))
         h = g.add(h, g.matmul(act, L["down"], True))
     last = g.reshape(g.index(g.rms_norm(h, wn["final_norm"], EPS), S - 1, 0), (1, HID))   # engine_model.cpp:241-246
-    logits = g.matmul(last, wn["emb"], True)
+    logits = g.matmul(last, wn.get("head", wn["emb"]), True)
     g.execute()
     out = g.get_output(logits).reshape(-1).copy()
     cache.update_from_graph(g, k_nodes, v_nodes, S)

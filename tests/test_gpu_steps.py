@@ -90,7 +90,7 @@ def oracle_forward(m, tokens, pos, caches, window=0, sink=0):
         act = O.binary("multiply", O.silu(omm(n2, L["gate"])), omm(n2, L["up"]))
         h = O.binary("add", h, omm(act, L["down"]))
     last = O.rms_norm(h[S - 1:S], m["final_norm"], EPS)
-    return omm(last, m["emb"])[0]
+    return omm(last, m.get("head", m["emb"]))[0]
 
 
 def ring_slot(i, window, sink):
