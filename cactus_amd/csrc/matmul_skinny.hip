@@ -47,6 +47,22 @@ __device__ unsigned long long g_sk_trace[64 * 8];
             g_sk_trace[tile * 8 + (ph)] = __builtin_readcyclecounter();                \
     } while (0)
 
+// Diagnostic builds only (-DFQ_TRACE, scripts/build_fq_trace.sh): wall-clock stamps (100 MHz, the same clock on every
+// CU and across launches) of the phases of the fused-quantization body, for up to FQT_WGS workgroups of each of the
+// last FQT_LAUNCHES launches.  A launch learns its index from a counter that thread 0 of every workgroup raises when
+// the workgroup is done (launches on one stream run one after the other).
+#ifdef FQ_TRACE
+constexpr int FQT_LAUNCHES = 512, FQT_WGS = 64, FQT_PH = 8;
+__device__ unsigned long long g_fq_trace[FQT_LAUNCHES * FQT_WGS * FQT_PH];
+static int g_fq_trace_next = 0;     // host: every enqueued launch takes the next index (a captured launch keeps its own)
+#define FQ_STAMP(ph)                                                                                   \
+    do {                                                                                               \
+        if (t == 0 && fqt_slot >= 0) g_fq_trace[fqt_slot * FQT_PH + (ph)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define FQ_STAMP(ph) do { } while (0)
+#endif
+
 __device__ __forceinline__ v4i ldg(const void* p) { return *reinterpret_cast<const v4i*>(p); }
 
 // Raw buffer loads: one SGPR descriptor per operand, a 32-bit per-lane byte offset, hardware
@@ -415,7 +431,8 @@ template <bool INT4, int W, int P, int CT, int PRO = 0, bool WT = false>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
                                         uint16_t* __restrict__ C, int M, int K, int N, int tl,
-                                        int t, float* __restrict__ sk_lds, bool pk, const FqPro pro = FqPro()) {
+                                        int t, float* __restrict__ sk_lds, bool pk, const FqPro pro = FqPro(),
+                                        int trace_id = -1) {
     // t: thread index among the W waves that share the tile; sk_lds: their LDS region.  A workgroup
     // may hold several such wave groups (tiles of one problem, same barrier sequence).
     constexpr int GPU_ = INT4 ? 2 : 1;   // groups per unit
@@ -432,6 +449,21 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     float* s_inv = wmax + W * 4;                                                            // [4]      (PRO 1)
     uint16_t* lds_x = reinterpret_cast<uint16_t*>(s_inv + 4);                               // [M][K]   (PRO 1)
 
+#ifdef FQ_TRACE
+    int fqt_slot = -1;
+    const unsigned long long fqt_t0 = __builtin_amdgcn_s_memrealtime();    // before anything else of the body
+    {
+        const int wg = (int)blockIdx.x, nb = (int)gridDim.x;
+        const int stride = nb > FQT_WGS ? nb / FQT_WGS : 1;     // FQT_WGS workgroups spread over the grid
+        if ((int)threadIdx.x == 0 && trace_id >= 0 && wg % stride == 0 && wg / stride < FQT_WGS)
+            fqt_slot = (trace_id % FQT_LAUNCHES) * FQT_WGS + wg / stride;
+    }
+    auto fqt_finish = [&]() {
+        if ((int)threadIdx.x == 0 && fqt_slot >= 0) g_fq_trace[fqt_slot * FQT_PH + 5] = __builtin_amdgcn_s_memrealtime();
+    };
+    if (t == 0 && fqt_slot >= 0) g_fq_trace[fqt_slot * FQT_PH + 0] = fqt_t0;
+    FQ_STAMP(6);
+#endif
     const int lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -660,6 +692,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
 #pragma unroll
         for (int m = 0; m < 4; m++)
             if (m < M) mx[m] = wave_max(mx[m]);
+        FQ_STAMP(2);    // the activation rows have arrived (and, with a producer prologue, have been produced)
         if (lane == 0) {
 #pragma unroll
             for (int m = 0; m < 4; m++) wmax[w * 4 + m] = mx[m];
@@ -696,6 +729,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         asm volatile("" ::: "memory");
     }
 
+    FQ_STAMP(1);
     if constexpr (WT) {
         const int rounds = nunits / P;               // K % 1024 == 0: whole rounds of 8 groups
         for (int rd = 0; rd + 1 < rounds; rd++) {
@@ -726,6 +760,9 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
                 }
             }
         }
+#ifdef FQ_TRACE
+        fqt_finish();
+#endif
         return;
     }
     const int rounds = (nunits + W * P - 1) / (W * P);
@@ -740,6 +777,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
 #pragma unroll
     for (int p = 0; p < P; p++) compute_unit(w + ((rounds - 1) * P + p) * W, ring[p], p);
 
+    FQ_STAMP(3);
     // the tile's scales -> LDS as fp32 (x 1/16 for INT4)
     if (fast) {
 #pragma unroll
@@ -768,6 +806,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    FQ_STAMP(4);
     // wave ct runs the chains of column tile ct (W >= CT): thread (m, n) walks its groups in order
     const int ct = w, e = lane;
     if (ct < CT && e < M * 16) {
@@ -795,6 +834,9 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         if (scales_out != nullptr && tl == 0 && ct == 0 && cn == 0) scales_out[cm] = as;
         if (n0 + ct * SK_TN + cn < N) C[(size_t)cm * N + n0 + ct * SK_TN + cn] = f2h_mul(run, as);
     }
+#ifdef FQ_TRACE
+    fqt_finish();
+#endif
 }
 
 template <bool INT4, int W, int P, int CT>
@@ -804,7 +846,8 @@ __global__ __launch_bounds__(W * 64) void skinny_fq_kernel(const uint16_t* __res
                                                           const uint16_t* __restrict__ B_scales,
                                                           uint16_t* __restrict__ C, int M, int K, int N, int pk) {
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
-    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, (int)blockIdx.x, (int)threadIdx.x, fq_lds, pk != 0);
+    fq_body<INT4, W, P, CT>(X, scales_out, B, B_scales, C, M, K, N, (int)blockIdx.x, (int)threadIdx.x, fq_lds, (pk & 1) != 0,
+                            FqPro(), (pk >> 1) - 1);
 }
 
 // Several independent FP16-activation matmuls (M <= 4 each) in one launch: the projections
@@ -824,6 +867,7 @@ struct SkinnyBatch {
     uint16_t* C[SK_MAXB];
     int M[SK_MAXB], K[SK_MAXB], N[SK_MAXB];
     unsigned pk_mask;               // bit i: problem i's B is the tile-major twin
+    int trace_id;                   // diagnostic builds: the launch's index in the stamp table (-1: none)
     FqPro pro;                      // producer prologue operands (shared by every problem of the launch)
 };
 
@@ -847,7 +891,7 @@ __global__ __launch_bounds__(W * 64) SK_WPE_ATTR void skinny_batch_kernel(const 
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
     fq_body<INT4, W, P, CT>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                         reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi],
-                        bt.N[pi], tile, (int)threadIdx.x, fq_lds, (bt.pk_mask >> pi) & 1u);
+                        bt.N[pi], tile, (int)threadIdx.x, fq_lds, (bt.pk_mask >> pi) & 1u, FqPro(), bt.trace_id);
 }
 
 // The batched launch with wave tiles: a workgroup of 4 waves quantizes its problem's activation rows once
@@ -861,7 +905,7 @@ __global__ __launch_bounds__(256) void skinny_batch_wave_kernel(const SkinnyBatc
     extern __shared__ __attribute__((aligned(16))) float fq_lds[];
     fq_body<INT4, 4, INT4 ? 4 : 8, 1, 0, true>(reinterpret_cast<const uint16_t*>(bt.X[pi]), nullptr,
                                     reinterpret_cast<const uint8_t*>(bt.B[pi]), bt.Bs[pi], bt.C[pi], bt.M[pi],
-                                    bt.K[pi], bt.N[pi], tile4, (int)threadIdx.x, fq_lds, (bt.pk_mask >> pi) & 1u);
+                                    bt.K[pi], bt.N[pi], tile4, (int)threadIdx.x, fq_lds, (bt.pk_mask >> pi) & 1u, FqPro(), bt.trace_id);
 }
 
 // The same launch with a workgroup of 4 waves split into 4 / wt wave groups, each on its own tile:
@@ -885,9 +929,9 @@ __global__ __launch_bounds__(256) void skinny_batch_sub_kernel(const SkinnyBatch
     const uint16_t* X = reinterpret_cast<const uint16_t*>(bt.X[pi]);
     const uint8_t* B = reinterpret_cast<const uint8_t*>(bt.B[pi]);
     const bool pk = (bt.pk_mask >> pi) & 1u;
-    if (wt == 1) fq_body<INT4, 1, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro);
-    else if (wt == 2) fq_body<INT4, 2, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro);
-    else fq_body<INT4, 4, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro);
+    if (wt == 1) fq_body<INT4, 1, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro, bt.trace_id);
+    else if (wt == 2) fq_body<INT4, 2, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro, bt.trace_id);
+    else fq_body<INT4, 4, P, 1, PRO>(X, nullptr, B, bt.Bs[pi], bt.C[pi], bt.M[pi], bt.K[pi], bt.N[pi], tile, t, lds, pk, bt.pro, bt.trace_id);
 }
 
 // Row-major weights -> the tile-major twin (layout above); one thread per 16-byte piece.  rows16: rows of the twin
@@ -915,6 +959,13 @@ hipError_t launch_pack_weights(bool int4, const void* B, void* packed, size_t K,
                                               row_bytes);
     return hipGetLastError();
 }
+
+#ifdef FQ_TRACE
+extern "C" int cactus_hip_debug_fq_trace(unsigned long long* out, unsigned int* launches) {
+    *launches = (unsigned int)g_fq_trace_next;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq_trace), sizeof(unsigned long long) * FQT_LAUNCHES * FQT_WGS * FQT_PH);
+}
+#endif
 
 int g_skinny_ablate = 0;   // benchmarks only: bit0 skip chain, bit1 skip LDS writes, bit2 skip scale staging,
                            // bit4 record phase stamps (read back with skinny_read_trace)
@@ -1022,9 +1073,13 @@ static hipError_t launch_fq(bool int4, int W, int ct, const uint16_t* X, float* 
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const size_t tiles = (N + SK_TN * ct - 1) / (SK_TN * ct);
     const dim3 grid((unsigned)tiles), block(W * 64);
+    int pk_arg = pk ? 1 : 0;        // bit 0: tile-major twin; diagnostic builds: (stamp-table index + 1) above it
+#ifdef FQ_TRACE
+    pk_arg |= (g_fq_trace_next++ + 1) << 1;
+#endif
 #define FQ_LAUNCH(I4, WW, CC)                                                                                     \
     skinny_fq_kernel<I4, WW, 4, CC><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C,       \
-                                                             (int)M, (int)K, (int)N, (int)pk)
+                                                             (int)M, (int)K, (int)N, pk_arg)
 #define FQ_CASE(WW)                                                        \
     case WW:                                                                \
         if (ct == 2 && WW >= 2) {                                           \
@@ -1097,6 +1152,10 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     SkinnyBatch bt;
     memset(&bt, 0, sizeof bt);
     bt.count = (int)count;
+    bt.trace_id = -1;
+#ifdef FQ_TRACE
+    bt.trace_id = g_fq_trace_next++;
+#endif
     size_t tiles = 0, lds = 0, kmax = 0;
     for (size_t i = 0; i < count; i++)
         if (pr[i].K > kmax) kmax = pr[i].K;
@@ -1218,6 +1277,10 @@ hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyPr
     SkinnyBatch bt;
     memset(&bt, 0, sizeof bt);
     bt.count = (int)count;
+    bt.trace_id = -1;
+#ifdef FQ_TRACE
+    bt.trace_id = g_fq_trace_next++;
+#endif
     bt.pro.x2 = x2; bt.pro.w = w; bt.pro.sum_out = sum_out; bt.pro.eps = eps;
     size_t order[SK_MAXB];
     for (size_t i = 0; i < count; i++) order[i] = i;
