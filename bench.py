@@ -168,6 +168,30 @@ def live_traffic(kernel="skinny_batch"):
                       "reads x 2 for gfx950)" % means["FETCH_SIZE"][1]}
 
 
+def greedy_identity_summary():
+    """Free-running greedy identity, as measured by scripts/greedy_identity.py on the GPU box (64 device-only steps per
+    run, the CPU restatement shadowing the device's token stream; tests/test_gpu_free_running.py asserts the same
+    bars): the committed table profiles/r03_greedy_identity.json condensed per case.  The bench itself runs no CPU
+    decode (only the cpu_baseline leg may call the restatement)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_greedy_identity.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    out = {"source": "profiles/r03_greedy_identity.json (scripts/greedy_identity.py --full; 64 free-running steps per run)"}
+    for case, rows in table.items():
+        runs = list(rows.values())
+        diffs = [d for r in runs for d in r["different_choices"]]
+        out[case] = {"runs": len(runs), "runs_with_all_64_identical": sum(r["identity_length"] == r["steps"] for r in runs),
+                     "shortest_identity_length": min(r["identity_length"] for r in runs),
+                     "differing_choices": len(diffs),
+                     "largest_oracle_margin_at_a_differing_choice": max((d["oracle_margin"] for d in diffs), default=0.0),
+                     "largest_margin_over_logit_error_at_a_differing_choice":
+                         round(max((d["oracle_margin"] / d["logit_error"] for d in diffs), default=0.0), 3),
+                     "worst_logit_error_rel_to_largest_logit": max(r["worst_logit_error_rel"] for r in runs)}
+    return out
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this file with torch.distributed.run as
     a child process (one rank per GPU, rendezvous on 127.0.0.1), pass its output through (rank 0 prints the one
@@ -263,13 +287,8 @@ def main():
                 step(first + j, batched)
         return g
 
-    # The same step on the row-major weights alone (no twins yet), for the record; then every weight gets its
-    # tile-major twin, as a host does once when it loads a model, and all timed steps below stream the twins.
-    row_major_ms = None
-    if not args.traffic_child:
-        g_rm = capture(True, CHUNK, 0)
-        row_major_ms = time_events(lambda i: g_rm.replay(), 3, warm=1) / CHUNK
-        del g_rm
+    # Every weight gets its tile-major twin, as a host does once when it loads a model; all timed steps stream the
+    # twins (extra.gemv_sweep_row_major_layout times the same step on weights without twins).
     for ws in sets:
         for B, _ in ws.values():
             H.pack_weights(B)
@@ -348,6 +367,9 @@ def main():
         extra = extra_table(H, gen, big)
     if rank == 0:
         extra = dict(extra, single_launch_8192=single)
+        gi = greedy_identity_summary()
+        if gi is not None:
+            extra["greedy_identity"] = gi
     if world > 1 and not args.no_extra:
         sd = sharded_decode(H, gen, world)
         ns = nsplit_8b(H, world, rank)
@@ -370,7 +392,6 @@ def main():
                                    f"{CHUNK} steps per HIP graph; weights resident row-major [N,K] with the "
                                    "library's tile-major twins (cactus_hip_weights_pack_dev, made once at load)",
                        "bytes_per_step": step_bytes,
-                       "row_major_only_ms_per_step": None if row_major_ms is None else round(row_major_ms, 4),
                        "separate_launches_ms_per_step": round(seq_ms, 4),
                        "parallelism": f"replicas x{world} (independent sequences)"},
             "roofline": roofline,
@@ -677,6 +698,19 @@ def extra_table(H, gen, big):
     """Secondary measurements: launches captured in a HIP graph and event timed, rotating weight
     buffers (> 256 MiB in total) so that weights come from HBM."""
     ex = {}
+    # the headline step on weights WITHOUT tile-major twins (the reference's row-major [N, K] layout read as it lies)
+    sets = [{(K, N): make_weights(K, N, False, gen) for K in SIZES for N in SIZES} for _ in range(2)]
+    acts = {K: (torch.rand((1, K), device="cuda", generator=gen) * 2 - 1).half() for K in SIZES}
+    outs = {(K, N): torch.empty((1, N), dtype=torch.float16, device="cuda") for K in SIZES for N in SIZES}
+    order = sorted(((K, N) for K in SIZES for N in SIZES), key=lambda kn: -kn[0] * kn[1])
+    batches = [H.MatmulBatch([(acts[K], ws[(K, N)][0], ws[(K, N)][1], outs[(K, N)]) for K, N in order], 128) for ws in sets]
+    ms = time_graph(lambda i: batches[i & 1].run(), 10)
+    sb = sum(gemv_bytes(1, K, N) for K in SIZES for N in SIZES)
+    ex["gemv_sweep_row_major_layout"] = {"us_per_step": round(ms * 1e3, 2), "GBps": round(sb / (ms * 1e-3) / 1e9, 1),
+                                         "frac_hbm": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                         "note": "the same batched launch reading the row-major weights (no twins)"}
+    del sets, batches
+    torch.cuda.empty_cache()
     # per-shape GEMV, INT8 and packed INT4, M = 1 and M = 16
     for int4 in (False, True):
         tag = "int4" if int4 else "int8"
@@ -719,6 +753,17 @@ def extra_table(H, gen, big):
         tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
         rows[f"M{M}_K{K}_N{N}"] = {"us": round(ms * 1e3, 1), "TFLOPs": round(tf, 1),
                                    "frac_fp16_mfma_peak": round(tf / 2500.0, 4)}
+        if M == 1:      # a GEMV: HBM-bound; 8 rotating weights, row-major and with tile-major twins
+            bs = [b16] + [(torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).half() for _ in range(7)]
+            for tag in ("row_major", "twins"):
+                if tag == "twins":
+                    for b_ in bs:
+                        H.pack_weights(b_)
+                ms = time_graph(lambda i: H.matmul_f16(a16, bs[i % 8], out=o), 16)
+                gb = (2.0 * N * K + 2 * K + 2 * N) / (ms * 1e-3) / 1e9
+                rows[f"M{M}_K{K}_N{N}_gemv_{tag}"] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1),
+                                                      "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
+            del bs
         del a16, b16
     ex["matmul_f16"] = rows
     # decode attention over the INT8 KV cache

@@ -125,21 +125,26 @@ bool skinny_addressable(bool int4, size_t K, size_t N) {
 
 // Tile-major twins of row-major weight matrices (cactus_hip_weights_pack_dev): the streaming kernels read the
 // twin when the matrix a call names has one of the call's shape.  Keyed by the row-major device pointer.
+enum { TWIN_INT8 = 0, TWIN_INT4 = 1, TWIN_F16 = 2 };
 struct PackedTwin {
     void* ptr;
     size_t N, K;
-    bool int4;
+    int kind;
 };
+size_t twin_row_bytes(int kind, size_t K) { return kind == TWIN_INT4 ? K / 2 : (kind == TWIN_F16 ? K * 2 : K); }
 std::mutex g_pk_mu;
 std::unordered_map<const void*, PackedTwin> g_pk;
 std::atomic<size_t> g_pk_count{0};
 
-const void* packed_twin(const void* B, bool int4, size_t K, size_t N) {
+const void* packed_twin_kind(const void* B, int kind, size_t K, size_t N) {
     if (g_pk_count.load(std::memory_order_relaxed) == 0) return nullptr;
     std::lock_guard<std::mutex> lk(g_pk_mu);
     auto it = g_pk.find(B);
-    if (it == g_pk.end() || it->second.int4 != int4 || it->second.K != K || it->second.N != N) return nullptr;
+    if (it == g_pk.end() || it->second.kind != kind || it->second.K != K || it->second.N != N) return nullptr;
     return it->second.ptr;
+}
+const void* packed_twin(const void* B, bool int4, size_t K, size_t N) {
+    return packed_twin_kind(B, int4 ? TWIN_INT4 : TWIN_INT8, K, N);
 }
 
 int matmul_q(bool int4, const int8_t* A, const float* As, const void* B, const cactus_half_t* Bs,
@@ -301,31 +306,34 @@ int cactus_hip_workspace_reserve(size_t bytes) {
     return workspace(bytes, &ws);
 }
 
-int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int int4, void* stream) {
+int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int kind, void* stream) {
     if (!B || N == 0 || K == 0) return fail(CACTUS_HIP_EINVAL, "weights_pack: null or empty matrix");
-    if (K % (int4 ? 256 : 128) != 0) return fail(CACTUS_HIP_EINVAL, "weights_pack: K must be a multiple of 128 (INT4: 256)");
+    if (kind < TWIN_INT8 || kind > TWIN_F16) return fail(CACTUS_HIP_EINVAL, "weights_pack: kind must be 0 (INT8), 1 (INT4) or 2 (FP16)");
+    const size_t row_bytes = twin_row_bytes(kind, K);
+    if (K % (kind == TWIN_INT4 ? 256 : (kind == TWIN_F16 ? 64 : 128)) != 0)
+        return fail(CACTUS_HIP_EINVAL, "weights_pack: K must be a multiple of 128 (INT4: 256, FP16: 64)");
     if (!aligned(B, 16)) return fail(CACTUS_HIP_EINVAL, "weights_pack: matrix must be 16-byte aligned");
-    if (!skinny_addressable(int4 != 0, K, N)) return fail(CACTUS_HIP_EINVAL, "weights_pack: matrix of 2 GiB or more");
-    const size_t bytes = ((N + 15) & ~size_t(15)) * (int4 ? K / 2 : K);
+    const size_t bytes = ((N + 15) & ~size_t(15)) * row_bytes;
+    if (bytes >= (size_t(1) << 31)) return fail(CACTUS_HIP_EINVAL, "weights_pack: matrix of 2 GiB or more");
     void* twin = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_pk_mu);
         auto it = g_pk.find(B);
-        if (it != g_pk.end() && it->second.N == N && it->second.K == K && it->second.int4 == (int4 != 0))
+        if (it != g_pk.end() && it->second.N == N && it->second.K == K && it->second.kind == kind)
             twin = it->second.ptr;                    // packed before: refresh the twin in place
         else if (it != g_pk.end())
             return fail(CACTUS_HIP_EINVAL, "weights_pack: this address is packed with another shape; release it first");
     }
     const bool fresh = twin == nullptr;
     if (fresh && hipMalloc(&twin, bytes) != hipSuccess) return fail(CACTUS_HIP_ENOMEM, "weights_pack hipMalloc");
-    hipError_t e = launch_pack_weights(int4 != 0, B, twin, K, N, S(stream));
+    hipError_t e = launch_pack_weights(row_bytes, B, twin, N, S(stream));
     if (e != hipSuccess) {
         if (fresh) (void)hipFree(twin);
         return fail(CACTUS_HIP_ERUNTIME, "weights_pack launch", e);
     }
     if (fresh) {
         std::lock_guard<std::mutex> lk(g_pk_mu);
-        g_pk[B] = PackedTwin{twin, N, K, int4 != 0};
+        g_pk[B] = PackedTwin{twin, N, K, kind};
         g_pk_count.store(g_pk.size(), std::memory_order_relaxed);
     }
     return CACTUS_HIP_OK;
@@ -533,6 +541,12 @@ int cactus_hip_matmul_f16_dev(const cactus_half_t* a, const cactus_half_t* bT, c
                               size_t M, size_t K, size_t N, void* stream) {
     if (M == 0 || N == 0) return CACTUS_HIP_OK;
     if (!a || !bT || !c) return fail(CACTUS_HIP_EINVAL, "matmul_f16: null operand");
+    if (gemv_f16_ok(a, bT, M, K, N)) {       // decode rows: the streaming kernel (and the weight's twin when it has one)
+        const void* twin = packed_twin_kind(bT, TWIN_F16, K, N);
+        hipError_t ge = launch_gemv_f16(a, static_cast<const uint16_t*>(twin ? twin : bT), c, M, K, N, S(stream), twin != nullptr);
+        if (ge != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_f16 launch", ge);
+        return CACTUS_HIP_OK;
+    }
     hipError_t e = launch_matmul_f16(a, bT, c, M, K, N, S(stream));
     if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "matmul_f16 launch", e);
     return CACTUS_HIP_OK;
@@ -1172,6 +1186,29 @@ int cactus_hip_attention_hybrid_int8_fp16_dev(
 
 size_t cactus_hip_noalloc_scratch_bytes(void) { return NOALLOC_SCRATCH_BYTES; }
 
+size_t cactus_hip_attention_hybrid_records_bytes(size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
+                                                 size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+                                                 size_t position_offset, int is_causal, size_t group_size) {
+    AttnArgs a{};
+    a.B = batch_size; a.S = seq_len; a.cache_len = cache_len; a.new_len = new_len;
+    a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.D = head_dim;
+    a.position_offset = position_offset; a.is_causal = is_causal; a.qgs = group_size;
+    a.cache_batch_stride = cache_len * num_kv_heads * head_dim;
+    a.f16_mode = 0;
+    if (a.B == 0 || a.S == 0 || a.Hq == 0 || a.D == 0 || a.Hkv == 0 || a.Hq % a.Hkv != 0) return 0;
+    // kernel selection looks at which operands exist and how they are aligned: stand-ins for 16-byte-aligned
+    // operands, never dereferenced
+    auto* stand_in = reinterpret_cast<unsigned char*>(uintptr_t(256));
+    a.q = reinterpret_cast<const uint16_t*>(stand_in);
+    a.out = reinterpret_cast<uint16_t*>(stand_in);
+    if (cache_len) {
+        a.k_cached = a.v_cached = reinterpret_cast<const int8_t*>(stand_in);
+        a.k_scales = a.v_scales = reinterpret_cast<const float*>(stand_in);
+    }
+    if (new_len) a.k_new = a.v_new = reinterpret_cast<const uint16_t*>(stand_in);
+    return attn_workspace_bytes(a);
+}
+
 int cactus_hip_attention_hybrid_int8_fp16_noalloc_dev(
     const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
     const float* k_scales, const float* v_scales, const cactus_half_t* keys_new,
@@ -1386,16 +1423,18 @@ void* upload(size_t slot, const void* host, size_t bytes) {
     return d;
 }
 
-// FNV-1a over 64 evenly spaced 64-byte samples (the whole buffer when it is small) and the size: a
-// few microseconds per call, enough to notice that an address now holds other data (a freed and
-// reused heap buffer, a scratch buffer a caller refills).
+// FNV-1a over the whole buffer up to 1 MiB, over 64 evenly spaced 64-byte samples (and the size) beyond: a few
+// microseconds per call.  It notices that an address now holds other data (a freed and reused heap buffer, a
+// scratch buffer a caller refills); it does NOT notice a change between the samples of a large buffer: weights
+// passed by host pointer must stay as they are while cached, and cactus_hip_release_weights is the way to
+// refresh one that was rewritten in place (the reference's weights are read-only mappings of its files).
 uint64_t content_signature(const void* host, size_t bytes) {
     const unsigned char* p = static_cast<const unsigned char*>(host);
     uint64_t h = 1469598103934665603ull ^ bytes;
     auto mix = [&](const unsigned char* q, size_t n) {
         for (size_t i = 0; i < n; i++) h = (h ^ q[i]) * 1099511628211ull;
     };
-    if (bytes <= 64 * 64) {
+    if (bytes <= (size_t(1) << 20)) {
         mix(p, bytes);
     } else {
         const size_t stride = (bytes - 64) / 63;

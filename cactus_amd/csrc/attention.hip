@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnParams p) {
     const int qsub = item / (int)a.B;
     const int h0 = kvh * p.gq + qsub * NQ;
 
-    const int cl = F16MODE ? 0 : (a.cache_lens ? a.cache_lens[b] : (int)a.cache_len);
+    const int cl = F16MODE ? 0 : (a.cache_lens ? min(max(a.cache_lens[b], 0), (int)a.cache_len) : (int)a.cache_len);
     const int new_len = (int)a.new_len;
     const int KV = cl + new_len;
     const long long qabs = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset) + qp;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(64) void attn_generic_kernel(const AttnParams p) {
     const int b = (int)(item / Hq);
     const int kvh = h / p.gq;
 
-    const int cl = F16MODE ? 0 : (a.cache_lens ? a.cache_lens[b] : (int)a.cache_len);
+    const int cl = F16MODE ? 0 : (a.cache_lens ? min(max(a.cache_lens[b], 0), (int)a.cache_len) : (int)a.cache_len);
     const int new_len = (int)a.new_len;
     const int KV = cl + new_len;
     const long long qabs = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset) + qp;

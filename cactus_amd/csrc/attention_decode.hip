@@ -158,7 +158,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     const int kvh = item % Hkv, b = item / Hkv;
     const int h0 = kvh * gq;
 
-    const int cl = a.cache_lens ? a.cache_lens[b] : (int)a.cache_len;
+    // a device-side length is never trusted beyond the rows the caller vouched for (a.cache_len: the slot count)
+    const int cl = a.cache_lens ? min(max(a.cache_lens[b], 0), (int)a.cache_len) : (int)a.cache_len;
     const int new_len = (int)a.new_len;
     const int KV = cl + new_len;
     const long long qabs = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset);

@@ -697,7 +697,7 @@ void attn_prefill_hybrid_kernel(const AttnArgs a, float* __restrict__ ws, int ns
     const int q_first = qt * PF_QTILE + w * 32;
     const int qi = q_first + jq;
     const bool q_live = qi < S;
-    const int cl = a.cache_lens ? a.cache_lens[b] : (int)a.cache_len;
+    const int cl = a.cache_lens ? min(max(a.cache_lens[b], 0), (int)a.cache_len) : (int)a.cache_len;
     const int KV = cl + new_len;
     const long long off = (long long)(a.pos_offsets ? (size_t)a.pos_offsets[b] : a.position_offset);
     float scale = a.scale;

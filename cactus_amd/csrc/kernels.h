@@ -51,8 +51,8 @@ hipError_t launch_unpack_int4(const uint8_t* packed, int8_t* unpacked, size_t co
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                                 size_t K, size_t N, hipStream_t st, bool packed = false);
-// packed must hold ((N + 15) & ~15) * (int4 ? K / 2 : K) bytes; K a multiple of 128 (INT4: 256)
-hipError_t launch_pack_weights(bool int4, const void* B, void* packed, size_t K, size_t N, hipStream_t st);
+// packed must hold ((N + 15) & ~15) * row_bytes bytes; row_bytes (K for INT8, K / 2 for INT4, 2 K for FP16) a multiple of 128
+hipError_t launch_pack_weights(size_t row_bytes, const void* B, void* packed, size_t N, hipStream_t st);
 
 // FP16 activations quantized inside the GEMV kernel (one launch).  Only for shapes
 // skinny_fused_quant_ok accepts (M <= 4, activations + group sums fit LDS); scales_out may be null.
@@ -110,6 +110,10 @@ hipError_t launch_matmul_generic(bool int4, const int8_t* A, const float* A_scal
                                  size_t K, size_t N, size_t gs, hipStream_t st);
 
 // matmul_f16.hip
+// streaming GEMV for up to 16 activation rows (K a multiple of 64, rows staged in LDS); packed: bT is the tile-major twin
+bool gemv_f16_ok(const uint16_t* a, const uint16_t* bT, size_t M, size_t K, size_t N);
+hipError_t launch_gemv_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K, size_t N,
+                           hipStream_t st, bool packed);
 hipError_t launch_matmul_f16(const uint16_t* a, const uint16_t* bT, uint16_t* c, size_t M, size_t K,
                              size_t N, hipStream_t st);
 

@@ -949,8 +949,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const uint8_t* __rest
     }
 }
 
-hipError_t launch_pack_weights(bool int4, const void* B, void* packed, size_t K, size_t N, hipStream_t st) {
-    const size_t row_bytes = int4 ? K / 2 : K;
+hipError_t launch_pack_weights(size_t row_bytes, const void* B, void* packed, size_t N, hipStream_t st) {
     if (row_bytes == 0 || row_bytes % 128 != 0 || N == 0) return hipErrorInvalidValue;
     const size_t rows16 = (N + 15) & ~size_t(15);
     const size_t total = rows16 * row_bytes / 16;

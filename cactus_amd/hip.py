@@ -70,6 +70,7 @@ SIGNATURES = {
     "cactus_hip_attention_hybrid_int8_fp16_dev": (_i, [_vp] * 8 + [_sz] * 7 + [_f, _sz, _i, _sz, _vp]),
     "cactus_hip_attention_hybrid_int8_fp16_noalloc_dev": (_i, [_vp] * 8 + [_sz] * 7 + [_f, _sz, _i, _sz, _vp]),
     "cactus_hip_noalloc_scratch_bytes": (_sz, []),
+    "cactus_hip_attention_hybrid_records_bytes": (_sz, [_sz] * 8 + [_i, _sz]),
     "cactus_hip_attention_hybrid_int8_fp16_batched_dev": (
         _i, [_vp] * 8 + [_sz, _sz, _vp, _sz, _sz, _sz, _sz, _f, _vp, _sz, _sz, _sz, _sz, _vp]),
     "cactus_hip_attention_decode_fused_f16_dev": (
@@ -176,12 +177,12 @@ def pack_weights(B):
     """Give the device-resident weight matrix B (int8 [N, K] or packed uint8 [N, K/2]) a tile-major twin: every
     later matmul with M <= 16 that names B streams the twin (cactus_hip_weights_pack_dev).  B must stay alive and
     unchanged until release_packed(B); the twin is released when the tensor object goes away."""
-    int4 = B.dtype == torch.uint8
-    _dev(B, torch.uint8 if int4 else torch.int8)
+    kind = {torch.int8: 0, torch.uint8: 1, torch.float16: 2}[B.dtype]     # INT8, packed INT4, FP16
+    _dev(B, B.dtype)
     N = B.shape[0]
-    K = B.shape[1] * (2 if int4 else 1)
+    K = B.shape[1] * (2 if kind == 1 else 1)
     fresh = not is_packed(B)
-    _check(lib.cactus_hip_weights_pack_dev(_p(B), N, K, int(int4), _stream()))
+    _check(lib.cactus_hip_weights_pack_dev(_p(B), N, K, kind, _stream()))
     if fresh:   # the twin is keyed by B's address: it must not outlive the tensor
         weakref.finalize(B, lib.cactus_hip_weights_release_packed_dev, C.c_void_p(B.data_ptr()))
     return B

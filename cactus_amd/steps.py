@@ -125,15 +125,24 @@ class _KvState:
         self.positions = torch.zeros((batch,), dtype=torch.int32, device="cuda")
         self.cache_lens = torch.zeros((batch,), dtype=torch.int32, device="cuda")
         self.tok = torch.zeros((batch,), dtype=torch.int32, device="cuda")
+        self.host_max_position = 0      # host mirror of max(positions): a step past the last slot is refused, not dropped
 
     def set_positions(self, positions):
         """positions: tokens each sequence has seen (host list); cache lengths follow."""
         p = torch.tensor(list(positions), dtype=torch.int32)
+        self.host_max_position = int(p.max()) if p.numel() else 0
         self.positions.copy_(p)
         self.cache_lens.copy_(torch.clamp(p, max=self.window) if self.window else p)
 
     def advance(self, n=1):
         H.kv_positions_advance(self.positions, self.cache_lens, n, self.window)
+        self.host_max_position += n
+
+    def check_room(self):
+        """Without a window every token needs a slot of its own: the kernels clamp a sequence that has run out of
+        slots (its new token is not appended) rather than write past its slice, so running out is an error here."""
+        if not self.window and self.host_max_position >= self.slots:
+            raise RuntimeError(f"KV cache full: a sequence is at position {self.host_max_position} of {self.slots} slots")
 
 
 class Qwen3Decode:
@@ -190,6 +199,7 @@ class Qwen3Decode:
 
     def step(self, advance=True):
         c, kv, b = self.cfg, self.kv, self.batch
+        kv.check_room()
         Hq, Hkv, D, eps, theta = c["q_heads"], c["kv_heads"], c["head_dim"], c["eps"], c["theta"]
         Ls, emb = self.w["layers"], self.w["emb"]
         head = self.w.get("head", emb)
@@ -410,6 +420,7 @@ class Lfm2Decode:
 
     def step(self, advance=True):
         c, kv, b = self.cfg, self.kv, self.batch
+        kv.check_room()
         Hd, Hq, Hkv, D, eps, theta = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["eps"], c["theta"]
         Ls, head = self.w["layers"], self.w["emb"]
         NL = len(Ls)

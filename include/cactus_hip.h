@@ -72,21 +72,23 @@ int   cactus_hip_synchronize(void* stream);
 int   cactus_hip_workspace_reserve(size_t bytes);
 
 /* Host-pointer family: drop cached device copies of weights (all, or the one
- * registered under host_ptr on the current device). */
+ * registered under host_ptr on the current device).  A weight passed by host pointer is uploaded on
+ * first use and must not change while cached: a later call re-checks the whole buffer up to 1 MiB but
+ * only 64 samples of a larger one, so a partial rewrite in place can go unnoticed - release it first. */
 void cactus_hip_release_weights(const void* host_ptr);
 
 /* Tile-major twins of device-resident weights.  No counterpart in the reference, whose weights stay in the
  * row-major [N, K] layout of its files (graph_io.cpp:49-73); the matmul entries below keep taking that layout.
- * Call this once when a quantized weight matrix (B int8[N, K], or packed uint8[N, K/2] with int4 != 0) has been
- * made resident: the library allocates a second copy in which every 16 rows x 128 bytes unit of the streaming
+ * Call this once when a weight matrix (kind 0: B int8[N, K]; 1: packed INT4 uint8[N, K/2]; 2: half[N, K], the
+ * b_transposed operand of cactus_hip_matmul_f16_dev) has been made resident: the library allocates a second copy in which every 16 rows x 128 bytes unit of the streaming
  * kernels is one contiguous 2 KB run (a whole 16-row tile is one contiguous stretch), and every later call with
  * M <= 16 rows that names B with the same N and K (the _dev matmuls, their _f16act, _batch, _norm / _silu /
  * _gelu forms) reads the twin instead: same integer sums, same fp32 chain, same bits, about a fifth less
  * time.  Launches with more rows read B itself, which must stay as it is.  B must not change while it has a
  * twin: call again to refresh the twin after rewriting B, or release it.  The call allocates (not under stream
- * capture); K a multiple of 128 (INT4: 256), B 16-byte aligned and below 2 GiB.  release(NULL) drops every twin;
+ * capture); K a multiple of 128 (INT4: 256, FP16: 64), B 16-byte aligned and below 2 GiB.  release(NULL) drops every twin;
  * release synchronizes the device before it frees. */
-int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int int4, void* stream);
+int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int kind, void* stream);
 int cactus_hip_weights_release_packed_dev(const void* B);
 int cactus_hip_weights_is_packed_dev(const void* B);
 
@@ -461,6 +463,12 @@ int cactus_hip_attention_hybrid_int8_fp16_dev(
  * (call it before capturing).  Calls on one device share the array: two that overlap (different
  * streams, or threads) race.  Nothing in it has to be cleared between calls. */
 size_t cactus_hip_noalloc_scratch_bytes(void);
+/* Bytes of split-KV records the hybrid attention entries keep for this shape with 16-byte-aligned operands (0: none): what the
+ * allocation-free entry compares with cactus_hip_noalloc_scratch_bytes(), and what
+ * cactus_hip_workspace_reserve needs at least before the allocating entry is captured. */
+size_t cactus_hip_attention_hybrid_records_bytes(size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
+                                                 size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+                                                 size_t position_offset, int is_causal, size_t group_size);
 int cactus_hip_attention_hybrid_int8_fp16_noalloc_dev(
     const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
     const float* k_scales, const float* v_scales,

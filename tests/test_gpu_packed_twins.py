@@ -166,6 +166,31 @@ def test_twin_follows_a_repack_and_ignores_other_shapes(H):
     assert (bits(H.matmul_f16act(dx, half, dBs[:N // 2].contiguous())) == oracle_f16act(x, B2[:N // 2], Bs[:N // 2], False)).all()
 
 
+@pytest.mark.parametrize("M,K,N", [(1, 4096, 4096), (1, 64, 1), (3, 1024, 1000), (16, 1024, 333), (2, 8192, 48), (1, 1024, 151936)])
+def test_f16_gemv_streams_and_its_twin_gives_the_same_bits(H, M, K, N):
+    """cactus_hip_matmul_f16_dev with up to 16 rows takes the streaming kernel (fp32 accumulation on the matrix
+    cores; the reference accumulates in fp16 lanes, kernel_gemm.cpp:17-126): within the reference's own distance
+    from the exact product plus one ulp, and the same bits from the tile-major twin of the FP16 weight."""
+    rng = np.random.default_rng(M + K + N)
+    a = rng.uniform(-1, 1, (M, K)).astype(np.float16)
+    b = rng.uniform(-1, 1, (N, K)).astype(np.float16)
+    da, db = dev(a), dev(b)
+    got = H.matmul_f16(da, db)
+    exact = a.astype(np.float64) @ b.astype(np.float64).T
+    err = np.abs(got.cpu().numpy().astype(np.float64) - exact)
+    if N <= 4096:
+        ref = O.matmul_f16(a, b).view(np.float16).astype(np.float64)
+        ref_err = np.abs(ref - exact)
+        ulp = np.maximum(np.abs(exact), 2.0 ** -14) * 2.0 ** -10
+        assert (err <= ref_err.max() + ulp).all()
+    assert (err <= 2e-3 + 1e-3 * np.abs(exact)).all()            # fp32 accumulation, one rounding to fp16
+    H.pack_weights(db)
+    assert H.is_packed(db)
+    again = H.matmul_f16(da, db)
+    assert torch.equal(got.view(torch.int16), again.view(torch.int16))
+    H.release_packed(db)
+
+
 def test_pack_argument_errors(H):
     import ctypes as C
     from cactus_amd.hip import lib
