@@ -9,8 +9,8 @@ LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libcactus_hip.so")
 
 SOURCES = ["quant_kernels.hip", "matmul_skinny.hip", "matmul_gemm.hip", "matmul_generic.hip",
-           "matmul_f16.hip", "attention.hip", "attention_decode.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "comm.hip", "api.hip", "graph.cpp"]
-HEADERS = ["common.hip.h", "block_math.hip.h", "kernels.h", "graph.h", os.path.join("..", "..", "include", "cactus_hip.h")]
+           "matmul_f16.hip", "attention.hip", "attention_decode.hip", "attention_prefill.hip", "block_ops.hip", "conv_ops.hip", "sampler.hip", "comm.hip", "api.hip", "graph.cpp", "steps.cpp"]
+HEADERS = ["common.hip.h", "block_math.hip.h", "kernels.h", "graph.h", os.path.join("..", "..", "include", "cactus_hip.h"), os.path.join("..", "..", "include", "cactus_hip_steps.h")]
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit fmaf(), so the
 # compiler must not introduce (or break) any -- results are compared bit for bit.
@@ -64,20 +64,24 @@ def build(force=False, verbose=False):
 
 
 def build_examples(force=False, verbose=False):
-    """examples/qwen_graph_decode.cpp -> cactus_amd/lib/qwen_graph_decode: a C++ host program on the C ABI
-    (host code only; it finds the library next to itself)."""
+    """examples/*.cpp -> cactus_amd/lib/<name>: C++ host programs on the C ABI (host code only; they find the library
+    next to themselves)."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "examples", "qwen_graph_decode.cpp")
-    exe = os.path.join(LIBDIR, "qwen_graph_decode")
-    if not os.path.exists(src):
-        return None
     inc = os.path.join(root, "include")
-    if force or _stale(exe, [src, SO, os.path.join(inc, "cactus_hip.h"), os.path.join(inc, "cactus_hip_graph.h")]):
-        cmd = ["hipcc", "-O2", "-std=c++17", "-Wall", "-I", inc, src, "-L", LIBDIR, "-lcactus_hip", "-Wl,-rpath,$ORIGIN", "-o", exe]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-    return exe
+    hdrs = [os.path.join(inc, h) for h in ("cactus_hip.h", "cactus_hip_graph.h", "cactus_hip_steps.h")]
+    built = []
+    for name in ("qwen_graph_decode", "qwen_batched_decode"):
+        src = os.path.join(root, "examples", name + ".cpp")
+        exe = os.path.join(LIBDIR, name)
+        if not os.path.exists(src):
+            continue
+        if force or _stale(exe, [src, SO] + hdrs):
+            cmd = ["hipcc", "-O2", "-std=c++17", "-Wall", "-I", inc, src, "-L", LIBDIR, "-lcactus_hip", "-Wl,-rpath,$ORIGIN", "-o", exe]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        built.append(exe)
+    return built
 
 
 if __name__ == "__main__":

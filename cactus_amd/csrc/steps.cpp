@@ -1,0 +1,332 @@
+// Whole decode / prefill steps (include/cactus_hip_steps.h): host code that enqueues the launches of cactus_hip.h in
+// the order the reference's models build their graphs (models/model_qwen.cpp:51-172, models/model_lfm2.cpp:123-331;
+// Model::decode / Model::prefill, engine_model.cpp:170-297), for batches of independent sequences.
+#include "../../include/cactus_hip_steps.h"
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+namespace cactus_hip {
+void set_last_error(const char* msg);
+}
+
+namespace {
+
+using half_t = cactus_half_t;
+
+int fail(const char* what) {
+    cactus_hip::set_last_error(what);
+    return CACTUS_HIP_EINVAL;
+}
+
+#define STEP_TRY(expr)                      \
+    do {                                    \
+        const int rc_ = (expr);             \
+        if (rc_ != CACTUS_HIP_OK) return rc_; \
+    } while (0)
+
+// carve a workspace into 256-byte aligned pieces; with base == nullptr it only measures
+struct Carver {
+    unsigned char* base;
+    size_t used = 0;
+    explicit Carver(void* b) : base(static_cast<unsigned char*>(b)) {}
+    template <typename T>
+    T* take(size_t count) {
+        const size_t at = used;
+        used += (count * sizeof(T) + 255) & ~size_t(255);
+        return base ? reinterpret_cast<T*>(base + at) : nullptr;
+    }
+};
+
+struct Out {
+    const cactus_hip_qmatrix* w;
+    half_t* c;
+};
+
+// Several weights against one quantized activation matrix (q/k/v, gate/up): one launch per precision present
+int shared_matmuls(const int8_t* A, const float* As, const Out* outs, size_t count, size_t M, size_t K, void* stream) {
+    for (int want4 = 0; want4 < 2; want4++) {
+        cactus_hip_matmul_weights ws[8];
+        size_t n = 0;
+        for (size_t i = 0; i < count; i++)
+            if ((outs[i].w->int4 != 0) == (want4 != 0)) ws[n++] = cactus_hip_matmul_weights{outs[i].w->B, outs[i].w->scales, outs[i].c, outs[i].w->N};
+        if (n == 0) continue;
+        STEP_TRY(want4 ? cactus_hip_matmul_int4_shared_dev(A, As, ws, n, M, K, 128, stream)
+                       : cactus_hip_matmul_int8_shared_dev(A, As, ws, n, M, K, 128, stream));
+    }
+    return CACTUS_HIP_OK;
+}
+
+// The same with the rows produced in the launch: rms_norm(x [+ addend]) * w (kind 1) or silu(x) * addend (kind 2)
+int produced_matmuls(int kind, const half_t* x, const half_t* addend, const half_t* norm_w, half_t* sum_out, float eps,
+                     const Out* outs, size_t count, size_t M, size_t K, void* stream) {
+    for (int want4 = 0; want4 < 2; want4++) {
+        cactus_hip_matmul_weights ws[8];
+        size_t n = 0;
+        for (size_t i = 0; i < count; i++)
+            if ((outs[i].w->int4 != 0) == (want4 != 0)) ws[n++] = cactus_hip_matmul_weights{outs[i].w->B, outs[i].w->scales, outs[i].c, outs[i].w->N};
+        if (n == 0) continue;
+        if (kind == 1)
+            STEP_TRY(want4 ? cactus_hip_matmul_int4_norm_f16act_dev(x, addend, norm_w, sum_out, eps, ws, n, M, K, 128, stream)
+                           : cactus_hip_matmul_int8_norm_f16act_dev(x, addend, norm_w, sum_out, eps, ws, n, M, K, 128, stream));
+        else
+            STEP_TRY(want4 ? cactus_hip_matmul_int4_silu_f16act_dev(x, addend, ws, n, M, K, 128, stream)
+                           : cactus_hip_matmul_int8_silu_f16act_dev(x, addend, ws, n, M, K, 128, stream));
+    }
+    return CACTUS_HIP_OK;
+}
+
+int matmul_q(const int8_t* A, const float* As, const cactus_hip_qmatrix& w, half_t* C, size_t M, void* stream) {
+    return w.int4 ? cactus_hip_matmul_int4_dev(A, As, static_cast<const uint8_t*>(w.B), w.scales, C, M, w.K, w.N, 128, stream)
+                  : cactus_hip_matmul_int8_dev(A, As, static_cast<const int8_t*>(w.B), w.scales, C, M, w.K, w.N, 128, stream);
+}
+
+int matmul_f16act(const half_t* X, const cactus_hip_qmatrix& w, half_t* C, size_t M, void* stream) {
+    return w.int4 ? cactus_hip_matmul_int4_f16act_dev(X, static_cast<const uint8_t*>(w.B), w.scales, C, M, w.K, w.N, 128, stream)
+                  : cactus_hip_matmul_int8_f16act_dev(X, static_cast<const int8_t*>(w.B), w.scales, C, M, w.K, w.N, 128, stream);
+}
+
+bool check_matrix(const cactus_hip_qmatrix& m, size_t N, size_t K) {
+    return m.B != nullptr && m.scales != nullptr && m.N == N && m.K == K;
+}
+
+const char* check_weights(const cactus_hip_decoder_weights* w, bool attention_only) {
+    if (!w || !w->blocks || w->layers == 0) return "decoder step: null model description";
+    if (w->hidden == 0 || w->q_heads == 0 || w->kv_heads == 0 || w->head_dim == 0 || w->ffn == 0 || w->vocab == 0)
+        return "decoder step: zero model dimension";
+    if (w->q_heads % w->kv_heads != 0) return "decoder step: q heads must be a multiple of kv heads";
+    if (w->hidden % 128 != 0 || w->ffn % 128 != 0 || (w->q_heads * w->head_dim) % 128 != 0)
+        return "decoder step: hidden, ffn and heads * head_dim must be multiples of the weight group (128)";
+    if (!check_matrix(w->embedding, w->vocab, w->hidden) || w->embedding.int4) return "decoder step: embedding must be INT8 [vocab, hidden]";
+    if (w->lm_head.B && !check_matrix(w->lm_head, w->vocab, w->hidden)) return "decoder step: lm_head must be [vocab, hidden]";
+    if (!w->final_norm) return "decoder step: null final norm";
+    const size_t Hd = w->hidden, QD = w->q_heads * w->head_dim, KD = w->kv_heads * w->head_dim;
+    for (size_t i = 0; i < w->layers; i++) {
+        const cactus_hip_block_weights& b = w->blocks[i];
+        if (!b.in_norm || !b.post_norm) return "decoder step: null block norm";
+        if (!check_matrix(b.gate, w->ffn, Hd) || !check_matrix(b.up, w->ffn, Hd) || !check_matrix(b.down, Hd, w->ffn))
+            return "decoder step: MLP matrices must be gate / up [ffn, hidden], down [hidden, ffn]";
+        if (b.kind == 0) {
+            if (!check_matrix(b.q, QD, Hd) || !check_matrix(b.k, KD, Hd) || !check_matrix(b.v, KD, Hd) || !check_matrix(b.o, Hd, QD))
+                return "decoder step: attention matrices must be q [Hq D, hidden], k / v [Hkv D, hidden], o [hidden, Hq D]";
+            if (!b.q_norm || !b.k_norm) return "decoder step: null q / k norm";
+        } else if (b.kind == 1) {
+            if (attention_only) return "prefill chunk: blocks with the short convolution are not supported";
+            if (!check_matrix(b.in_proj, 3 * Hd, Hd) || !check_matrix(b.out_proj, Hd, Hd) || !b.conv_weight)
+                return "decoder step: conv block needs in_proj [3 hidden, hidden], out_proj [hidden, hidden], conv_weight";
+            if (b.in_proj.int4 || b.out_proj.int4) return "decoder step: conv block projections must be INT8";
+            if (w->conv_taps < 2 || w->conv_rows == 0) return "decoder step: conv_taps / conv_rows missing";
+        } else {
+            return "decoder step: unknown block kind";
+        }
+    }
+    return nullptr;
+}
+
+struct DecodeBuffers {
+    half_t *h0, *hid, *x, *h2, *qo, *ko, *vo, *qr, *kr, *ao, *oo, *go, *uo, *dn, *ipj;
+    int8_t *xq, *xq2, *aq, *oq, *cq;
+    float *xs, *xs2, *as, *os, *cs;
+};
+
+size_t carve_decode(const cactus_hip_decoder_weights* w, size_t b, void* base, DecodeBuffers* out) {
+    Carver c(base);
+    const size_t Hd = w->hidden, QD = w->q_heads * w->head_dim, KD = w->kv_heads * w->head_dim, F = w->ffn;
+    DecodeBuffers d;
+    d.h0 = c.take<half_t>(b * Hd); d.hid = c.take<half_t>(b * Hd); d.x = c.take<half_t>(b * Hd); d.h2 = c.take<half_t>(b * Hd);
+    d.qo = c.take<half_t>(b * QD); d.ko = c.take<half_t>(b * KD); d.vo = c.take<half_t>(b * KD);
+    d.qr = c.take<half_t>(b * QD); d.kr = c.take<half_t>(b * KD); d.ao = c.take<half_t>(b * QD);
+    d.oo = c.take<half_t>(b * Hd); d.go = c.take<half_t>(b * F); d.uo = c.take<half_t>(b * F); d.dn = c.take<half_t>(b * Hd);
+    d.ipj = c.take<half_t>(b * 3 * Hd);
+    d.xq = c.take<int8_t>(b * Hd); d.xq2 = c.take<int8_t>(b * Hd); d.aq = c.take<int8_t>(b * F);
+    d.oq = c.take<int8_t>(b * QD); d.cq = c.take<int8_t>(b * Hd);
+    d.xs = c.take<float>(b); d.xs2 = c.take<float>(b); d.as = c.take<float>(b); d.os = c.take<float>(b); d.cs = c.take<float>(b);
+    if (out) *out = d;
+    return c.used;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t cactus_hip_decode_step_workspace_bytes(const cactus_hip_decoder_weights* w, size_t batch) {
+    if (!w || batch == 0) return 0;
+    return carve_decode(w, batch, nullptr, nullptr);
+}
+
+int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus_hip_decode_state* kv, void* workspace,
+                               cactus_half_t* logits, int advance, void* stream) {
+    if (const char* bad = check_weights(w, false)) return fail(bad);
+    if (!kv || kv->batch == 0) return fail("decode step: null or empty state");
+    if (!workspace || !logits) return fail("decode step: null workspace or logits");
+    if (!kv->positions || !kv->cache_lens || !kv->tokens) return fail("decode step: null positions / cache_lens / tokens");
+    if (kv->window && (kv->sink >= kv->window || kv->window > kv->slots)) return fail("decode step: need sink < window <= slots");
+    const size_t b = kv->batch, Hd = w->hidden, Hq = w->q_heads, Hkv = w->kv_heads, D = w->head_dim, F = w->ffn, V = w->vocab;
+    const size_t G = (D + 127) / 128, NL = w->layers;
+    size_t n_attn = 0, n_conv = 0;
+    for (size_t i = 0; i < NL; i++) (w->blocks[i].kind == 0 ? n_attn : n_conv)++;
+    if (n_attn && (!kv->k_cache || !kv->v_cache || !kv->k_scales || !kv->v_scales || kv->slots == 0))
+        return fail("decode step: null KV cache");
+    if (n_conv && !kv->conv_state) return fail("decode step: null convolution state");
+    DecodeBuffers d;
+    carve_decode(w, b, workspace, &d);
+    const cactus_hip_qmatrix& head = w->lm_head.B ? w->lm_head : w->embedding;
+    const bool small = b <= 4 && n_conv == 0;      // streaming launches that produce their own input rows
+    const size_t cbs = kv->slots * Hkv * D, sbs = kv->slots * Hkv * G;
+    const bool fused_append = kv->window == 0;
+    const bool fused_attention = fused_append && (D == 64 || D == 128 || D == 256);
+    const bool o_quant = fused_append && D == 128 && !small && n_conv == 0;
+
+    STEP_TRY(cactus_hip_embedding_int8_dev(static_cast<const int8_t*>(w->embedding.B), w->embedding.scales, kv->tokens, d.h0, b,
+                                           V, Hd, 128, nullptr, stream));
+    if (!small)
+        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h0, nullptr, w->blocks[0].in_norm, nullptr, nullptr, d.xq, d.xs, b, Hd,
+                                                       w->eps, stream));
+    const half_t* res = d.h0;
+    size_t ai = 0, ci = 0;
+    for (size_t li = 0; li < NL; li++) {
+        const cactus_hip_block_weights& L = w->blocks[li];
+        if (L.kind == 0) {
+            const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
+            if (small) {
+                // residual add of the previous block + this block's input norm + q/k/v, one launch per precision
+                if (li == 0) STEP_TRY(produced_matmuls(1, d.h0, nullptr, L.in_norm, nullptr, w->eps, qkv, 3, b, Hd, stream));
+                else STEP_TRY(produced_matmuls(1, d.h2, d.dn, L.in_norm, d.hid, w->eps, qkv, 3, b, Hd, stream));
+                if (li) res = d.hid;
+            } else {
+                STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, b, Hd, stream));     // rows quantized by the launch that produced them
+            }
+            int8_t* kc = kv->k_cache + ai * b * cbs;
+            int8_t* vc = kv->v_cache + ai * b * cbs;
+            float* ks = kv->k_scales + ai * b * sbs;
+            float* vs = kv->v_scales + ai * b * sbs;
+            ai++;
+            // q/k norm + RoPE at each sequence's position.  Without a window the new token's K and V join the cache in
+            // the same launch as the attention; with a window they are appended after the attention, which must still
+            // see the token a full window is about to drop.
+            if (fused_attention) {
+                if (o_quant)
+                    STEP_TRY(cactus_hip_attention_decode_fused_quant_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs, d.ao,
+                                                                            d.oq, d.os, b, kv->cache_lens, kv->positions,
+                                                                            kv->max_position, Hq, Hkv, D, w->eps, w->theta, 0.0f, 128,
+                                                                            cbs, sbs, kv->slots, kv->slots, stream));
+                else
+                    STEP_TRY(cactus_hip_attention_decode_fused_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs, d.ao, b,
+                                                                      kv->cache_lens, kv->positions, kv->max_position, Hq, Hkv, D,
+                                                                      w->eps, w->theta, 0.0f, 128, cbs, sbs, kv->slots, kv->slots,
+                                                                      stream));
+            } else {
+                const bool app = fused_append;
+                STEP_TRY(cactus_hip_qk_norm_rope_seq_f16_dev(d.qo, d.ko, app ? d.vo : nullptr, L.q_norm, L.k_norm, d.qr, d.kr,
+                                                            app ? kc : nullptr, app ? vc : nullptr, app ? ks : nullptr,
+                                                            app ? vs : nullptr, kv->positions, kv->max_position, b, 1, Hq, Hkv, D,
+                                                            w->eps, w->theta, 128, app ? cbs : 0, app ? sbs : 0,
+                                                            app ? kv->slots : 0, 0, 0, stream));
+                STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_batched_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, b, 1, kv->cache_lens, 1,
+                                                                          Hq, Hkv, D, 0.0f, kv->positions, 128, cbs, sbs, kv->slots,
+                                                                          stream));
+            }
+            if (!fused_append)
+                STEP_TRY(cactus_hip_kv_append_windowed_dev(d.kr, d.vo, kc, vc, ks, vs, kv->positions, b, 1, Hkv, D, 128, cbs, sbs,
+                                                          kv->slots, kv->window, kv->sink, stream));
+            if (o_quant) STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, b, stream));
+            else STEP_TRY(matmul_f16act(d.ao, L.o, d.oo, b, stream));
+        } else {
+            // LFM2 short convolution: in-projection; B * X, convolution over the carried rows, C gate, state update and
+            // the out-projection's row quantization in one launch; out-projection
+            half_t* state = kv->conv_state + ci * b * w->conv_rows * Hd;
+            ci++;
+            STEP_TRY(matmul_q(d.xq, d.xs, L.in_proj, d.ipj, b, stream));
+            STEP_TRY(cactus_hip_lfm2_conv_gate_quant_f16_dev(d.ipj, L.conv_weight, state, nullptr, d.cq, d.cs, b, 1, Hd, w->conv_taps,
+                                                            w->conv_rows, stream));
+            STEP_TRY(matmul_q(d.cq, d.cs, L.out_proj, d.oo, b, stream));
+        }
+        const half_t* nxt = li + 1 < NL ? w->blocks[li + 1].in_norm : w->final_norm;
+        const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
+        if (small) {
+            STEP_TRY(produced_matmuls(1, res, d.oo, L.post_norm, d.h2, w->eps, gu, 2, b, Hd, stream));   // add + norm + gate/up
+            const Out dn[1] = {{&L.down, d.dn}};
+            STEP_TRY(produced_matmuls(2, d.go, d.uo, nullptr, nullptr, 0.0f, dn, 1, b, F, stream));        // silu x up + down
+        } else {   // norm / activation launches that also quantize the next matmul's input rows
+            STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, b, Hd, w->eps, stream));
+            STEP_TRY(shared_matmuls(d.xq2, d.xs2, gu, 2, b, Hd, stream));
+            STEP_TRY(cactus_hip_silu_multiply_quant_f16_dev(d.go, d.uo, nullptr, d.aq, d.as, b, F, stream));
+            STEP_TRY(matmul_q(d.aq, d.as, L.down, d.dn, b, stream));
+            const bool last = li + 1 == NL;     // the lm_head below takes the FP16 row
+            STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h2, d.dn, nxt, d.hid, last ? d.x : nullptr, d.xq, d.xs, b, Hd, w->eps,
+                                                           stream));
+            res = d.hid;
+        }
+    }
+    if (small) {   // last residual add + final norm + lm_head
+        const Out hd[1] = {{&head, logits}};
+        STEP_TRY(produced_matmuls(1, d.h2, d.dn, w->final_norm, d.hid, w->eps, hd, 1, b, Hd, stream));
+    } else {
+        STEP_TRY(matmul_f16act(d.x, head, logits, b, stream));
+    }
+    STEP_TRY(cactus_hip_sample_greedy_f16_dev(logits, reinterpret_cast<uint32_t*>(kv->tokens), b, V, stream));
+    if (advance) STEP_TRY(cactus_hip_kv_positions_advance_dev(kv->positions, kv->cache_lens, b, 1, kv->window, stream));
+    return CACTUS_HIP_OK;
+}
+
+size_t cactus_hip_prefill_chunk_workspace_bytes(const cactus_hip_decoder_weights* w, size_t chunk) {
+    if (!w || chunk == 0) return 0;
+    return carve_decode(w, chunk, nullptr, nullptr);
+}
+
+int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* st, const int32_t* tokens,
+                                 size_t chunk, size_t cache_start, const int32_t* cache_start_dev, void* workspace, int last,
+                                 cactus_half_t* logits, int32_t* token_out, void* stream) {
+    if (const char* bad = check_weights(w, true)) return fail(bad);
+    if (!st || !st->k_cache || !st->v_cache || !st->k_scales || !st->v_scales) return fail("prefill chunk: null cache");
+    if (!tokens || !cache_start_dev || !workspace || chunk == 0) return fail("prefill chunk: null operand");
+    if (cache_start + chunk > st->capacity) return fail("prefill chunk: the cache cannot hold cache_start + chunk tokens");
+    if (last && (!logits || !token_out)) return fail("prefill chunk: the last chunk needs logits and token_out");
+    const size_t M = chunk, Hd = w->hidden, Hq = w->q_heads, Hkv = w->kv_heads, D = w->head_dim, F = w->ffn, V = w->vocab;
+    const size_t G = (D + 127) / 128, NL = w->layers, QD = Hq * D;
+    const size_t cbs = st->capacity * Hkv * D, sbs = st->capacity * Hkv * G;
+    DecodeBuffers d;
+    carve_decode(w, M, workspace, &d);
+    const cactus_hip_qmatrix& head = w->lm_head.B ? w->lm_head : w->embedding;
+    STEP_TRY(cactus_hip_embedding_int8_dev(static_cast<const int8_t*>(w->embedding.B), w->embedding.scales, tokens, d.h0, M, V, Hd,
+                                           128, nullptr, stream));
+    STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h0, nullptr, w->blocks[0].in_norm, nullptr, nullptr, d.xq, d.xs, M, Hd, w->eps,
+                                                   stream));
+    const half_t* res = d.h0;
+    for (size_t li = 0; li < NL; li++) {
+        const cactus_hip_block_weights& L = w->blocks[li];
+        const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
+        STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, M, Hd, stream));
+        int8_t* kc = st->k_cache + li * cbs;
+        int8_t* vc = st->v_cache + li * cbs;
+        float* ks = st->k_scales + li * sbs;
+        float* vs = st->v_scales + li * sbs;
+        STEP_TRY(cactus_hip_qk_norm_rope_kv_append_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, d.qr, d.kr, kc, vc, ks, vs,
+                                                          cache_start_dev, 1, M, Hq, Hkv, D, w->eps, cache_start, w->theta, 128, cbs,
+                                                          sbs, st->capacity, stream));
+        if (cache_start == 0)
+            STEP_TRY(cactus_hip_attention_f16_dev(d.qr, d.kr, d.vo, d.ao, 1, M, M, Hq, Hkv, D, 0.0f, nullptr, 0, 0, 1, stream));
+        else
+            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, 1, M, cache_start, M, Hq, Hkv, D,
+                                                              0.0f, cache_start, 1, 128, stream));
+        STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
+        STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, M, stream));
+        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, M, Hd, w->eps, stream));
+        const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
+        STEP_TRY(shared_matmuls(d.xq2, d.xs2, gu, 2, M, Hd, stream));
+        STEP_TRY(cactus_hip_silu_multiply_quant_f16_dev(d.go, d.uo, nullptr, d.aq, d.as, M, F, stream));
+        STEP_TRY(matmul_q(d.aq, d.as, L.down, d.dn, M, stream));
+        const half_t* nxt = li + 1 < NL ? w->blocks[li + 1].in_norm : w->final_norm;
+        const bool fin = li + 1 == NL && last;
+        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h2, d.dn, nxt, d.hid, fin ? d.x : nullptr, d.xq, d.xs, M, Hd, w->eps, stream));
+        res = d.hid;
+    }
+    if (last) {
+        STEP_TRY(matmul_f16act(d.x + (M - 1) * Hd, head, logits, 1, stream));
+        STEP_TRY(cactus_hip_sample_greedy_f16_dev(logits, reinterpret_cast<uint32_t*>(token_out), 1, V, stream));
+    }
+    return CACTUS_HIP_OK;
+}
+
+}  // extern "C"

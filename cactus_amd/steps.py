@@ -11,6 +11,8 @@ tests/test_gpu_steps.py checks sequence by sequence against a CPU restatement of
 Weights: dicts of device tensors.  A quantized matrix is a pair (B, B_scales): int8 [N, K] or packed
 uint8 [N, K/2] (INT4) with fp16 scales [N, K/128]; a norm weight is an fp16 vector.
 """
+import ctypes as C
+
 import torch
 
 from . import hip as H
@@ -145,134 +147,120 @@ class _KvState:
             raise RuntimeError(f"KV cache full: a sequence is at position {self.host_max_position} of {self.slots} slots")
 
 
-class Qwen3Decode:
-    """One decode step of the Qwen3 op sequence (model_qwen.cpp:51-129, 143-172; the decode tail of
-    engine_model.cpp:221-253) for `batch` independent sequences: embedding lookup of each sequence's last
-    token (the table is the tied lm_head weight), per block input norm, q/k/v, per-head q/k norms + RoPE at
-    each sequence's own position, attention over its INT8 cache plus the new FP16 token, the new token's
-    K/V quantized into the cache, o projection, residual add, post-attention norm, gate/up, SiLU x up, down,
-    residual add; final norm, lm_head, greedy sampler.  Batches of at most 4 run every matmul as a
-    streaming launch that also produces its own input rows (norm / activation in the prologue); larger
-    ones quantize rows in the producing launch and use the tile kernel, q/k/v and gate/up in shared
-    launches."""
+# ------------------------------------------------------------------------------------------------
+# The step drivers themselves live in the library (include/cactus_hip_steps.h, cactus_amd/csrc/steps.cpp): a C or
+# C++ engine calls them directly.  The classes below describe a model and its state to them and own the tensors.
+class _QMatrix(C.Structure):
+    _fields_ = [("B", C.c_void_p), ("scales", C.c_void_p), ("N", C.c_size_t), ("K", C.c_size_t), ("int4", C.c_int)]
+
+
+class _Block(C.Structure):
+    _fields_ = [("kind", C.c_int), ("q", _QMatrix), ("k", _QMatrix), ("v", _QMatrix), ("o", _QMatrix),
+                ("in_proj", _QMatrix), ("out_proj", _QMatrix), ("conv_weight", C.c_void_p),
+                ("gate", _QMatrix), ("up", _QMatrix), ("down", _QMatrix),
+                ("in_norm", C.c_void_p), ("post_norm", C.c_void_p), ("q_norm", C.c_void_p), ("k_norm", C.c_void_p)]
+
+
+class _Weights(C.Structure):
+    _fields_ = [("hidden", C.c_size_t), ("q_heads", C.c_size_t), ("kv_heads", C.c_size_t), ("head_dim", C.c_size_t),
+                ("ffn", C.c_size_t), ("vocab", C.c_size_t), ("layers", C.c_size_t), ("conv_taps", C.c_size_t),
+                ("conv_rows", C.c_size_t), ("eps", C.c_float), ("theta", C.c_float), ("blocks", C.POINTER(_Block)),
+                ("embedding", _QMatrix), ("lm_head", _QMatrix), ("final_norm", C.c_void_p)]
+
+
+class _DecodeState(C.Structure):
+    _fields_ = [("batch", C.c_size_t), ("slots", C.c_size_t), ("window", C.c_size_t), ("sink", C.c_size_t),
+                ("max_position", C.c_size_t), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("k_scales", C.c_void_p),
+                ("v_scales", C.c_void_p), ("positions", C.c_void_p), ("cache_lens", C.c_void_p), ("tokens", C.c_void_p),
+                ("conv_state", C.c_void_p)]
+
+
+class _PrefillState(C.Structure):
+    _fields_ = [("capacity", C.c_size_t), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("k_scales", C.c_void_p),
+                ("v_scales", C.c_void_p)]
+
+
+_lib = H.lib
+_lib.cactus_hip_decode_step_workspace_bytes.restype = C.c_size_t
+_lib.cactus_hip_decode_step_workspace_bytes.argtypes = [C.POINTER(_Weights), C.c_size_t]
+_lib.cactus_hip_decode_step_dev.restype = C.c_int
+_lib.cactus_hip_decode_step_dev.argtypes = [C.POINTER(_Weights), C.POINTER(_DecodeState), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+_lib.cactus_hip_prefill_chunk_workspace_bytes.restype = C.c_size_t
+_lib.cactus_hip_prefill_chunk_workspace_bytes.argtypes = [C.POINTER(_Weights), C.c_size_t]
+_lib.cactus_hip_prefill_chunk_dev.restype = C.c_int
+_lib.cactus_hip_prefill_chunk_dev.argtypes = [C.POINTER(_Weights), C.POINTER(_PrefillState), C.c_void_p, C.c_size_t, C.c_size_t,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def _qm(pair):
+    if pair is None:
+        return _QMatrix(None, None, 0, 0, 0)
+    B, Bs = pair
+    int4 = B.dtype == torch.uint8
+    H._dev(B, torch.uint8 if int4 else torch.int8); H._dev(Bs, torch.float16)
+    return _QMatrix(B.data_ptr(), Bs.data_ptr(), B.shape[0], B.shape[1] * (2 if int4 else 1), int(int4))
+
+
+def _vp(t):
+    return None if t is None else t.data_ptr()
+
+
+def describe_model(weights, cfg):
+    """The model dict of this module as the library's cactus_hip_decoder_weights (the dict must outlive it)."""
+    Ls = weights["layers"]
+    blocks = (_Block * len(Ls))()
+    for i, L in enumerate(Ls):
+        conv = "q" not in L
+        blocks[i] = _Block(
+            int(conv), _qm(L.get("q")), _qm(L.get("k")), _qm(L.get("v")), _qm(L.get("o")), _qm(L.get("in_proj")),
+            _qm(L.get("out_proj")), _vp(L.get("conv_w")), _qm(L["gate"]), _qm(L["up"]), _qm(L["down"]),
+            _vp(L["in_norm"]), _vp(L["post_norm"]), _vp(L.get("q_norm")), _vp(L.get("k_norm")))
+    w = _Weights(cfg["hidden"], cfg["q_heads"], cfg["kv_heads"], cfg["head_dim"], cfg["ffn"], cfg["vocab"], len(Ls),
+                 cfg.get("conv_taps", 0), cfg.get("conv_rows", 0), cfg["eps"], cfg["theta"], blocks, _qm(weights["emb"]),
+                 _qm(weights.get("head")), _vp(weights["final_norm"]))
+    w._keep = (blocks, weights)
+    return w
+
+
+class _DecodeStep:
+    """One decode step of a decoder model for `batch` independent sequences through cactus_hip_decode_step_dev:
+    embedding lookup of each sequence's last token, every block (attention over its INT8 cache plus the new FP16 token,
+    the new token's K/V quantized into the cache; or LFM2's short convolution over its carried rows), the SwiGLU MLP,
+    final norm, lm_head, greedy sampler; token ids, positions, caches and convolution rows stay on the device."""
 
     def __init__(self, weights, cfg, batch, slots, window=0, sink=4, max_position=None, cache_gen=None):
         c = self.cfg = cfg
         self.w, self.batch = weights, batch
-        Hd, Hq, Hkv, D, F, V = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["ffn"], c["vocab"]
-        NL = len(weights["layers"])
-        self.kv = _KvState(NL, batch, slots, Hkv, D, window, sink, cache_gen)
-        self.max_position = max_position if max_position is not None else slots
-        H.rope_reserve(D, c["theta"], self.max_position + 1)
-        b = batch
-        self.h0, self.hid, self.x, self.h2 = _half(b, Hd), _half(b, Hd), _half(b, Hd), _half(b, Hd)
-        self.qo, self.ko, self.vo = _half(b, Hq * D), _half(b, Hkv * D), _half(b, Hkv * D)
-        self.qr, self.kr, self.ao = _half(b, Hq * D), _half(b, Hkv * D), _half(b, 1, Hq, D)
-        self.oo, self.go, self.uo, self.do = _half(b, Hd), _half(b, F), _half(b, F), _half(b, Hd)
-        self.logits = _half(b, V)
-        self.xq, self.xs, self.xq2, self.xs2 = _i8(b, Hd), _f32(b), _i8(b, Hd), _f32(b)
-        self.aq, self.asc = _i8(b, F), _f32(b)
-        self.oq, self.osc = _i8(b, Hq * D), _f32(b)      # attention output rows, quantized for the output projection
-        self.small = batch <= 4
+        Ls = weights["layers"]
         if batch <= 16:        # the streaming kernels take these batches: give them the tile-major layout
             pack_model_weights(weights)
-        Ls = weights["layers"]
-        head = weights.get("head", weights["emb"])     # tied embeddings unless the model brings an lm_head of its own
-
-        def groups(entries, cls):
-            """entries [(weight pair, out)] split by precision: one launch object per precision."""
-            out = []
-            for want4 in (False, True):
-                sel = [(w[0], w[1], o) for w, o in entries if _is4(w) == want4]
-                if sel:
-                    out.append(cls(sel, 128, int4=want4))
-            return out
-        self.qkv, self.gu, self.down = [], [], []
-        cls = H.MatmulProduced if self.small else H.MatmulShared
-        for L in Ls:
-            self.qkv.append(groups([(L["q"], self.qo), (L["k"], self.ko), (L["v"], self.vo)], cls))
-            self.gu.append(groups([(L["gate"], self.go), (L["up"], self.uo)], cls))
-            if self.small:
-                self.down.append(groups([(L["down"], self.do)], cls))
-        if self.small:
-            self.head_p = H.MatmulProduced([(head[0], head[1], self.logits)], 128, int4=_is4(head))
+        self.attn_index = {}
+        for li, L in enumerate(Ls):
+            if "q" in L:
+                self.attn_index[li] = len(self.attn_index)
+        self.kv = _KvState(len(self.attn_index), batch, slots, c["kv_heads"], c["head_dim"], window, sink, cache_gen)
+        self.max_position = max_position if max_position is not None else slots
+        H.rope_reserve(c["head_dim"], c["theta"], self.max_position + 1)
+        conv_layers = [li for li, L in enumerate(Ls) if "q" not in L]
+        self._conv = None
+        self.state = {}
+        if conv_layers:
+            self._conv = torch.zeros((len(conv_layers), batch, c["conv_rows"], c["hidden"]), dtype=torch.float16, device="cuda")
+            self.state = {li: self._conv[i] for i, li in enumerate(conv_layers)}
+        self.logits = _half(batch, c["vocab"])
+        self._desc = describe_model(weights, cfg)
+        kv = self.kv
+        self._state = _DecodeState(batch, slots, window, kv.sink, self.max_position, _vp(kv.kc), _vp(kv.vc), _vp(kv.ksc),
+                                   _vp(kv.vsc), _vp(kv.positions), _vp(kv.cache_lens), _vp(kv.tok), _vp(self._conv))
+        nbytes = _lib.cactus_hip_decode_step_workspace_bytes(C.byref(self._desc), batch)
+        self._ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
 
     def step(self, advance=True):
-        c, kv, b = self.cfg, self.kv, self.batch
-        kv.check_room()
-        Hq, Hkv, D, eps, theta = c["q_heads"], c["kv_heads"], c["head_dim"], c["eps"], c["theta"]
-        Ls, emb = self.w["layers"], self.w["emb"]
-        head = self.w.get("head", emb)
-        NL = len(Ls)
-        H.embedding(emb[0], kv.tok, emb[1], 128, out=self.h0, check=False)
-        if not self.small:
-            H.add_rms_norm_quant(self.h0, None, Ls[0]["in_norm"], eps, out_q=self.xq, out_scales=self.xs)
-        res = self.h0
-        q4, k4, v4 = self.qo.view(b, 1, Hq, D), self.ko.view(b, 1, Hkv, D), self.vo.view(b, 1, Hkv, D)
-        qr4, kr4 = self.qr.view(b, 1, Hq, D), self.kr.view(b, 1, Hkv, D)
-        for li, L in enumerate(Ls):
-            if self.small:
-                # residual add of the previous block + this block's input norm + q/k/v, one launch per precision
-                for mp in self.qkv[li]:
-                    if li == 0:
-                        mp.run_norm(self.h0, None, L["in_norm"], eps)
-                    else:
-                        mp.run_norm(self.h2, self.do, L["in_norm"], eps, self.hid)
-                if li:
-                    res = self.hid
-            else:
-                for sh in self.qkv[li]:
-                    sh.run(self.xq, self.xs)       # rows quantized by the norm launch that produced them
-            # q/k norm + RoPE at each sequence's position; without a window the new token's K and V join the
-            # cache in the same launch (the slot beyond the cached length: this step's attention reads them
-            # as FP16), with a window they are appended after the attention, which must still see the token
-            # a full window is about to drop
-            # Without a window all of it - norm, RoPE, cache append, attention - is one launch (head_dim 64 / 128 / 256).
-            fused_append = kv.window == 0
-            # batches above 4 rows: the attention launch also leaves its rows quantized for the output projection
-            o_quant = fused_append and D == 128 and not self.small   # (head_dim 64: the wider workgroups cost more than the launch)
-            if fused_append and D in (64, 128, 256):
-                H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
-                                         L["q_norm"], L["k_norm"], kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li],
-                                         kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao,
-                                         out_q=self.oq if o_quant else None, out_scales=self.osc if o_quant else None)
-            else:
-                H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta,
-                                   kv.positions, self.max_position, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], 0, 0,
-                                   128, out_q=qr4, out_k=kr4)
-                H.attention_hybrid_batched(qr4, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], kr4, v4, 0.0,
-                                           kv.cache_lens, kv.positions, out=self.ao)
-            if not fused_append:
-                H.kv_append_windowed(kr4, v4, kv.kc[li], kv.vc[li], kv.ksc[li], kv.vsc[li], kv.positions, kv.window,
-                                     kv.sink)
-            if o_quant:
-                (H.matmul_int4 if _is4(L["o"]) else H.matmul_int8)(self.oq, self.osc, L["o"][0], L["o"][1], 128, out=self.oo)
-            else:
-                H.matmul_f16act(self.ao.view(b, Hq * D), L["o"][0], L["o"][1], 128, int4=_is4(L["o"]), out=self.oo)
-            nxt = Ls[li + 1]["in_norm"] if li + 1 < NL else self.w["final_norm"]
-            if self.small:
-                for mp in self.gu[li]:
-                    mp.run_norm(res, self.oo, L["post_norm"], eps, self.h2)     # add + norm + gate/up
-                self.down[li][0].run_act(self.go, self.uo, "silu")              # silu x up + down
-            else:   # norm / activation launches that also quantize the next matmul's input rows
-                H.add_rms_norm_quant(res, self.oo, L["post_norm"], eps, out_sum=self.h2, out_q=self.xq2,
-                                     out_scales=self.xs2)
-                for sh in self.gu[li]:
-                    sh.run(self.xq2, self.xs2)
-                H.silu_multiply_quant(self.go, self.uo, out_q=self.aq, out_scales=self.asc)
-                (H.matmul_int4 if _is4(L["down"]) else H.matmul_int8)(self.aq, self.asc, L["down"][0], L["down"][1], 128,
-                                                                      out=self.do)
-                last = li + 1 == NL   # the lm_head below takes the FP16 row
-                H.add_rms_norm_quant(self.h2, self.do, nxt, eps, out_sum=self.hid, out_norm=self.x if last else None,
-                                     out_q=self.xq, out_scales=self.xs)
-                res = self.hid
-        if self.small:   # last residual add + final norm + lm_head
-            self.head_p.run_norm(self.h2, self.do, self.w["final_norm"], eps, self.hid)
-        else:
-            H.matmul_f16act(self.x, head[0], head[1], 128, int4=_is4(head), out=self.logits)
-        H.sample_greedy(self.logits, out=kv.tok)
+        self.kv.check_room()
+        H._check(_lib.cactus_hip_decode_step_dev(C.byref(self._desc), C.byref(self._state), self._ws.data_ptr(),
+                                                 self.logits.data_ptr(), int(bool(advance)), H._stream()))
         if advance:
-            kv.advance(1)
+            self.kv.host_max_position += 1
 
     def weight_bytes(self):
         """Algorithmic bytes of one step's weight matmuls (weights + scales + activations + outputs)."""
@@ -280,87 +268,50 @@ class Qwen3Decode:
             N = w[0].shape[0]
             K = w[0].shape[1] * (2 if _is4(w) else 1)
             return w[0].numel() + 2 * N * (K // 128) + 2 * M * K + 2 * M * N
-        total = one(self.w["emb"], self.batch)
+        total = one(self.w.get("head", self.w["emb"]), self.batch)
         for L in self.w["layers"]:
-            total += sum(one(L[n], self.batch) for n in ("q", "k", "v", "o", "gate", "up", "down"))
+            total += sum(one(v, self.batch) for v in L.values() if isinstance(v, tuple))
         return total
 
 
+class Qwen3Decode(_DecodeStep):
+    """The Qwen3 op sequence (model_qwen.cpp:51-129, 143-172; the decode tail of engine_model.cpp:221-253).  Batches of
+    at most 4 run every matmul as a streaming launch that also produces its own input rows (norm / activation in the
+    prologue); larger ones quantize rows in the producing launch and use the tile kernel, q/k/v and gate/up in shared
+    launches."""
+
+
 class Qwen3Prefill:
-    """A chunked prefill of one sequence through the Qwen3 op sequence, the way the engine walks a long
-    prompt (Model::prefill, engine_model.cpp:170-219: chunks of `chunk` tokens, the first against nothing,
-    the others against the INT8 cache): per block norm + activation quantization, q/k/v GEMM, q/k norm +
-    RoPE + cache append, attention (FP16 for chunk 0, INT8-cache hybrid after), o GEMM, add + norm, gate/up
-    GEMM, SiLU x up, down GEMM, add; after the last chunk the final norm, the lm_head on the last token and
-    the greedy sampler.  No window: the cache holds the whole prompt."""
+    """A chunked prefill of one sequence through the Qwen3 op sequence, the way the engine walks a long prompt
+    (Model::prefill, engine_model.cpp:170-219: chunks of `chunk` tokens, the first against nothing, the others against
+    the INT8 cache), through cactus_hip_prefill_chunk_dev: per block norm + activation quantization, q/k/v GEMM, q/k
+    norm + RoPE + cache append, attention (FP16 for chunk 0, INT8-cache hybrid after), o GEMM, add + norm, gate/up GEMM,
+    SiLU x up, down GEMM, add; after the last chunk the final norm, the lm_head on the last token and the greedy
+    sampler.  No window: the cache holds the whole prompt."""
 
     def __init__(self, weights, cfg, tokens, chunk):
         c = self.cfg = cfg
         assert tokens % chunk == 0
         self.w, self.tokens, self.chunk, self.nchunks = weights, tokens, chunk, tokens // chunk
-        Hd, Hq, Hkv, D, F, V = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["ffn"], c["vocab"]
+        Hkv, D, V = c["kv_heads"], c["head_dim"], c["vocab"]
         NL = len(weights["layers"])
-        M = chunk
+        G = (D + 127) // 128
         H.rope_reserve(D, c["theta"], tokens + 1)
-        self.toks = torch.zeros((self.nchunks, M), dtype=torch.int32, device="cuda")
+        self.toks = torch.zeros((self.nchunks, chunk), dtype=torch.int32, device="cuda")
         self.kc, self.vc = _i8(NL, 1, tokens, Hkv, D), _i8(NL, 1, tokens, Hkv, D)
-        self.ksc, self.vsc = _f32(NL, 1, tokens, Hkv, 1), _f32(NL, 1, tokens, Hkv, 1)
-        self.h0, self.hid, self.h2, self.x = _half(M, Hd), _half(M, Hd), _half(M, Hd), _half(M, Hd)
-        self.qo, self.ko, self.vo = _half(M, Hq * D), _half(M, Hkv * D), _half(M, Hkv * D)
-        self.qr, self.kr = _half(M, Hq * D), _half(M, Hkv * D)
-        self.ao, self.oo, self.go, self.uo, self.do = _half(1, M, Hq, D), _half(M, Hd), _half(M, F), _half(M, F), _half(M, Hd)
+        self.ksc, self.vsc = _f32(NL, 1, tokens, Hkv, G), _f32(NL, 1, tokens, Hkv, G)
         self.logits, self.tok = _half(1, V), torch.empty((1,), dtype=torch.int32, device="cuda")
-        self.xq, self.xs, self.xq2, self.xs2 = _i8(M, Hd), _f32(M), _i8(M, Hd), _f32(M)
-        self.aq, self.asc, self.oq, self.os_ = _i8(M, F), _f32(M), _i8(M, Hq * D), _f32(M)
-
-        def groups(entries):
-            out = []
-            for want4 in (False, True):
-                sel = [(w[0], w[1], o) for w, o in entries if _is4(w) == want4]
-                if sel:
-                    out.append(H.MatmulShared(sel, 128, int4=want4))
-            return out
-        self.qkv = [groups([(L["q"], self.qo), (L["k"], self.ko), (L["v"], self.vo)]) for L in weights["layers"]]
-        self.gu = [groups([(L["gate"], self.go), (L["up"], self.uo)]) for L in weights["layers"]]
         self.slots = [torch.full((1,), ci * chunk, dtype=torch.int32, device="cuda") for ci in range(self.nchunks)]
+        self._desc = describe_model(weights, cfg)
+        self._state = _PrefillState(tokens, _vp(self.kc), _vp(self.vc), _vp(self.ksc), _vp(self.vsc))
+        nbytes = _lib.cactus_hip_prefill_chunk_workspace_bytes(C.byref(self._desc), chunk)
+        self._ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
 
     def run_chunk(self, ci):
-        c, M = self.cfg, self.chunk
-        Hq, Hkv, D, eps, theta = c["q_heads"], c["kv_heads"], c["head_dim"], c["eps"], c["theta"]
-        Ls, head = self.w["layers"], self.w["emb"]
-        NL = len(Ls)
-        cache = ci * M
-        H.embedding(head[0], self.toks[ci], head[1], 128, out=self.h0, check=False)
-        H.add_rms_norm_quant(self.h0, None, Ls[0]["in_norm"], eps, out_q=self.xq, out_scales=self.xs)
-        res = self.h0
-        q4, k4, v4 = self.qo.view(1, M, Hq, D), self.ko.view(1, M, Hkv, D), self.vo.view(1, M, Hkv, D)
-        qr4, kr4 = self.qr.view(1, M, Hq, D), self.kr.view(1, M, Hkv, D)
-        for li, L in enumerate(Ls):
-            for sh in self.qkv[li]:
-                sh.run(self.xq, self.xs)
-            H.qk_norm_rope_kv_append(q4, k4, v4, L["q_norm"], L["k_norm"], eps, theta, cache, self.kc[li], self.vc[li],
-                                     self.ksc[li], self.vsc[li], self.slots[ci], 128, out_q=qr4, out_k=kr4)
-            if cache == 0:
-                a = H.attention_f16(qr4, kr4, v4, 0.0, out=self.ao)
-            else:
-                a = H.attention_hybrid(qr4, self.kc[li, 0, :cache], self.vc[li, 0, :cache], self.ksc[li, 0, :cache],
-                                       self.vsc[li, 0, :cache], kr4, v4, 0.0, position_offset=cache, out=self.ao)
-            H.quantize_activations(a.view(M, Hq * D), out_q=self.oq, out_scales=self.os_)
-            (H.matmul_int4 if _is4(L["o"]) else H.matmul_int8)(self.oq, self.os_, L["o"][0], L["o"][1], 128, out=self.oo)
-            H.add_rms_norm_quant(res, self.oo, L["post_norm"], eps, out_sum=self.h2, out_q=self.xq2, out_scales=self.xs2)
-            for sh in self.gu[li]:
-                sh.run(self.xq2, self.xs2)
-            H.silu_multiply_quant(self.go, self.uo, out_q=self.aq, out_scales=self.asc)
-            (H.matmul_int4 if _is4(L["down"]) else H.matmul_int8)(self.aq, self.asc, L["down"][0], L["down"][1], 128,
-                                                                  out=self.do)
-            nxt = Ls[li + 1]["in_norm"] if li + 1 < NL else self.w["final_norm"]
-            last = li + 1 == NL and ci + 1 == self.nchunks
-            H.add_rms_norm_quant(self.h2, self.do, nxt, eps, out_sum=self.hid, out_norm=self.x if last else None,
-                                 out_q=self.xq, out_scales=self.xs)
-            res = self.hid
-        if ci + 1 == self.nchunks:
-            H.matmul_f16act(self.x[M - 1:M], head[0], head[1], 128, int4=_is4(head), out=self.logits)
-            H.sample_greedy(self.logits, out=self.tok)
+        last = ci + 1 == self.nchunks
+        H._check(_lib.cactus_hip_prefill_chunk_dev(C.byref(self._desc), C.byref(self._state), self.toks[ci].data_ptr(),
+                                                   self.chunk, ci * self.chunk, self.slots[ci].data_ptr(), self._ws.data_ptr(),
+                                                   int(last), self.logits.data_ptr(), self.tok.data_ptr(), H._stream()))
 
 
 def lfm2_synthetic_weights(gen, batch, cfg=LFM2_1P2B):
@@ -381,91 +332,13 @@ def lfm2_synthetic_weights(gen, batch, cfg=LFM2_1P2B):
     return {"layers": layers, "emb": synthetic_matrix(gen, V, Hd), "final_norm": _norm_weight(gen, Hd)}
 
 
-class Lfm2Decode:
-    """One decode step of the LFM2 op sequence (model_lfm2.cpp:123-331) for `batch` independent sequences:
-    blocks with the short convolution (in-projection to 3 x hidden; B*X, causal conv over the carried rows,
-    C-gate, state update and the out-projection's row quantization in one launch; out-projection) or with
-    attention (q/k/v, per-head q/k norms, RoPE, INT8 cache append, attention over the cache, o), each
-    followed by residual add, norm, gate/up, SiLU x up, down, residual add; final norm, lm_head, greedy
-    sampler; embedding lookup of the previous token in front.  INT8 weights."""
-
-    def __init__(self, weights, cfg, batch, slots, window=0, sink=4, max_position=None, cache_gen=None):
-        c = self.cfg = cfg
-        self.w, self.batch = weights, batch
-        Hd, Hq, Hkv, D, F, V = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["ffn"], c["vocab"]
-        Ls = weights["layers"]
-        if batch <= 16:
-            pack_model_weights(weights)
-        self.attn_index = {}
-        for li, L in enumerate(Ls):
-            if "q" in L:
-                self.attn_index[li] = len(self.attn_index)
-        self.kv = _KvState(len(self.attn_index), batch, slots, Hkv, D, window, sink, cache_gen)
-        self.max_position = max_position if max_position is not None else slots
-        H.rope_reserve(D, c["theta"], self.max_position + 1)
-        b = batch
-        self.state = {li: torch.zeros((b, c["conv_rows"], Hd), dtype=torch.float16, device="cuda")
-                      for li, L in enumerate(Ls) if "q" not in L}
-        self.h0, self.hid, self.x, self.h2 = _half(b, Hd), _half(b, Hd), _half(b, Hd), _half(b, Hd)
-        self.qo, self.ko, self.vo = _half(b, Hq * D), _half(b, Hkv * D), _half(b, Hkv * D)
-        self.qr, self.kr, self.ao = _half(b, Hq * D), _half(b, Hkv * D), _half(b, 1, Hq, D)
-        self.ipj, self.oo, self.go, self.uo, self.do = _half(b, 3 * Hd), _half(b, Hd), _half(b, F), _half(b, F), _half(b, Hd)
-        self.logits = _half(b, V)
-        self.xq, self.xs, self.xq2, self.xs2 = _i8(b, Hd), _f32(b), _i8(b, Hd), _f32(b)
-        self.aq, self.asc, self.cq, self.cs = _i8(b, F), _f32(b), _i8(b, Hd), _f32(b)
-        self.qkv = {li: H.MatmulShared([(L["q"][0], L["q"][1], self.qo), (L["k"][0], L["k"][1], self.ko),
-                                        (L["v"][0], L["v"][1], self.vo)], 128) for li, L in enumerate(Ls) if "q" in L}
-        self.gu = [H.MatmulShared([(L["gate"][0], L["gate"][1], self.go), (L["up"][0], L["up"][1], self.uo)], 128)
-                   for L in Ls]
-
-    def step(self, advance=True):
-        c, kv, b = self.cfg, self.kv, self.batch
-        kv.check_room()
-        Hd, Hq, Hkv, D, eps, theta = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["eps"], c["theta"]
-        Ls, head = self.w["layers"], self.w["emb"]
-        NL = len(Ls)
-        H.embedding(head[0], kv.tok, head[1], 128, out=self.h0, check=False)
-        H.add_rms_norm_quant(self.h0, None, Ls[0]["in_norm"], eps, out_q=self.xq, out_scales=self.xs)
-        res = self.h0
-        q4, k4, v4 = self.qo.view(b, 1, Hq, D), self.ko.view(b, 1, Hkv, D), self.vo.view(b, 1, Hkv, D)
-        qr4, kr4 = self.qr.view(b, 1, Hq, D), self.kr.view(b, 1, Hkv, D)
-        for li, L in enumerate(Ls):
-            if "q" in L:
-                ai = self.attn_index[li]
-                self.qkv[li].run(self.xq, self.xs)
-                fused_append = kv.window == 0
-                if fused_append and D in (64, 128, 256):     # norm, RoPE, cache append and attention in one launch
-                    H.attention_decode_fused(self.qo.view(b, Hq, D), self.ko.view(b, Hkv, D), self.vo.view(b, Hkv, D),
-                                             L["q_norm"], L["k_norm"], kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai],
-                                             kv.cache_lens, kv.positions, self.max_position, eps, theta, out=self.ao)
-                else:
-                    H.qk_norm_rope_seq(q4, k4, v4 if fused_append else None, L["q_norm"], L["k_norm"], eps, theta,
-                                       kv.positions, self.max_position, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], 0,
-                                       0, 128, out_q=qr4, out_k=kr4)
-                    H.attention_hybrid_batched(qr4, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], kr4, v4, 0.0,
-                                               kv.cache_lens, kv.positions, out=self.ao)
-                if not fused_append:
-                    H.kv_append_windowed(kr4, v4, kv.kc[ai], kv.vc[ai], kv.ksc[ai], kv.vsc[ai], kv.positions, kv.window,
-                                         kv.sink)
-                H.matmul_f16act(self.ao.view(b, Hq * D), L["o"][0], L["o"][1], 128, out=self.oo)
-            else:
-                H.matmul_int8(self.xq, self.xs, L["in_proj"][0], L["in_proj"][1], 128, out=self.ipj)
-                H.lfm2_conv_gate_quant(self.ipj.view(b, 1, 3 * Hd), L["conv_w"], self.state[li], out_q=self.cq,
-                                       out_scales=self.cs)
-                H.matmul_int8(self.cq, self.cs, L["out_proj"][0], L["out_proj"][1], 128, out=self.oo)
-            H.add_rms_norm_quant(res, self.oo, L["post_norm"], eps, out_sum=self.h2, out_q=self.xq2, out_scales=self.xs2)
-            self.gu[li].run(self.xq2, self.xs2)
-            H.silu_multiply_quant(self.go, self.uo, out_q=self.aq, out_scales=self.asc)
-            H.matmul_int8(self.aq, self.asc, L["down"][0], L["down"][1], 128, out=self.do)
-            last = li + 1 == NL
-            nxt = self.w["final_norm"] if last else Ls[li + 1]["in_norm"]
-            H.add_rms_norm_quant(self.h2, self.do, nxt, eps, out_sum=self.hid, out_norm=self.x if last else None,
-                                 out_q=self.xq, out_scales=self.xs)
-            res = self.hid
-        H.matmul_f16act(self.x, head[0], head[1], 128, out=self.logits)
-        H.sample_greedy(self.logits, out=kv.tok)
-        if advance:
-            kv.advance(1)
+class Lfm2Decode(_DecodeStep):
+    """The LFM2 op sequence (model_lfm2.cpp:123-331): blocks with the short convolution (in-projection to 3 x hidden;
+    B*X, causal conv over the carried rows, C-gate, state update and the out-projection's row quantization in one
+    launch; out-projection) or with attention (q/k/v, per-head q/k norms, RoPE, INT8 cache append, attention over the
+    cache, o), each followed by residual add, norm, gate/up, SiLU x up, down, residual add; final norm, lm_head, greedy
+    sampler; embedding lookup of the previous token in front.  INT8 weights.  self.state[li]: the carried rows
+    half [batch, conv_rows, hidden] of conv block li."""
 
 
 class Qwen3GraphModel:

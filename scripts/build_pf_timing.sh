@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 python cactus_amd/build.py > /dev/null
 mkdir -p scripts/variants
-objs=$(ls cactus_amd/build/*.hip.o cactus_amd/build/graph.cpp.o | grep -v attention_prefill | grep -v gemv_bench)
+objs=$(ls cactus_amd/build/*.hip.o cactus_amd/build/*.cpp.o | grep -v attention_prefill | grep -v gemv_bench)
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -c cactus_amd/csrc/attention_prefill.hip -o scripts/variants/pf_$name.o

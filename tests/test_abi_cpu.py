@@ -32,6 +32,28 @@ def test_graph_library_exports_every_declared_symbol():
     assert sorted(G.GRAPH_SIGNATURES) == names
 
 
+def test_steps_library_exports_every_declared_symbol():
+    import cactus_amd.hip as H
+    names = _declared("cactus_hip_steps.h")
+    assert names == ["cactus_hip_decode_step_dev", "cactus_hip_decode_step_workspace_bytes",
+                     "cactus_hip_prefill_chunk_dev", "cactus_hip_prefill_chunk_workspace_bytes"]
+    for n in names:
+        assert hasattr(H.lib, n), f"{n} declared in include/cactus_hip_steps.h but not exported"
+
+
+def test_step_driver_rejects_a_bad_model_description_without_gpu():
+    """Argument checks of the step driver run on the host before anything is enqueued."""
+    import ctypes as C
+    from cactus_amd import steps as ST
+    import cactus_amd.hip as H
+    w = ST._Weights()
+    st = ST._DecodeState()
+    assert H.lib.cactus_hip_decode_step_dev(C.byref(w), C.byref(st), None, None, 1, None) == -1
+    assert b"null model description" in H.lib.cactus_hip_last_error()
+    assert H.lib.cactus_hip_decode_step_workspace_bytes(C.byref(w), 0) == 0
+    H.lib.cactus_hip_clear_error()
+
+
 def test_graph_builder_errors_without_gpu():
     """Shape validation happens at build time on the host (graph_builder.cpp:65-76): same
     conditions, same messages, no GPU involved."""

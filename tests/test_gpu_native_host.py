@@ -76,3 +76,44 @@ def test_cpp_host_and_python_binding_agree(tmp_path):
         want.append(model.step([want[-1]]))
     model.close()
     assert got == want
+
+
+BATCH_EXE = os.path.join(os.path.dirname(EXE), "qwen_batched_decode")
+
+
+@pytest.mark.parametrize("batch", [3, 6])
+def test_cpp_host_batched_decode_equals_the_python_driver(tmp_path, batch):
+    """examples/qwen_batched_decode.cpp: a C++ host that loads the folder itself, describes the model to the library's
+    step driver (cactus_hip_decode_step_dev) and decodes `batch` sequences from position 0.  The same weights through
+    cactus_amd.steps.Qwen3Decode (the Python view of the same driver): identical tokens, sequence by sequence; and
+    sequence 0's first choices against the oracle (3 sequences: streaming launches; 6: the tile kernel)."""
+    import cactus_amd.hip as H
+    H.init(0)
+    from cactus_amd import cact, steps as ST
+    from tests import test_gpu_steps as SD
+    assert os.path.exists(BATCH_EXE), "cactus_amd/lib/qwen_batched_decode is not built"
+    LAYERS, VOCAB, steps = 4, 8192, 10
+    rng = np.random.default_rng(40 + batch)
+    m = GD.make_model(rng, LAYERS, VOCAB, 0.05)
+    first = rng.integers(0, VOCAB, batch).tolist()
+    cfg = dict(ST.QWEN3_0P6B, layers=LAYERS, vocab=VOCAB)
+    cact.write_qwen_folder(tmp_path, m, cfg)
+    r = subprocess.run([BATCH_EXE, str(tmp_path), str(batch), str(steps)] + [str(t) for t in first], capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])["tokens"]
+    dec = ST.Qwen3Decode(ST.weights_to_device(m), cfg, batch, steps + 4, max_position=steps + 4)
+    dec.kv.set_positions([0] * batch)
+    dec.kv.tok.copy_(torch.tensor(first, dtype=torch.int32))
+    want = [[] for _ in range(batch)]
+    for _ in range(steps):
+        dec.step()
+        for b, t in enumerate(dec.kv.tok.cpu().tolist()):
+            want[b].append(t)
+    assert got == want
+    caches, tok, pos = [None] * LAYERS, first[0], 0
+    for s in range(4):          # the oracle on sequence 0 (tied head: wide margins)
+        ref = SD.oracle_forward(m, [tok], pos, caches).view(np.float16)
+        tok = int(O.sample_greedy(ref[None])[0])
+        assert got[0][s] == tok, (s, got[0])
+        pos += 1
