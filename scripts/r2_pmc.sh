@@ -11,6 +11,7 @@ run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INS
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC
 run sq3 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_I8
 run fetch FETCH_SIZE
+run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE
 timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- "${CMD[@]}" > $out/stats.log 2>&1
 cd $R
