@@ -705,6 +705,7 @@ hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f
 
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) {
     if (attn_prefill_ok(a)) return launch_attention_prefill(a, st);
+    if (attn_prefill_win_ok(a)) return launch_attention_prefill_win(a, st);
     if (attn_prefill_hybrid_ok(a)) {
         hipError_t e = launch_attention_prefill_hybrid(a, reinterpret_cast<float*>(workspace), st);
         const int ns = attn_prefill_hybrid_splits(a);

@@ -1,6 +1,7 @@
 // Prefill-shaped cactus_attention_f16 (cactus/kernel/kernel_attention.cpp:10-255) on the FP16 matrix
-// cores: many queries against FP16 K/V, causal or not, head_dim 64, 128 or 256, no mask tensor and no window
-// that cuts anything (those go to the VALU kernel in attention.hip).
+// cores: many queries against FP16 K/V, causal or not, head_dim 64, 128 or 256, no mask tensor (that goes to the
+// VALU kernel in attention.hip, as does a window on non-causal attention); a causal window that cuts visible keys
+// has its own kernel below (attn_prefill_win_kernel).
 //
 // Roofline: MFMA (FP16) / VALU for the per-block softmax; algorithmic flops 4*S*KV*Hq*D (half of
 // that when causal).
@@ -290,6 +291,223 @@ void attn_prefill_kernel(const AttnArgs a) {
 
     if (!q_live) return;
     // O^T accumulators: lane (query, g) holds d = 32*dt + 8*(r/4) + 4*g + r%4
+    uint16_t* orow = a.out + (((size_t)b * S + qi) * Hq + h) * D;
+    const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            uint32_t lo = 0, hi = 0;
+            if (l_run > 0.0f) {
+                lo = (uint32_t)f2h_mul(o[dt][4 * r4], inv) | ((uint32_t)f2h_mul(o[dt][4 * r4 + 1], inv) << 16);
+                hi = (uint32_t)f2h_mul(o[dt][4 * r4 + 2], inv) | ((uint32_t)f2h_mul(o[dt][4 * r4 + 3], inv) << 16);
+            }
+            *reinterpret_cast<uint2*>(orow + dt * 32 + 8 * r4 + 4 * g) = make_uint2(lo, hi);
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// A sliding window that cuts (Gemma's local layers once the prompt is longer than the window; kernel_attention.cpp:
+// 78-90, 149-151), causal.  The reference starts a query's 32-key blocks at ITS first visible key,
+// o(q) = q_abs - window, so every query of a wave has its own block boundaries, and the polynomial weights depend on
+// them (each block has its own maximum).  The matrix cores still work on tiles that all queries share: tiles of 32
+// keys from the origin of the workgroup's first query, B0.  A lane's origin sits s = (o(q) - B0) mod 32 keys into a
+// tile, so its block j is the last 32 - s keys of one tile followed by the first s keys of the next, and the loop runs
+// one tile behind its scores: with the scores of tile t in hand, a lane closes the block made of tile t-1's keys
+// ib >= s and tile t's keys ib < s (maximum, rescale of the running state, weights), which completes the weights of
+// tile t-1 -- its keys below s were weighted one step earlier as the tail of the previous block and are brought to the
+// new maximum by the same factor as the running state -- and P.V of tile t-1 follows.  LDS therefore holds K of tile
+// t beside V of tile t-1.  Keys before a lane's origin, after its query or past KV are masked; a block with no
+// visible key (lanes whose origin lies in a later tile) leaves the state alone, as the reference's blocks do.
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 256 ? 1 : 2, D == 256 ? 1 : 2)))
+void attn_prefill_win_kernel(const AttnArgs a) {
+    constexpr int KROW = D + 8;
+    constexpr int VROW = PF_BLOCK + 4;
+    constexpr int NDT = D / 32;
+    constexpr int NST = D / 16;
+    constexpr int PPT = (PF_BLOCK * D / 8) / 256;
+    __shared__ __attribute__((aligned(16))) uint16_t sK[PF_BLOCK * KROW];
+    __shared__ __attribute__((aligned(16))) uint16_t sVt[D * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int jq = lane & 31, g = lane >> 5;
+    const int S = (int)a.S, KV = (int)a.new_len, Hq = (int)a.Hq, Hkv = (int)a.Hkv;
+    const int nt = (S + PF_QTILE - 1) / PF_QTILE, hb = Hq * (int)a.B;
+    const int id = (int)blockIdx.x;
+    const int qt = id / hb;
+    const int h = (id % hb) % Hq, b = (id % hb) / Hq;
+    (void)nt;
+    const int kvh = h / (Hq / Hkv);
+    const int q_first = qt * PF_QTILE + w * 32;
+    const int qi = q_first + jq;
+    const bool q_live = qi < S;
+    const long long off = (long long)a.position_offset, win = (long long)a.window_size;
+    const long long qabs = off + min(qi, S - 1);
+    float scale = a.scale;
+    if (scale == 0.0f) scale = 1.0f / sqrtf((float)D);
+
+    const bool cut = a.window_size < a.new_len;   // :81 -- only then does the window move a query's first block
+    auto origin = [&](long long qa) -> long long { return (cut && qa > win) ? qa - win : 0; };
+    const long long B0 = origin(off + (long long)qt * PF_QTILE);
+    const long long o_q = origin(qabs);
+    const int s = (int)((o_q - B0) & 31);
+    // visible keys of this lane: lo_q <= key <= hi_q
+    const long long lo_q = max(o_q, qabs - win);
+    const long long hi_q = q_live ? min(qabs, (long long)KV - 1) : -1;
+
+    const int q_last_wg = min(S, (qt + 1) * PF_QTILE) - 1, q_last_wave = min(S - 1, q_first + 31);
+    const long long kv_end_wg = min((long long)KV, off + q_last_wg + 1);
+    const long long kv_end_wave = min((long long)KV, off + q_last_wave + 1);
+    const long long lo_wave = origin(off + min(q_first, S - 1));
+    const bool wave_live = q_first < S;
+    const int nT = kv_end_wg > B0 ? (int)((kv_end_wg - B0 + PF_BLOCK - 1) / PF_BLOCK) : 0;   // tiles; one more step closes the last block
+
+    v8hf qf[NST];
+    {
+        const uint16_t* qrow = a.q + (((size_t)b * S + min(qi, S - 1)) * Hq + h) * D;
+#pragma unroll
+        for (int st = 0; st < NST; st++) qf[st] = *reinterpret_cast<const v8hf*>(qrow + st * 16 + g * 8);
+    }
+    const uint16_t* Kb = a.k_new + (size_t)b * KV * Hkv * D + (size_t)kvh * D;
+    const uint16_t* Vb = a.v_new + (size_t)b * KV * Hkv * D + (size_t)kvh * D;
+    const size_t kv_stride = (size_t)Hkv * D;
+
+    // staging as in attn_prefill_kernel, K of tile t and V of tile t-1 (rows clamped into the matrix: their weights are 0)
+    v4i kst[PPT], vst[PPT];
+    const int vkey = lane & 31;
+    auto row_of = [&](long long key) -> size_t { return (size_t)max(0LL, min(key, (long long)KV - 1)); };
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            const int idx = p * 256 + tid, key = idx / (D / 8), d8 = idx % (D / 8);
+            kst[p] = *reinterpret_cast<const v4i*>(Kb + row_of(B0 + (long long)t * PF_BLOCK + key) * kv_stride + d8 * 8);
+            const int vd8 = (p * 4 + w) * 2 + g;
+            vst[p] = *reinterpret_cast<const v4i*>(Vb + row_of(B0 + (long long)(t - 1) * PF_BLOCK + vkey) * kv_stride + vd8 * 8);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < PPT; p++) {
+            const int idx = p * 256 + tid, key = idx / (D / 8), d8 = idx % (D / 8);
+            *reinterpret_cast<v4i*>(sK + key * KROW + d8 * 8) = kst[p];
+            const int vd8 = (p * 4 + w) * 2 + g;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                sVt[(vd8 * 8 + e) * VROW + vkey] = (uint16_t)(((uint32_t)vst[p][e >> 1] >> (16 * (e & 1))) & 0xFFFFu);
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    v16f o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[dt][r] = 0.0f;
+    float prev[16], carry[16];   // masked scores of tile t-1; weights of its keys ib < s (the tail of the block before)
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        prev[r] = -INFINITY;
+        carry[r] = 0.0f;
+    }
+
+    if (nT > 0) fetch(0);
+    for (int t = 0; t <= nT && nT > 0; t++) {
+        __syncthreads();
+        stash();
+        __syncthreads();
+        if (t + 1 <= nT) fetch(t + 1);
+
+        const long long kb = B0 + (long long)t * PF_BLOCK;   // first key of tile t
+        // wave-uniform: neither tile t-1 nor tile t holds a key that a query of this wave can see
+        if (!wave_live || kb + PF_BLOCK <= lo_wave || kb - PF_BLOCK >= kv_end_wave) continue;
+
+        v16f sacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.0f;
+#pragma unroll
+        for (int st = 0; st < NST; st++) {
+            const v8hf kf = *reinterpret_cast<const v8hf*>(sK + jq * KROW + st * 16 + g * 8);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], sacc, 0, 0, 0);
+        }
+        // this lane's 16 keys of a tile: ib = 8*(r/4) + 4*g + r%4
+        const int lo_i = (int)max(-64LL, min(64LL, lo_q - kb)) - 4 * g, hi_i = (int)max(-64LL, min(64LL, hi_q - kb)) - 4 * g;
+        const int sg = s - 4 * g;
+        float z[16];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ibg = 8 * (r >> 2) + (r & 3);
+            const float cur = (ibg >= lo_i && ibg <= hi_i) ? sacc[r] * scale : -INFINITY;
+            z[r] = (ibg >= sg) ? prev[r] : cur;   // the key of the block being closed that this register pair holds
+            prev[r] = cur;
+            bm = fmaxf(bm, z[r]);
+        }
+        bm = halves_max(bm);
+        if (bm > -INFINITY) {    // :160-169, the running maximum is replaced
+            const float corr = __expf(m_run - bm);
+            l_run *= corr;
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[dt][r] *= corr;
+#pragma unroll
+            for (int r = 0; r < 16; r++) carry[r] *= corr;
+            m_run = bm;
+        }
+        // the block ends at KV when fewer than 32 keys remain from its start: its last size % 4 keys use expf (:172, 197-204)
+        const long long bstart = kb - PF_BLOCK + s;
+        const int bsz = (int)min((long long)PF_BLOCK, (long long)KV - bstart);
+        const int vecn = bsz & ~3;
+        const bool near_end = kb + PF_BLOCK - 1 > (long long)KV;   // wave-uniform: some lane's block may be cut by KV
+        float wgt[16];
+        float bsum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int ibg = 8 * (r >> 2) + (r & 3);
+            const float x = (z[r] - bm) * 1.442695f;
+            const int xi = (int)x;
+            const float xf = x - (float)xi;
+            float y = fmaf(xf, 0.6931472f, 1.0f);
+            y = fmaf(xf * xf, 0.2402265f, y);
+            float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
+            if (near_end && ((ibg - sg) & 31) >= vecn) wv = __expf(z[r] - bm);
+            wv = (z[r] == -INFINITY) ? 0.0f : wv;
+            bsum += wv;
+            const bool head = ibg >= sg;           // a key of tile t-1; else of tile t: kept for the next step
+            wgt[r] = head ? wv : carry[r];
+            carry[r] = head ? 0.0f : wv;
+        }
+        bsum = halves_sum(bsum);
+        l_run += bsum;
+
+        v8hf phi[2], plo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float wv = wgt[8 * ks + e];
+                const _Float16 hi = (_Float16)wv;
+                phi[ks][e] = hi;
+                plo[ks][e] = (_Float16)(wv - (float)hi);
+            }
+        if (t == 0) continue;   // there is no tile before the first
+#pragma unroll
+        for (int dt = 0; dt < NDT; dt++) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const uint16_t* vr = sVt + (dt * 32 + jq) * VROW + 16 * ks + 4 * g;
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vr);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(vr + 8);
+                const v4i packed = {(int)v0.x, (int)v0.y, (int)v1.x, (int)v1.y};
+                const v8hf vf = __builtin_bit_cast(v8hf, packed);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, phi[ks], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, plo[ks], o[dt], 0, 0, 0);
+            }
+        }
+    }
+
+    if (!q_live) return;
     uint16_t* orow = a.out + (((size_t)b * S + qi) * Hq + h) * D;
     const float inv = (l_run > 0.0f) ? 1.0f / l_run : 0.0f;
 #pragma unroll
@@ -1027,16 +1245,37 @@ hipError_t launch_attention_prefill_hybrid(const AttnArgs& a, float* ws, hipStre
     return hipGetLastError();
 }
 
+static bool attn_prefill_common_ok(const AttnArgs& a) {
+    return a.f16_mode && a.mask == nullptr && (a.D == 64 || a.D == 128 || a.D == 256) && a.S >= 32 &&
+           a.new_len >= 1 && a.new_len < (size_t(1) << 30) && a.S < (size_t(1) << 30) && a.Hkv > 0 &&
+           a.Hq % a.Hkv == 0 && a.Hq <= 65535 && a.B <= 65535 && a.Hq * a.B <= 1048576 &&
+           ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k_new) |
+             reinterpret_cast<uintptr_t>(a.v_new) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+}
+
+// causal attention under a window that cuts: attn_prefill_win_kernel
+bool attn_prefill_win_ok(const AttnArgs& a) {
+    return a.window_size > 0 && a.is_causal && !attn_prefill_ok(a) && attn_prefill_common_ok(a) &&
+           a.position_offset < (size_t(1) << 40) && a.window_size < (size_t(1) << 40);
+}
+
+hipError_t launch_attention_prefill_win(const AttnArgs& a, hipStream_t st) {
+    if (!attn_prefill_win_ok(a)) return hipErrorInvalidValue;
+    const size_t total = ((a.S + PF_QTILE - 1) / PF_QTILE) * a.Hq * a.B;
+    if (total > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)total), block(256);
+    if (a.D == 256) attn_prefill_win_kernel<256><<<grid, block, 0, st>>>(a);
+    else if (a.D == 128) attn_prefill_win_kernel<128><<<grid, block, 0, st>>>(a);
+    else attn_prefill_win_kernel<64><<<grid, block, 0, st>>>(a);
+    return hipGetLastError();
+}
+
 bool attn_prefill_ok(const AttnArgs& a) {
     // a window that no (query, key) pair of the call can exceed does nothing (kernel_attention.cpp:78-90, 149-151:
     // it moves kv_start only when window < KV and masks a key only when more than `window` behind its query)
     const bool no_window = a.window_size == 0 ||
                            (a.window_size >= a.new_len && a.position_offset + a.S <= a.window_size + 1);
-    return a.f16_mode && a.mask == nullptr && no_window && (a.D == 64 || a.D == 128 || a.D == 256) && a.S >= 32 &&
-           a.new_len >= 1 && a.new_len < (size_t(1) << 30) && a.S < (size_t(1) << 30) && a.Hkv > 0 &&
-           a.Hq % a.Hkv == 0 && a.Hq <= 65535 && a.B <= 65535 && a.Hq * a.B <= 1048576 &&
-           ((reinterpret_cast<uintptr_t>(a.q) | reinterpret_cast<uintptr_t>(a.k_new) |
-             reinterpret_cast<uintptr_t>(a.v_new) | reinterpret_cast<uintptr_t>(a.out)) & 15) == 0;
+    return no_window && attn_prefill_common_ok(a);
 }
 
 hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st) {

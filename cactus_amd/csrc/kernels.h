@@ -184,6 +184,10 @@ hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f
 // 128, no window, no mask tensor); launch_attention routes eligible calls there
 bool attn_prefill_ok(const AttnArgs& a);
 hipError_t launch_attention_prefill(const AttnArgs& a, hipStream_t st);
+// causal FP16 attention whose sliding window cuts visible keys (every query's 32-key blocks start at its own first
+// visible key, kernel_attention.cpp:78-92): same shapes as above
+bool attn_prefill_win_ok(const AttnArgs& a);
+hipError_t launch_attention_prefill_win(const AttnArgs& a, hipStream_t st);
 // the same for cactus_attention_hybrid_int8_fp16 with many queries (a prefill chunk against the INT8
 // cache): key ranges split over workgroups, records merged by attn_merge_kernel (ws as in
 // attn_workspace_bytes)

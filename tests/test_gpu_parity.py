@@ -704,7 +704,14 @@ F16ATT = [
     (3, 64, 64, 6, 3, 64, 0, 0, True, False),
     (1, 200, 200, 4, 1, 128, 0, 512, True, False),   # a window longer than the prompt cuts nothing: matrix-core kernel
     (1, 64, 300, 4, 1, 128, 236, 512, True, False),  # ... with an offset, still inside the window
-    (1, 64, 600, 4, 1, 128, 536, 512, True, False),  # the window cuts: the VALU kernel
+    (1, 64, 600, 4, 1, 128, 536, 512, True, False),  # the window cuts: every query's blocks start at its own first key
+    (1, 700, 700, 4, 1, 256, 0, 512, True, False),   # Gemma local layer, the window starts to cut inside a workgroup
+    (1, 300, 300, 4, 2, 128, 0, 100, True, False),   # a window that is no multiple of the block
+    (2, 200, 331, 4, 2, 64, 131, 50, True, False),   # offset; the last block is cut by the K/V length (expf tail of 3)
+    (1, 130, 130, 2, 1, 64, 0, 7, True, False),      # a window shorter than a block
+    (1, 96, 400, 2, 1, 128, 1000, 512, True, False), # every query lies further than the window behind the last key: zeros
+    (1, 64, 300, 2, 1, 64, 500, 400, True, False),   # a window longer than K/V masks by distance only (blocks from key 0)
+    (1, 64, 200, 2, 1, 128, 300, 64, False, False),  # non-causal with a window: the VALU kernel
     (2, 300, 300, 8, 2, 128, 0, 0, True, False),     # two sequences, heads x sequences a multiple of 8 (heads pinned to XCDs)
     (2, 200, 260, 4, 2, 64, 60, 0, True, False),
     (1, 128, 96, 8, 8, 128, 0, 0, False, False),     # 3 key blocks: the two wave groups take 2 and 1
