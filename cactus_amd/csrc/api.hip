@@ -1067,10 +1067,11 @@ int cactus_hip_sample_f16_dev(const cactus_half_t* logits, uint32_t* output, siz
     if (!draws || !workspace) return fail(CACTUS_HIP_EINVAL, "sample: draws and workspace are required");
     if ((history == nullptr) != (history_counts == nullptr))
         return fail(CACTUS_HIP_EINVAL, "sample: history and history_counts go together");
-    // top_k = 0 (or above what the first kernel holds in LDS) can leave a row more survivors than that: those
-    // rows are finished by a second kernel that works in the library workspace
+    // top_k = 0, a top_k above what the first kernel holds in LDS, or ties with the k-th value (all of them survive,
+    // kernel_nn.cpp:526-533) can leave a row more survivors than that: those rows are finished by a second kernel
+    // that works in the library workspace (rows it has nothing to do for cost it one word read)
     void* wide = nullptr;
-    if ((top_k == 0 || top_k > cactus_hip_sample_max_survivors()) && vocab_size > cactus_hip_sample_max_survivors()) {
+    if (vocab_size > cactus_hip_sample_max_survivors()) {
         int rc = ::workspace(sample_wide_scratch_bytes(rows), &wide);
         if (rc != CACTUS_HIP_OK) return rc;
     }
@@ -1182,6 +1183,36 @@ int cactus_hip_attention_hybrid_int8_fp16_dev(
         return fail(CACTUS_HIP_EINVAL, "attention_hybrid: null cache");
     if (new_len && (!keys_new || !values_new)) return fail(CACTUS_HIP_EINVAL, "attention_hybrid: null new K/V");
     return attention(a, stream);
+}
+
+int cactus_hip_attention_hybrid_int8_fp16_quant_dev(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales, const cactus_half_t* keys_new,
+    const cactus_half_t* values_new, cactus_half_t* output, int8_t* output_q, float* output_scales,
+    size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len, size_t num_q_heads, size_t num_kv_heads,
+    size_t head_dim, float scale, size_t position_offset, int is_causal, size_t group_size, void* stream) {
+    AttnArgs a{};
+    a.q = queries; a.k_cached = keys_cached; a.v_cached = values_cached;
+    a.k_scales = k_scales; a.v_scales = v_scales; a.k_new = keys_new; a.v_new = values_new;
+    a.out = output; a.B = batch_size; a.S = seq_len; a.cache_len = cache_len; a.new_len = new_len;
+    a.Hq = num_q_heads; a.Hkv = num_kv_heads; a.D = head_dim; a.scale = scale;
+    a.position_offset = position_offset; a.is_causal = is_causal; a.qgs = group_size;
+    a.cache_batch_stride = cache_len * num_kv_heads * head_dim;
+    a.scale_batch_stride = 0;
+    a.f16_mode = 0;
+    if (a.B == 0 || a.S == 0 || a.Hq == 0 || a.D == 0) return CACTUS_HIP_OK;
+    if (a.Hkv == 0 || a.Hq % a.Hkv != 0) return fail(CACTUS_HIP_EINVAL, "attention_hybrid_quant: Hq must be a multiple of Hkv");
+    if (a.D > 8000 || a.qgs == 0) return fail(CACTUS_HIP_EINVAL, "attention_hybrid_quant: head_dim above 8000 or KV group_size 0");
+    if (!queries || !output || !output_q || !output_scales) return fail(CACTUS_HIP_EINVAL, "attention_hybrid_quant: null operand");
+    if (cache_len && (!keys_cached || !values_cached || !k_scales || !v_scales))
+        return fail(CACTUS_HIP_EINVAL, "attention_hybrid_quant: null cache");
+    if (new_len && (!keys_new || !values_new)) return fail(CACTUS_HIP_EINVAL, "attention_hybrid_quant: null new K/V");
+    void* ws = nullptr;
+    int rc = workspace(attn_workspace_bytes(a), &ws);
+    if (rc != CACTUS_HIP_OK) return rc;
+    hipError_t e = launch_attention_quant(a, ws, output_q, output_scales, S(stream));
+    if (e != hipSuccess) return fail(CACTUS_HIP_ERUNTIME, "attention_hybrid_quant launch", e);
+    return CACTUS_HIP_OK;
 }
 
 size_t cactus_hip_noalloc_scratch_bytes(void) { return NOALLOC_SCRATCH_BYTES; }

@@ -703,6 +703,96 @@ hipError_t launch_attention_decode_fused(const AttnArgs& a, const AttnFusedIn& f
     return e;
 }
 
+// The split records of a prefill chunk (attn_prefill_hybrid_kernel) merged per TOKEN: a workgroup owns the Hq * D
+// outputs of one query token, so the activation quantization
+// that the output projection needs (graph_ops_nn.cpp:35-66: absmax / 127 over the row, round to nearest even) can
+// follow in the same launch on the rounded fp16 values -- the same numbers as act_quant_rowwise_kernel gives on
+// `out`.  Up to MERGE_TOKEN_PASSES * 2048 outputs per token (two consecutive dims per thread and pass).
+constexpr int MERGE_TOKEN_PASSES = 4;
+constexpr int MERGE_TOKEN_THREADS = 1024;
+__global__ __launch_bounds__(MERGE_TOKEN_THREADS) void attn_merge_token_kernel(
+    const float* __restrict__ ws, uint16_t* __restrict__ out, int8_t* __restrict__ q_out, float* __restrict__ q_scales,
+    int nsplit, int Hq, int D) {
+    __shared__ float red[MERGE_TOKEN_THREADS / 64];
+    const size_t tok = blockIdx.x;
+    const int QD = Hq * D, tid = threadIdx.x;
+    const int rec = D + 2;
+    uint32_t packed[MERGE_TOKEN_PASSES];   // two outputs per thread and pass
+    float amax = 0.0f;
+#pragma unroll
+    for (int p = 0; p < MERGE_TOKEN_PASSES; p++) {
+        const int e0 = (p * MERGE_TOKEN_THREADS + tid) * 2;
+        if (e0 >= QD) break;
+        const int h = e0 / D, d0 = e0 - h * D;
+        const float* base = ws + (tok * Hq + h) * (size_t)nsplit * rec;
+        // loads in batches of 8 splits, all issued before the first use (a record comes from another XCD's L2 or
+        // from memory: a microsecond each if waited for one by one)
+        float M = -INFINITY;
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            float m[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) m[u] = base[(size_t)min(s0 + u, nsplit - 1) * rec];
+#pragma unroll
+            for (int u = 0; u < 8; u++) M = fmaxf(M, m[u]);
+        }
+        float L = 0.0f, ox = 0.0f, oy = 0.0f;
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            float2 ml[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float* r = base + (size_t)min(s0 + u, nsplit - 1) * rec;
+                ml[u] = *reinterpret_cast<const float2*>(r);
+                v[u] = *reinterpret_cast<const float2*>(r + 2 + d0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float f = (M > -INFINITY && s0 + u < nsplit) ? __expf(ml[u].x - M) : 0.0f;
+                L = fmaf(ml[u].y, f, L);
+                ox = fmaf(v[u].x, f, ox);
+                oy = fmaf(v[u].y, f, oy);
+            }
+        }
+        const float inv = (L > 0.0f) ? 1.0f / L : 0.0f;
+        const uint16_t a = (L > 0.0f) ? f2h_mul(ox, inv) : (uint16_t)0;
+        const uint16_t b = (L > 0.0f) ? f2h_mul(oy, inv) : (uint16_t)0;
+        packed[p] = (uint32_t)a | ((uint32_t)b << 16);
+        amax = fmaxf(amax, fmaxf(fabsf(h2f(a)), fabsf(h2f(b))));
+        *reinterpret_cast<uint32_t*>(out + tok * QD + e0) = packed[p];
+    }
+    if (q_out == nullptr) return;
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MERGE_TOKEN_THREADS / 64; i++) amax = fmaxf(amax, red[i]);
+    float scale = amax / 127.0f;
+    if (scale < 1e-10f) scale = 1e-10f;
+    if (tid == 0) q_scales[tok] = scale;
+    const float qinv = 1.0f / scale;
+#pragma unroll
+    for (int p = 0; p < MERGE_TOKEN_PASSES; p++) {
+        const int e0 = (p * MERGE_TOKEN_THREADS + tid) * 2;
+        if (e0 >= QD) break;
+        uint32_t w2 = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float q = h2f((uint16_t)(j ? (packed[p] >> 16) : (packed[p] & 0xFFFFu))) * qinv;
+            q = fmaxf(fminf(q, 127.0f), -128.0f);
+            w2 |= (uint32_t)(clamp_i8(rne_i32(q)) & 0xFF) << (8 * j);
+        }
+        *reinterpret_cast<uint16_t*>(q_out + tok * QD + e0) = (uint16_t)w2;
+    }
+}
+
+// merge launch behind attn_prefill_hybrid_kernel: per token when a token's outputs fit the kernel above and are
+// 16-byte pieces, else per (token, head) row
+static bool merge_token_ok(const AttnArgs& a, const int8_t* q_out) {
+    const size_t QD = a.Hq * a.D;
+    return a.D % 2 == 0 && QD <= (size_t)MERGE_TOKEN_PASSES * MERGE_TOKEN_THREADS * 2 && a.B * a.S <= 0x7FFFFFFFull &&
+           (reinterpret_cast<uintptr_t>(a.out) & 3) == 0 && (reinterpret_cast<uintptr_t>(q_out) & 1) == 0;
+}
+
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) {
     if (attn_prefill_ok(a)) return launch_attention_prefill(a, st);
     if (attn_prefill_win_ok(a)) return launch_attention_prefill_win(a, st);
@@ -710,8 +800,12 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) 
         hipError_t e = launch_attention_prefill_hybrid(a, reinterpret_cast<float*>(workspace), st);
         const int ns = attn_prefill_hybrid_splits(a);
         if (e == hipSuccess && ns > 1) {
-            attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(
-                reinterpret_cast<const float*>(workspace), a.out, ns, (int)a.D);
+            if (merge_token_ok(a, nullptr))
+                attn_merge_token_kernel<<<dim3((unsigned)(a.B * a.S)), dim3(MERGE_TOKEN_THREADS), 0, st>>>(
+                    reinterpret_cast<const float*>(workspace), a.out, nullptr, nullptr, ns, (int)a.Hq, (int)a.D);
+            else
+                attn_merge_kernel<<<dim3((unsigned)(a.B * a.Hq * a.S)), dim3(256), 0, st>>>(
+                    reinterpret_cast<const float*>(workspace), a.out, ns, (int)a.D);
             e = hipGetLastError();
         }
         return e;
@@ -760,6 +854,23 @@ hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st) 
         e = hipGetLastError();
     }
     return e;
+}
+
+// attention followed by the row quantization of its output (rows = tokens, Hq * D values each) for the output
+// projection: one merge + quantization launch behind a chunk attention that leaves split records, else the
+// attention's own launches and the row quantization kernel
+hipError_t launch_attention_quant(const AttnArgs& a, void* workspace, int8_t* q_out, float* q_scales, hipStream_t st) {
+    if (attn_prefill_hybrid_ok(a) && !attn_prefill_ok(a) && !attn_prefill_win_ok(a) && attn_prefill_hybrid_splits(a) > 1 &&
+        merge_token_ok(a, q_out)) {
+        hipError_t e = launch_attention_prefill_hybrid(a, reinterpret_cast<float*>(workspace), st);
+        if (e != hipSuccess) return e;
+        attn_merge_token_kernel<<<dim3((unsigned)(a.B * a.S)), dim3(MERGE_TOKEN_THREADS), 0, st>>>(
+            reinterpret_cast<const float*>(workspace), a.out, q_out, q_scales, attn_prefill_hybrid_splits(a), (int)a.Hq, (int)a.D);
+        return hipGetLastError();
+    }
+    hipError_t e = launch_attention(a, workspace, st);
+    if (e != hipSuccess) return e;
+    return launch_act_quant(a.out, q_out, q_scales, a.B * a.S, a.Hq * a.D, st);
 }
 
 }  // namespace cactus_hip

@@ -144,6 +144,8 @@ struct AttnArgs {
 // workspace: float scratch for split-KV partials; needs attn_workspace_bytes(args) bytes.
 size_t attn_workspace_bytes(const AttnArgs& a);
 hipError_t launch_attention(const AttnArgs& a, void* workspace, hipStream_t st);
+// the same, and the output rows [B * S, Hq * D] quantized as launch_act_quant would (q_out int8, q_scales [B * S])
+hipError_t launch_attention_quant(const AttnArgs& a, void* workspace, int8_t* q_out, float* q_scales, hipStream_t st);
 
 // attention_decode.hip: cactus_attention_hybrid_int8_fp16 for one query position per sequence on the matrix
 // cores (head_dim 64 / 128 with one scale group per row or 256 with two, up to 16 query heads per kv head); key ranges split

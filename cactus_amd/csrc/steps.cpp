@@ -305,12 +305,13 @@ int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cact
         STEP_TRY(cactus_hip_qk_norm_rope_kv_append_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, d.qr, d.kr, kc, vc, ks, vs,
                                                           cache_start_dev, 1, M, Hq, Hkv, D, w->eps, cache_start, w->theta, 128, cbs,
                                                           sbs, st->capacity, stream));
-        if (cache_start == 0)
+        if (cache_start == 0) {
             STEP_TRY(cactus_hip_attention_f16_dev(d.qr, d.kr, d.vo, d.ao, 1, M, M, Hq, Hkv, D, 0.0f, nullptr, 0, 0, 1, stream));
-        else
-            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, 1, M, cache_start, M, Hq, Hkv, D,
-                                                              0.0f, cache_start, 1, 128, stream));
-        STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
+            STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
+        } else {
+            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_quant_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, d.oq, d.os, 1, M, cache_start,
+                                                                    M, Hq, Hkv, D, 0.0f, cache_start, 1, 128, stream));
+        }
         STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, M, stream));
         STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, M, Hd, w->eps, stream));
         const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};

@@ -68,6 +68,7 @@ SIGNATURES = {
     "cactus_hip_attention_f16_dev": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, _f, _vp,
                                           _sz, _sz, _i, _vp]),
     "cactus_hip_attention_hybrid_int8_fp16_dev": (_i, [_vp] * 8 + [_sz] * 7 + [_f, _sz, _i, _sz, _vp]),
+    "cactus_hip_attention_hybrid_int8_fp16_quant_dev": (_i, [_vp] * 10 + [_sz] * 7 + [_f, _sz, _i, _sz, _vp]),
     "cactus_hip_attention_hybrid_int8_fp16_noalloc_dev": (_i, [_vp] * 8 + [_sz] * 7 + [_f, _sz, _i, _sz, _vp]),
     "cactus_hip_noalloc_scratch_bytes": (_sz, []),
     "cactus_hip_attention_hybrid_records_bytes": (_sz, [_sz] * 8 + [_i, _sz]),
@@ -783,15 +784,24 @@ def attention_f16(q, k, v, scale, mask=None, position_offset=0, window_size=0, i
 
 
 def attention_hybrid(q, k_cached, v_cached, k_scales, v_scales, k_new, v_new, scale, position_offset=0,
-                     is_causal=True, group_size=128, cache_len=None, out=None, noalloc=False):
+                     is_causal=True, group_size=128, cache_len=None, out=None, noalloc=False, out_q=None,
+                     out_scales=None):
     """noalloc: the entry point that keeps its split-KV records in the library's fixed scratch
-    (pass `out`, so that nothing is allocated on the way either)."""
+    (pass `out`, so that nothing is allocated on the way either).
+    out_q int8 [B * S, Hq * D] / out_scales fp32 [B * S]: the output rows are also left quantized for the
+    output projection."""
     _dev(q, torch.float16)
     B, S, Hq, D = q.shape
     new_len, Hkv = k_new.shape[1], k_new.shape[2]
     if cache_len is None:
         cache_len = k_cached.shape[-3]
     out = out if out is not None else torch.empty_like(q)
+    if out_q is not None:
+        _check(lib.cactus_hip_attention_hybrid_int8_fp16_quant_dev(
+            _p(q), _p(k_cached), _p(v_cached), _p(k_scales), _p(v_scales), _p(k_new), _p(v_new), _p(out), _p(out_q),
+            _p(out_scales), B, S, cache_len, new_len, Hq, Hkv, D, float(scale), position_offset, int(bool(is_causal)),
+            group_size, _stream()))
+        return out
     fn = lib.cactus_hip_attention_hybrid_int8_fp16_noalloc_dev if noalloc else lib.cactus_hip_attention_hybrid_int8_fp16_dev
     _check(fn(
         _p(q), _p(k_cached), _p(v_cached), _p(k_scales), _p(v_scales), _p(k_new), _p(v_new), _p(out),

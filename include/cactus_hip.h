@@ -391,12 +391,13 @@ int cactus_hip_sample_greedy_f16_dev(const cactus_half_t* logits, uint32_t* outp
  *     before use (:473-496), so they never change a result.
  *   - workspace: device half[rows, vocab_size] scratch.
  *   - a row of which at most cactus_hip_sample_max_survivors() logits survive top-k is sampled by one
- *     launch.  With top_k == 0 (every finite logit survives) or top_k above that number, rows with more
- *     survivors are finished by a second, slower launch (about a millisecond for 150k survivors: the
- *     reference's sequential fp32 sums in descending and in index order are kept) that works in the
- *     library workspace (cactus_hip_workspace_reserve before stream capture: 25 MB).  Only a row whose
- *     ties with the k-th value push a top_k <= that number beyond it gets token 0xFFFFFFFF and *status
- *     (device int, may be NULL, cleared by the caller) set to 1.
+ *     launch.  Rows with more survivors (top_k == 0: every finite logit survives; a top_k above that
+ *     number; ties with the k-th value, which all survive, :526-533) are finished by a second, slower
+ *     launch (about a millisecond for 150k survivors: the reference's sequential fp32 sums in
+ *     descending and in index order are kept) that works in the library workspace
+ *     (cactus_hip_workspace_reserve before stream capture: 25 MB); it is enqueued whenever vocab_size
+ *     exceeds that number and returns at once for rows that are done.  *status (device int, may be
+ *     NULL) is not written by this entry.
  *   - equal logits keep ascending index order in the top-p pass (the reference leaves it to
  *     std::sort); exp is computed in double and rounded (the reference uses its libm's expf). */
 int cactus_hip_sample_f16_dev(const cactus_half_t* logits, uint32_t* output, size_t rows,
@@ -445,6 +446,21 @@ int cactus_hip_attention_hybrid_int8_fp16_dev(
     const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
     const float* k_scales, const float* v_scales,
     const cactus_half_t* keys_new, const cactus_half_t* values_new, cactus_half_t* output,
+    size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
+    size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
+    float scale, size_t position_offset, int is_causal, size_t group_size, void* stream);
+
+/* cactus_attention_hybrid_int8_fp16 (kernel.h:92-104) followed by the activation quantization that the
+ * output projection applies to the attention node's output (graph_ops_nn.cpp:35-66; model_qwen.cpp:103-106):
+ * output as above, and output_q int8[B * S, Hq * D] (8-byte aligned) with output_scales float[B * S] equal to
+ * cactus_hip_quantize_activations_dev(output, ...) bit for bit.  For a prefill chunk whose key range is
+ * split over workgroups the merge of the splits and the quantization are one launch (one workgroup per
+ * token); other shapes run the quantization kernel behind the attention. */
+int cactus_hip_attention_hybrid_int8_fp16_quant_dev(
+    const cactus_half_t* queries, const int8_t* keys_cached, const int8_t* values_cached,
+    const float* k_scales, const float* v_scales,
+    const cactus_half_t* keys_new, const cactus_half_t* values_new, cactus_half_t* output,
+    int8_t* output_q, float* output_scales,
     size_t batch_size, size_t seq_len, size_t cache_len, size_t new_len,
     size_t num_q_heads, size_t num_kv_heads, size_t head_dim,
     float scale, size_t position_offset, int is_causal, size_t group_size, void* stream);

@@ -627,6 +627,36 @@ def test_attention_hybrid_vs_oracle(H, B, S, Hq, Hkv, D, cache, new, off):
     assert (d <= 2e-3 + 4e-3 * np.abs(want)).all(), d.max()
 
 
+@pytest.mark.parametrize("B,S,Hq,Hkv,D,cache,new,off", [
+    (1, 256, 16, 8, 128, 512, 256, None),    # Qwen3 prefill chunk: splits merged per token, quantized in the same launch
+    (1, 256, 16, 8, 128, 3840, 256, None),   # the last chunk of a 4096-token prompt
+    (2, 64, 6, 2, 128, 200, 64, None),       # 768 outputs per token: part of the workgroup idle
+    (1, 70, 40, 8, 128, 333, 70, None),      # 5120 outputs per token: three passes per thread
+    (1, 256, 4, 1, 256, 700, 256, None),     # Gemma heads
+    (1, 40, 4, 2, 64, 333, 40, None),
+    (1, 5, 4, 2, 128, 70, 5, None),          # few queries: attention, then the row quantization kernel
+    (3, 1, 16, 8, 128, 100, 1, None),        # decode shape
+    (1, 40, 80, 8, 128, 333, 40, None),      # 10240 outputs per token: more than the merge kernel holds
+])
+def test_attention_hybrid_quant_equals_attention_then_quantize(H, B, S, Hq, Hkv, D, cache, new, off):
+    """cactus_hip_attention_hybrid_int8_fp16_quant_dev: the quantized rows and scales are exactly what
+    cactus_hip_quantize_activations_dev makes of ITS output, and that output is within the hybrid attention's
+    tolerance of the oracle."""
+    rng = np.random.default_rng(B * 7 + S + D + cache + 1)
+    q, kq, vq, ks, vs, kn, vn = _hybrid_case(rng, B, S, Hq, Hkv, D, cache, new)
+    off = cache if off is None else off
+    oq = torch.empty((B * S, Hq * D), dtype=torch.int8, device="cuda")
+    osc = torch.empty((B * S,), dtype=torch.float32, device="cuda")
+    out = H.attention_hybrid(dev(q), dev(kq), dev(vq), dev(ks), dev(vs), dev(kn), dev(vn), 0.0, position_offset=off,
+                             cache_len=cache, out_q=oq, out_scales=osc)
+    want_q, want_s = H.quantize_activations(out.reshape(B * S, Hq * D))
+    assert torch.equal(oq, want_q)
+    assert torch.equal(osc, want_s)
+    want = O.attention_hybrid(q, kq, vq, ks, vs, kn, vn, 0.0, position_offset=off, cache_len=cache)
+    d = np.abs(f16(bits(out)) - f16(want))
+    assert (d <= 2e-3 + 4e-3 * np.abs(f16(want))).all(), d.max()
+
+
 @pytest.mark.parametrize("B,Hq,Hkv,D,cache", [(1, 16, 8, 128, 512), (4, 16, 8, 128, 4096), (1, 32, 8, 64, 333),
                                               (64, 32, 8, 64, 100), (1, 32, 8, 128, 20000), (2, 4, 1, 256, 512),
                                               (1, 8, 4, 256, 6000)])
