@@ -145,7 +145,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     constexpr int NG = D == 256 ? 2 : 1;            // scale groups per row (head_dim 256: two groups of 128 dims)
     constexpr int CG = NC / NG;                     // column blocks per scale group
     constexpr int RING = NW * DC_STAGES * STAGE;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0)];   // + each wave's rotated key row (+ its absmax)
+    constexpr int ROWS_OWN = FUSED && D == 256 ? 18 * D * 2 : 0;   // per wave: the fused rows when a ring stage cannot hold them
+    static_assert(ROWS_OWN || !FUSED || 18 * D * 2 <= STAGE, "a stage holds the fused rows");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0) + NW * ROWS_OWN];   // + each wave's rotated key row (+ its absmax) (+ rows)
 
     const AttnArgs& a = p.a;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -181,88 +183,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 
     uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
     uint16_t* kn_lds = reinterpret_cast<uint16_t*>(lds + RING) + (FUSED ? w * D : 0);
-    if constexpr (FUSED) {
-        // rows of this wave, 16 lanes each, four at a time: its query heads, its key, and (key range 0) its value;
-        // they sit in the still idle ring: [gq] normalized + rotated q rows, the k row, the raw v row
-        const AttnFusedIn& f = p.f;
-        uint16_t* rows = reinterpret_cast<uint16_t*>(my_lds);
-        const int l = lane & 15, g = lane >> 4, base = lane & ~15;
-        const int nrows = gq + (split == 0 ? 2 : 0);      // only key range 0 uses the step's own key and value
-        const int pos = max(0, min((int)qabs, f.max_position));
-        const bool place = split == 0 && (size_t)cl < f.max_slots;
-        const size_t doff = (size_t)b * a.cache_batch_stride + ((size_t)cl * Hkv + kvh) * D;
-        const size_t soff = (size_t)b * a.scale_batch_stride + ((size_t)cl * Hkv + kvh) * (size_t)((D + (int)a.qgs - 1) / (int)a.qgs);
-        for (int r0 = 0; r0 < nrows; r0 += 4) {
-            const bool act = r0 + g < nrows;
-            const int r = min(r0 + g, nrows - 1);
-            const bool is_q = r < gq, is_k = r == gq, is_v = r > gq;
-            const uint16_t* src = is_q ? a.q + ((size_t)b * Hq + h0 + r) * D
-                                       : (is_k ? a.k_new : a.v_new) + ((size_t)b * Hkv + kvh) * D;
-            uint16_t* nrm = rows + (size_t)r * D;
-            if (act)
-                for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(nrm + c * 8) = *reinterpret_cast<const v4i*>(src + c * 8);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const float inv = row_inv_rms([&](int i) -> uint16_t { return nrm[i]; }, D, f.eps, l, base);
-            const h16 inv_h = (h16)inv;
-            if (act && !is_v) {
-                const uint16_t* wv = is_q ? f.q_weight : f.k_weight;
-                for (int i = l; i < D; i += 16) nrm[i] = rms_out(nrm[i], wv[i], inv, inv_h, true);   // own elements
-                for (int i = l; i < D / 2; i += 16) {                                               // ... and their RoPE pairs
-                    uint16_t o1, o2;
-                    rope_pair(f.cos_t[(size_t)pos * (D / 2) + i], f.sin_t[(size_t)pos * (D / 2) + i], nrm[i], nrm[D / 2 + i], o1, o2);
-                    nrm[i] = o1;
-                    nrm[D / 2 + i] = o2;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (act && is_k) {
-                for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(kn_lds + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
-                if (f.k_out)      // key range 0 only (the other ranges do not process the key): one writer per row
-                    for (int c = l; c < D / 8; c += 16)
-                        *reinterpret_cast<v4i*>(f.k_out + ((size_t)b * Hkv + kvh) * D + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
-            }
-            if (act && place && !is_q)
-                quant_row_groups(nrm, D, (int)a.qgs, (is_k ? f.kc : f.vc) + doff, (is_k ? f.ks : f.vs) + soff, l);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-
-    // Q^T operand: lane (head, q) holds, for MFMA step (ld, half), Q[head][64 ld + 16 q + 8 half .. + 8)
-    v8h qreg[KL * 2];
-    float qsum[NG];
-#pragma unroll
-    for (int n = 0; n < NG; n++) qsum[n] = 0.0f;
-    {
-        const uint16_t* qrow = FUSED ? reinterpret_cast<const uint16_t*>(my_lds) + (size_t)min(hd, gq - 1) * D
-                                     : a.q + ((size_t)b * Hq + h0 + min(hd, gq - 1)) * D;
-#pragma unroll
-        for (int s = 0; s < KL * 2; s++) {
-            v4i raw = *reinterpret_cast<const v4i*>(qrow + 64 * (s >> 1) + 16 * q + 8 * (s & 1));
-            if (hd >= gq) raw = v4i{0, 0, 0, 0};
-            qreg[s] = __builtin_bit_cast(v8h, raw);
-#pragma unroll
-            for (int e = 0; e < 8; e++) qsum[(s >> 1) * NG / KL] += (float)qreg[s][e];
-        }
-#pragma unroll
-        for (int n = 0; n < NG; n++) {
-            qsum[n] = quad_rows_sum(qsum[n]);
-        }
-    }
-    float nqsum[NG];        // per scale group: the group's scores are rescaled separately
-#pragma unroll
-    for (int n = 0; n < NG; n++) nqsum[n] = -1152.0f * qsum[n];
-    const float scale2 = scale * 1.44269504f;     // scores are kept times log2(e)
-    if constexpr (FUSED) {      // the q rows are in registers: the ring may be written from here on
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-
+    uint8_t* rows_lds = ROWS_OWN ? lds + RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0) + w * ROWS_OWN : my_lds + STAGE;
+    struct KRegs { v4i k[2][KL]; };
     // per-lane pieces of the addresses
     constexpr int ROW_CHUNKS = D / 16;                               // 16-byte chunks of a row
     const int dma_row = lane / ROW_CHUNKS;                           // row inside one DMA instruction
@@ -293,7 +215,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     // the other lanes nothing
     const unsigned s_lane_off = lane < 32 * NG ? (unsigned)(((lane / NG) * Hkv + kvh) * NG + lane % NG) * 4u : OOB;
 
-    struct KRegs { v4i k[2][KL]; };
     // K: 16 keys x 64 bytes per wave instruction, straight to registers
     auto issue_k = [&](int blk, KRegs& kr) __attribute__((always_inline)) {
         const unsigned base = blk < blk_last ? (unsigned)blk * DC_BLOCK * (unsigned)row_stride : OOB;
@@ -315,6 +236,118 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ksrsrc, (lptr_t)(st + VBYTES), 4, (int)(sbase + s_lane_off), 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrsrc, (lptr_t)(st + VBYTES + 256), 4, (int)(sbase + s_lane_off), 0, 0, 0);
     };
+
+    KRegs kr[DC_STAGES];
+    // FUSED: the first block of the wave's range is requested before the wave turns to its rows (whose loads, tables
+    // and arithmetic would otherwise all precede the first byte of the cache stream); the rows then sit in the ring's
+    // second stage, which the requests of the second block overwrite once the q rows are in registers
+    // (head_dim 256: up to 18 rows of 512 bytes do not fit a stage and have an area of their own).  The requests are
+    // unconditional like all others: a wave without blocks reads nothing.
+    constexpr bool early = FUSED;
+    if constexpr (early) {
+        issue_k(blk_first, kr[0]);
+        issue_v(blk_first, 0);
+    }
+    if constexpr (FUSED) {
+        // rows of this wave, 16 lanes each, four at a time: its query heads, its key, and (key range 0) its value;
+        // they sit in the still idle ring: [gq] normalized + rotated q rows, the k row, the raw v row
+        const AttnFusedIn& f = p.f;
+        uint16_t* rows = reinterpret_cast<uint16_t*>(rows_lds);
+        const int l = lane & 15, g = lane >> 4, base = lane & ~15;
+        const int nrows = gq + (split == 0 ? 2 : 0);      // only key range 0 uses the step's own key and value
+        const int pos = max(0, min((int)qabs, f.max_position));
+        const bool place = split == 0 && (size_t)cl < f.max_slots;
+        const size_t doff = (size_t)b * a.cache_batch_stride + ((size_t)cl * Hkv + kvh) * D;
+        const size_t soff = (size_t)b * a.scale_batch_stride + ((size_t)cl * Hkv + kvh) * (size_t)((D + (int)a.qgs - 1) / (int)a.qgs);
+        for (int r0 = 0; r0 < nrows; r0 += 4) {
+            const bool act = r0 + g < nrows;
+            const int r = min(r0 + g, nrows - 1);
+            const bool is_q = r < gq, is_k = r == gq, is_v = r > gq;
+            const uint16_t* src = is_q ? a.q + ((size_t)b * Hq + h0 + r) * D
+                                       : (is_k ? a.k_new : a.v_new) + ((size_t)b * Hkv + kvh) * D;
+            uint16_t* nrm = rows + (size_t)r * D;
+            // everything the row needs from memory is requested at once: its halves, the norm weights of the lane's
+            // elements, the rotation factors of its pairs (one round trip instead of three dependent ones)
+            constexpr int RC = (D / 8 + 15) / 16;
+            v4i rowv[RC];
+            uint16_t wreg[D / 16], creg[D / 32], sreg[D / 32];
+            const uint16_t* wv = is_q ? f.q_weight : f.k_weight;
+#pragma unroll
+            for (int j = 0; j < RC; j++) rowv[j] = *reinterpret_cast<const v4i*>(src + min(l + 16 * j, D / 8 - 1) * 8);
+#pragma unroll
+            for (int j = 0; j < D / 16; j++) wreg[j] = wv[l + 16 * j];
+#pragma unroll
+            for (int j = 0; j < D / 32; j++) {
+                creg[j] = f.cos_t[(size_t)pos * (D / 2) + l + 16 * j];
+                sreg[j] = f.sin_t[(size_t)pos * (D / 2) + l + 16 * j];
+            }
+            if (act)
+#pragma unroll
+                for (int j = 0; j < RC; j++)
+                    if (l + 16 * j < D / 8) *reinterpret_cast<v4i*>(nrm + (l + 16 * j) * 8) = rowv[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float inv = row_inv_rms([&](int i) -> uint16_t { return nrm[i]; }, D, f.eps, l, base);
+            const h16 inv_h = (h16)inv;
+            if (act && !is_v) {
+#pragma unroll
+                for (int j = 0; j < D / 16; j++) nrm[l + 16 * j] = rms_out(nrm[l + 16 * j], wreg[j], inv, inv_h, true);   // own elements
+#pragma unroll
+                for (int j = 0; j < D / 32; j++) {                                                                       // ... and their RoPE pairs
+                    const int i = l + 16 * j;
+                    uint16_t o1, o2;
+                    rope_pair(creg[j], sreg[j], nrm[i], nrm[D / 2 + i], o1, o2);
+                    nrm[i] = o1;
+                    nrm[D / 2 + i] = o2;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (act && is_k) {
+                for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(kn_lds + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
+                if (f.k_out)      // key range 0 only (the other ranges do not process the key): one writer per row
+                    for (int c = l; c < D / 8; c += 16)
+                        *reinterpret_cast<v4i*>(f.k_out + ((size_t)b * Hkv + kvh) * D + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
+            }
+            if (act && place && !is_q)
+                quant_row_groups(nrm, D, (int)a.qgs, (is_k ? f.kc : f.vc) + doff, (is_k ? f.ks : f.vs) + soff, l);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // Q^T operand: lane (head, q) holds, for MFMA step (ld, half), Q[head][64 ld + 16 q + 8 half .. + 8)
+    v8h qreg[KL * 2];
+    float qsum[NG];
+#pragma unroll
+    for (int n = 0; n < NG; n++) qsum[n] = 0.0f;
+    {
+        const uint16_t* qrow = FUSED ? reinterpret_cast<const uint16_t*>(rows_lds) + (size_t)min(hd, gq - 1) * D
+                                     : a.q + ((size_t)b * Hq + h0 + min(hd, gq - 1)) * D;
+#pragma unroll
+        for (int s = 0; s < KL * 2; s++) {
+            v4i raw = *reinterpret_cast<const v4i*>(qrow + 64 * (s >> 1) + 16 * q + 8 * (s & 1));
+            if (hd >= gq) raw = v4i{0, 0, 0, 0};
+            qreg[s] = __builtin_bit_cast(v8h, raw);
+#pragma unroll
+            for (int e = 0; e < 8; e++) qsum[(s >> 1) * NG / KL] += (float)qreg[s][e];
+        }
+#pragma unroll
+        for (int n = 0; n < NG; n++) {
+            qsum[n] = quad_rows_sum(qsum[n]);
+        }
+    }
+    float nqsum[NG];        // per scale group: the group's scores are rescaled separately
+#pragma unroll
+    for (int n = 0; n < NG; n++) nqsum[n] = -1152.0f * qsum[n];
+    const float scale2 = scale * 1.44269504f;     // scores are kept times log2(e)
+    if constexpr (FUSED) {      // the q rows are in registers: the ring may be written from here on
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     // m_run is the running maximum minus 6 (scores are base-2 logarithms): weights are 2^(s - m_run) <= 64, which
     // keeps the binary16 parts of small weights out of the subnormal range; numerator and denominator carry
@@ -491,7 +524,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     // all lanes.  A stage is rewritten by the requests issued after its consumer, whose LDS reads have
     // completed by then (the consumer waited for them).
     if (blk_first < blk_last) {
-        KRegs kr[DC_STAGES];
         int blk = blk_first;
         const int mine = blk_last - blk;      // blocks of this wave
         auto compute = [&](int bk, int stage, KRegs& k) __attribute__((always_inline)) {
@@ -499,10 +531,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             else compute_block(std::false_type{}, bk, stage, k);
         };
         constexpr int OPS_PER_BLOCK = 2 * KL + NDMA + 2;   // vector-memory operations of one block's requests
+        static_assert(DC_STAGES == 2, "the early request covers exactly the blocks requested ahead of the loop");
+        if constexpr (!early) {
 #pragma unroll
-        for (int u = 0; u < DC_STAGES - 1; u++) {
-            issue_k(blk + u, kr[u]);
-            issue_v(blk + u, u);
+            for (int u = 0; u < DC_STAGES - 1; u++) {
+                issue_k(blk + u, kr[u]);
+                issue_v(blk + u, u);
+            }
         }
         for (int it = 0; it < mine; it += DC_STAGES) {
 #pragma unroll
@@ -517,6 +552,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last, empty requests still write this wave's LDS
+    } else if constexpr (early) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the early requests of a wave without blocks
     }
 
     // ---- this wave's state -> LDS (the ring is idle now), then the workgroup's merge
