@@ -25,6 +25,7 @@ scaling.  The same JSON line carries
                    decode attention over the INT8 KV cache.
 """
 import argparse
+import threading
 import subprocess
 import json
 import os
@@ -213,6 +214,9 @@ def spawn_ranks(args):
     return subprocess.run(cmd).returncode
 
 
+EXTRAS_LIMIT_S = 420     # several ranks: time the additions to the headline may take before the run ends itself
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -362,25 +366,8 @@ def main():
               "us_per_launch": round(ms * 1e3, 2), "GBps": round(kbytes / (ms * 1e-3) / 1e9, 1),
               "frac_hbm": round(kbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "bytes_per_launch": kbytes}
 
-    extra = {}
-    if not args.no_extra and rank == 0 and world == 1:   # the secondary table is a single-GPU measurement
-        extra = extra_table(H, gen, big)
+    line = None
     if rank == 0:
-        extra = dict(extra, single_launch_8192=single)
-        gi = greedy_identity_summary()
-        if gi is not None:
-            extra["greedy_identity"] = gi
-    if world > 1 and not args.no_extra:
-        sd = sharded_decode(H, gen, world)
-        ns = nsplit_8b(H, world, rank)
-        if rank == 0:
-            extra = dict(extra, sharded_decode=sd, nsplit_8b=ns)
-
-    if rank == 0:
-        cpu = None
-        if world == 1 and not args.no_cpu:
-            cpu = cpu_baseline([(acts[K].cpu().numpy(), sets[0][(K, N)][0].cpu().numpy(), sets[0][(K, N)][1].cpu().numpy())
-                                for K, N in order])
         line = {
             "metric": "quant_gemv_hbm_throughput", "value": round(value, 1), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -396,14 +383,66 @@ def main():
                        "parallelism": f"replicas x{world} (independent sequences)"},
             "roofline": roofline,
         }
-        if cpu is not None:
-            line["cpu_baseline"] = cpu
-        if extra:
-            line["extra"] = extra
-        print(json.dumps(line))
+
+    # The headline is measured; what follows only adds to the line.  With several ranks the additions run code whose
+    # collectives involve every rank (RCCL through the library's own communicator): if a rank fails there the others
+    # would wait for it for ever, so every rank arms a watchdog that ends the run cleanly -- rank 0 prints the line with
+    # what it has -- once the additions have taken longer than EXTRAS_LIMIT_S.
+    printed = threading.Event()
+    emit_lock = threading.Lock()
+
+    def emit(note=None):
+        with emit_lock:
+            if rank == 0 and not printed.is_set():
+                if note:
+                    line.setdefault("extra", {})["multi_gpu_extras"] = note
+                print(json.dumps(line), flush=True)
+                printed.set()
+
+    watchdog = None
+    if world > 1:
+        def expire():
+            emit(f"not finished after {EXTRAS_LIMIT_S} s: the run was ended by its watchdog")
+            os._exit(0)
+        watchdog = threading.Timer(EXTRAS_LIMIT_S, expire)
+        watchdog.daemon = True
+        watchdog.start()
+
+    extra = {}
+    if not args.no_extra and rank == 0 and world == 1:   # the secondary table is a single-GPU measurement
+        extra = extra_table(H, gen, big)
+    if rank == 0:
+        extra = dict(extra, single_launch_8192=single)
+        gi = greedy_identity_summary()
+        if gi is not None:
+            extra["greedy_identity"] = gi
+        line["extra"] = extra
+    if world > 1 and not args.no_extra:
+        try:
+            sd = sharded_decode(H, gen, world)
+            if rank == 0:
+                line["extra"]["sharded_decode"] = sd
+            ns = nsplit_8b(H, world, rank)
+            if rank == 0:
+                line["extra"]["nsplit_8b"] = ns
+        except Exception as e:     # the other ranks may now wait in a collective: the watchdogs end the run
+            print(f"[bench] rank {rank}: multi-GPU extras failed: {e!r}", file=sys.stderr, flush=True)
+            if rank == 0:
+                line["extra"]["multi_gpu_extras"] = f"failed on rank 0: {e!r}"
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline([(acts[K].cpu().numpy(), sets[0][(K, N)][0].cpu().numpy(),
+                                                  sets[0][(K, N)][1].cpu().numpy()) for K, N in order])
+            line["extra"] = line.pop("extra")      # keep the order of the keys: extra last
+        emit()
     if world > 1:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception as e:
+            print(f"[bench] rank {rank}: destroy_process_group: {e!r}", file=sys.stderr, flush=True)
+        watchdog.cancel()
 
 
 def sharded_decode(H, gen, world):
