@@ -241,6 +241,24 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // q and k rows of up to 256 dims: the norm weights of the lane's elements and the rotation factors of its pairs
+    // are requested together with the row, not behind the reduction and the barrier (three dependent round trips
+    // otherwise)
+    const int half_dim = D / 2;
+    int s = (int)(token % seq_len);
+    if (ap.positions) s = max(0, min(ap.positions[token / seq_len] + s, ap.max_position));
+    const bool pre = vecD && D <= 256 && !is_v;
+    uint16_t wreg[16], creg[8], sreg[8];
+    if (pre) {
+        const uint16_t* w = is_q ? qw : kw;
+#pragma unroll
+        for (int j = 0; j < 16; j++) wreg[j] = w[min(l + 16 * j, D - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            creg[j] = cos_t[(size_t)s * half_dim + min(l + 16 * j, half_dim - 1)];
+            sreg[j] = sin_t[(size_t)s * half_dim + min(l + 16 * j, half_dim - 1)];
+        }
+    }
     if (is_v) {   // a v row goes straight to the quantizer
         const uint16_t* vr = ap.v + hr * D;
         if (vecD) {
@@ -258,7 +276,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
             wave_sync();
             const float inv = row_inv_rms([&](int i) -> uint16_t { return nrm[i]; }, D, eps, l, base);
             const h16 inv_h = (h16)inv;
-            for (int i = l; i < D; i += 16) nrm[i] = rms_out(nrm[i], w[i], inv, inv_h, true);   // in place: own elements
+            if (pre) {
+#pragma unroll
+                for (int j = 0; j < 16; j++)
+                    if (l + 16 * j < D) nrm[l + 16 * j] = rms_out(nrm[l + 16 * j], wreg[j], inv, inv_h, true);
+            } else {
+                for (int i = l; i < D; i += 16) nrm[i] = rms_out(nrm[i], w[i], inv, inv_h, true);   // in place: own elements
+            }
         } else {
             const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, D, eps, l, base);
             const h16 inv_h = (h16)inv;
@@ -271,11 +295,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
         if (place) quant_row_groups(nrm, D, ap.gs, ap.vc + doff, ap.vs + soff, l);
         return;
     }
-    const int half_dim = D / 2;
-    int s = (int)(token % seq_len);
-    if (ap.positions) s = max(0, min(ap.positions[token / seq_len] + s, ap.max_position));
-    for (int i = l; i < half_dim; i += 16) {
-        const uint16_t cb = cos_t[(size_t)s * half_dim + i], sb = sin_t[(size_t)s * half_dim + i];
+    auto rotate = [&](int i, uint16_t cb, uint16_t sb) {
         const uint16_t x1b = nrm[i], x2b = nrm[half_dim + i];
         uint16_t o1, o2;
         if (i < (half_dim & ~7)) {
@@ -294,6 +314,13 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
             orow[half_dim + i] = o2;
         }
         if (place || vecD) { nrm[i] = o1; nrm[half_dim + i] = o2; }   // the lane's own two elements: the rotated row
+    };
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (l + 16 * j < half_dim) rotate(l + 16 * j, creg[j], sreg[j]);
+    } else {
+        for (int i = l; i < half_dim; i += 16) rotate(i, cos_t[(size_t)s * half_dim + i], sin_t[(size_t)s * half_dim + i]);
     }
     if (place || vecD) wave_sync();
     if (vecD) {
@@ -373,6 +400,9 @@ __global__ __launch_bounds__(256) void row_quant_kernel(const uint16_t* __restri
         return x;
     };
     if (MODE == 0) {
+        // the norm weights of the thread's first piece are requested with the row itself, not behind the reduction
+        v4i w_first = {0, 0, 0, 0};
+        if (vec && t < nch) w_first = *reinterpret_cast<const v4i*>(w + t * 8);
         if (vec) {
             for (int c = t; c < nch; c += 256) {
                 v4i xv = *reinterpret_cast<const v4i*>(a + off + c * 8);
@@ -405,7 +435,7 @@ __global__ __launch_bounds__(256) void row_quant_kernel(const uint16_t* __restri
         if (vec) {
             for (int c = t; c < nch; c += 256) {
                 const v4i xv = *reinterpret_cast<const v4i*>(xin + c * 8);
-                const v4i wv = *reinterpret_cast<const v4i*>(w + c * 8);
+                const v4i wv = c == t ? w_first : *reinterpret_cast<const v4i*>(w + c * 8);
                 uint16_t y[8];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
