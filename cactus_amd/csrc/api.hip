@@ -62,6 +62,11 @@ struct Workspace {
 };
 std::mutex g_ws_mu;
 std::unordered_map<int, Workspace> g_ws;
+// Calls enqueued on one stream follow one another, so they can share one workspace.  A host that enqueues on two streams
+// at once (the step driver's two half-batches) names a lane per stream while it enqueues for it: every lane has its own
+// buffer.  The lane is a property of the enqueueing thread.
+constexpr int WS_LANES = 2;
+thread_local int g_ws_lane = 0;
 
 int workspace(size_t bytes, void** out) {
     *out = nullptr;
@@ -69,7 +74,7 @@ int workspace(size_t bytes, void** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    Workspace& w = g_ws[dev];
+    Workspace& w = g_ws[dev * WS_LANES + g_ws_lane];
     if (w.bytes < bytes) {
         const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes + bytes / 2;
         void* np = nullptr;
@@ -85,6 +90,12 @@ int workspace(size_t bytes, void** out) {
 }  // namespace
 namespace cactus_hip {
 int workspace_for_comm(size_t bytes, void** out) { return workspace(bytes, out); }   // comm.hip's staging slots
+// the workspace lane (0 or 1) of the calls this thread enqueues from now on; returns the previous one
+int workspace_lane(int lane) {
+    const int prev = g_ws_lane;
+    g_ws_lane = lane < 0 ? 0 : (lane >= WS_LANES ? WS_LANES - 1 : lane);
+    return prev;
+}
 }  // namespace cactus_hip
 namespace {
 
@@ -303,7 +314,14 @@ int cactus_hip_synchronize(void* stream) {
 
 int cactus_hip_workspace_reserve(size_t bytes) {
     void* ws = nullptr;
-    return workspace(bytes, &ws);
+    const int lane = cactus_hip::workspace_lane(0);
+    int rc = CACTUS_HIP_OK;
+    for (int l = 0; l < WS_LANES && rc == CACTUS_HIP_OK; l++) {   // every lane: a captured step may use both
+        cactus_hip::workspace_lane(l);
+        rc = workspace(bytes, &ws);
+    }
+    cactus_hip::workspace_lane(lane);
+    return rc;
 }
 
 int cactus_hip_weights_pack_dev(const void* B, size_t N, size_t K, int kind, void* stream) {

@@ -653,7 +653,10 @@ Plan make_plan(const AttnArgs& a) {
     // enough workgroups to fill the chip (about 2048 of 4 waves), but at least one 32-key block per wave;
     // at most 256 splits (the merge kernel keeps one factor per split in LDS).  The matrix-core kernel's
     // units are single waves: about 1024 of them (one per SIMD) stream fastest, each with two blocks or more.
-    const size_t target = pl.mfma ? 1024 : 2048;
+#ifndef AT_MFMA_TARGET
+#define AT_MFMA_TARGET 1024
+#endif
+    const size_t target = pl.mfma ? AT_MFMA_TARGET : 2048;
     size_t ns = pl.items ? (target + pl.items - 1) / pl.items : 1;
     const size_t per_unit = pl.mfma ? 2 : AT_WAVES;     // blocks a unit should at least have
     const size_t cap = maxblk / per_unit ? maxblk / per_unit : 1;

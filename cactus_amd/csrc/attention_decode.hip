@@ -46,7 +46,10 @@ namespace cactus_hip {
 namespace {
 
 constexpr int DC_BLOCK = 32;     // keys per block
-constexpr int DC_STAGES = 2;     // LDS stages and K register sets per wave: DC_STAGES - 1 blocks in flight
+#ifndef DC_STAGES_N
+#define DC_STAGES_N 2
+#endif
+constexpr int DC_STAGES = DC_STAGES_N;     // LDS stages and K register sets per wave: DC_STAGES - 1 blocks in flight
 constexpr int DC_MAX_NEW = 8;    // FP16 tokens of the step itself (decode: 1)
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 
     uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
     uint16_t* kn_lds = reinterpret_cast<uint16_t*>(lds + RING) + (FUSED ? w * D : 0);
-    uint8_t* rows_lds = ROWS_OWN ? lds + RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0) + w * ROWS_OWN : my_lds + STAGE;
+    uint8_t* rows_lds = ROWS_OWN ? lds + RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0) + w * ROWS_OWN : my_lds + (DC_STAGES - 1) * STAGE;
     struct KRegs { v4i k[2][KL]; };
     // per-lane pieces of the addresses
     constexpr int ROW_CHUNKS = D / 16;                               // 16-byte chunks of a row
@@ -240,13 +243,16 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     KRegs kr[DC_STAGES];
     // FUSED: the first block of the wave's range is requested before the wave turns to its rows (whose loads, tables
     // and arithmetic would otherwise all precede the first byte of the cache stream); the rows then sit in the ring's
-    // second stage, which the requests of the second block overwrite once the q rows are in registers
+    // last stage, which later requests overwrite once the q rows are in registers
     // (head_dim 256: up to 18 rows of 512 bytes do not fit a stage and have an area of their own).  The requests are
     // unconditional like all others: a wave without blocks reads nothing.
     constexpr bool early = FUSED;
     if constexpr (early) {
-        issue_k(blk_first, kr[0]);
-        issue_v(blk_first, 0);
+#pragma unroll
+        for (int u = 0; u < DC_STAGES - 1; u++) {
+            issue_k(blk_first + u, kr[u]);
+            issue_v(blk_first + u, u);
+        }
     }
     if constexpr (FUSED) {
         // rows of this wave, 16 lanes each, four at a time: its query heads, its key, and (key range 0) its value;
@@ -531,7 +537,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             else compute_block(std::false_type{}, bk, stage, k);
         };
         constexpr int OPS_PER_BLOCK = 2 * KL + NDMA + 2;   // vector-memory operations of one block's requests
-        static_assert(DC_STAGES == 2, "the early request covers exactly the blocks requested ahead of the loop");
         if constexpr (!early) {
 #pragma unroll
             for (int u = 0; u < DC_STAGES - 1; u++) {

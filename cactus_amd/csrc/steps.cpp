@@ -3,12 +3,18 @@
 // Model::decode / Model::prefill, engine_model.cpp:170-297), for batches of independent sequences.
 #include "../../include/cactus_hip_steps.h"
 
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 namespace cactus_hip {
 void set_last_error(const char* msg);
+int workspace_lane(int lane);
 }
 
 namespace {
@@ -146,12 +152,85 @@ size_t carve_decode(const cactus_hip_decoder_weights* w, size_t b, void* base, D
     return c.used;
 }
 
+// the rows [r0, ...) of every buffer
+DecodeBuffers rows_from(const cactus_hip_decoder_weights* w, const DecodeBuffers& d, size_t r0) {
+    const size_t Hd = w->hidden, QD = w->q_heads * w->head_dim, KD = w->kv_heads * w->head_dim, F = w->ffn;
+    DecodeBuffers v = d;
+    v.h0 += r0 * Hd; v.hid += r0 * Hd; v.x += r0 * Hd; v.h2 += r0 * Hd;
+    v.qo += r0 * QD; v.ko += r0 * KD; v.vo += r0 * KD; v.qr += r0 * QD; v.kr += r0 * KD; v.ao += r0 * QD;
+    v.oo += r0 * Hd; v.go += r0 * F; v.uo += r0 * F; v.dn += r0 * Hd; v.ipj += r0 * 3 * Hd;
+    v.xq += r0 * Hd; v.xq2 += r0 * Hd; v.aq += r0 * F; v.oq += r0 * QD; v.cq += r0 * Hd;
+    v.xs += r0; v.xs2 += r0; v.as += r0; v.os += r0; v.cs += r0;
+    return v;
+}
+
+// Two half-batches in step (see cactus_hip_decode_step_dev): the second half's stream and the events that order the
+// halves' attention launches, one set per device, made on first use and kept.
+struct StepPipeline {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    std::vector<hipEvent_t> a_done, b_done;     // per attention layer
+};
+std::mutex g_pipe_mu;
+StepPipeline g_pipe[64];
+
+StepPipeline* step_pipeline(size_t attention_layers) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    StepPipeline& p = g_pipe[dev];
+    if (!p.side) {
+        if (hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking) != hipSuccess) { p.side = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p.join, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+    }
+    if (!p.fork || !p.join) return nullptr;
+    while (p.a_done.size() < attention_layers) {
+        hipEvent_t ea = nullptr, eb = nullptr;
+        if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess)
+            return nullptr;
+        p.a_done.push_back(ea);
+        p.b_done.push_back(eb);
+    }
+    return &p;
+}
+
+// Batches from this size on are run as two half-batches (0: never, the default: on the shapes measured a half-batch's
+// attention, 128 workgroups of 8 waves, streams its cache at 3.2 - 3.7 TB/s against 4.5 - 5.4 TB/s for the whole batch,
+// which costs more than hiding the other half's matmuls returns).  CACTUS_HIP_STEP_SPLIT sets the initial value.
+size_t& step_split_value() {
+    static size_t t = [] {
+        const char* e = std::getenv("CACTUS_HIP_STEP_SPLIT");
+        return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)0;
+    }();
+    return t;
+}
+size_t step_split_threshold() { return step_split_value(); }
+
+#define HIP_STEP_TRY(expr)                                        \
+    do {                                                          \
+        if ((expr) != hipSuccess) return fail("decode step: stream / event call failed"); \
+    } while (0)
+
 }  // namespace
 
 extern "C" {
 
+size_t cactus_hip_decode_step_split(size_t min_batch) {
+    const size_t prev = step_split_value();
+    step_split_value() = min_batch;
+    return prev;
+}
+
 size_t cactus_hip_decode_step_workspace_bytes(const cactus_hip_decoder_weights* w, size_t batch) {
     if (!w || batch == 0) return 0;
+    if (w->blocks && step_split_threshold() && batch >= step_split_threshold()) {   // outside any stream capture
+        size_t n_attn = 0;
+        for (size_t i = 0; i < w->layers; i++) n_attn += w->blocks[i].kind == 0;
+        step_pipeline(n_attn);
+    }
     return carve_decode(w, batch, nullptr, nullptr);
 }
 
@@ -180,84 +259,159 @@ int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus
 
     STEP_TRY(cactus_hip_embedding_int8_dev(static_cast<const int8_t*>(w->embedding.B), w->embedding.scales, kv->tokens, d.h0, b,
                                            V, Hd, 128, nullptr, stream));
-    if (!small)
+    if (!small) {
         STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h0, nullptr, w->blocks[0].in_norm, nullptr, nullptr, d.xq, d.xs, b, Hd,
                                                        w->eps, stream));
-    const half_t* res = d.h0;
-    size_t ai = 0, ci = 0;
-    for (size_t li = 0; li < NL; li++) {
-        const cactus_hip_block_weights& L = w->blocks[li];
-        if (L.kind == 0) {
-            const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
-            if (small) {
-                // residual add of the previous block + this block's input norm + q/k/v, one launch per precision
-                if (li == 0) STEP_TRY(produced_matmuls(1, d.h0, nullptr, L.in_norm, nullptr, w->eps, qkv, 3, b, Hd, stream));
-                else STEP_TRY(produced_matmuls(1, d.h2, d.dn, L.in_norm, d.hid, w->eps, qkv, 3, b, Hd, stream));
-                if (li) res = d.hid;
-            } else {
-                STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, b, Hd, stream));     // rows quantized by the launch that produced them
-            }
-            int8_t* kc = kv->k_cache + ai * b * cbs;
-            int8_t* vc = kv->v_cache + ai * b * cbs;
-            float* ks = kv->k_scales + ai * b * sbs;
-            float* vs = kv->v_scales + ai * b * sbs;
-            ai++;
-            // q/k norm + RoPE at each sequence's position.  Without a window the new token's K and V join the cache in
-            // the same launch as the attention; with a window they are appended after the attention, which must still
-            // see the token a full window is about to drop.
-            if (fused_attention) {
-                if (o_quant)
-                    STEP_TRY(cactus_hip_attention_decode_fused_quant_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs, d.ao,
-                                                                            d.oq, d.os, b, kv->cache_lens, kv->positions,
-                                                                            kv->max_position, Hq, Hkv, D, w->eps, w->theta, 0.0f, 128,
-                                                                            cbs, sbs, kv->slots, kv->slots, stream));
-                else
-                    STEP_TRY(cactus_hip_attention_decode_fused_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs, d.ao, b,
-                                                                      kv->cache_lens, kv->positions, kv->max_position, Hq, Hkv, D,
-                                                                      w->eps, w->theta, 0.0f, 128, cbs, sbs, kv->slots, kv->slots,
-                                                                      stream));
-            } else {
-                const bool app = fused_append;
-                STEP_TRY(cactus_hip_qk_norm_rope_seq_f16_dev(d.qo, d.ko, app ? d.vo : nullptr, L.q_norm, L.k_norm, d.qr, d.kr,
-                                                            app ? kc : nullptr, app ? vc : nullptr, app ? ks : nullptr,
-                                                            app ? vs : nullptr, kv->positions, kv->max_position, b, 1, Hq, Hkv, D,
-                                                            w->eps, w->theta, 128, app ? cbs : 0, app ? sbs : 0,
-                                                            app ? kv->slots : 0, 0, 0, stream));
-                STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_batched_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, b, 1, kv->cache_lens, 1,
-                                                                          Hq, Hkv, D, 0.0f, kv->positions, 128, cbs, sbs, kv->slots,
-                                                                          stream));
-            }
-            if (!fused_append)
-                STEP_TRY(cactus_hip_kv_append_windowed_dev(d.kr, d.vo, kc, vc, ks, vs, kv->positions, b, 1, Hkv, D, 128, cbs, sbs,
-                                                          kv->slots, kv->window, kv->sink, stream));
-            if (o_quant) STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, b, stream));
-            else STEP_TRY(matmul_f16act(d.ao, L.o, d.oo, b, stream));
-        } else {
-            // LFM2 short convolution: in-projection; B * X, convolution over the carried rows, C gate, state update and
-            // the out-projection's row quantization in one launch; out-projection
-            half_t* state = kv->conv_state + ci * b * w->conv_rows * Hd;
-            ci++;
-            STEP_TRY(matmul_q(d.xq, d.xs, L.in_proj, d.ipj, b, stream));
-            STEP_TRY(cactus_hip_lfm2_conv_gate_quant_f16_dev(d.ipj, L.conv_weight, state, nullptr, d.cq, d.cs, b, 1, Hd, w->conv_taps,
-                                                            w->conv_rows, stream));
-            STEP_TRY(matmul_q(d.cq, d.cs, L.out_proj, d.oo, b, stream));
+        // Large batches run as two half-batches on two streams, their attention launches taking turns (A0 B0 A1 B1 ...):
+        // a half's attention streams the KV cache (HBM-bound) while the other half runs its matmuls, norms and
+        // activations (short launches, latency-bound, few bytes), instead of the two kinds of work alternating on an
+        // otherwise idle chip.  Rows are independent, so every result is what the single stream gives.  The second
+        // stream forks from and joins the caller's, so a stream capture of the caller's takes in both.
+        StepPipeline* pipe = nullptr;
+        if (step_split_threshold() && b >= step_split_threshold() && b >= 2) pipe = step_pipeline(n_attn);
+        const int nh = pipe ? 2 : 1;
+        struct Half { size_t r0, n; DecodeBuffers d; void* stream; const half_t* res; };
+        Half hv[2];
+        const size_t b0 = nh == 2 ? ((b / 2 + 15) / 16) * 16 : b;     // whole 16-row tiles in the first half
+        hv[0] = Half{0, nh == 2 ? (b0 < b ? b0 : b / 2) : b, d, stream, d.h0};
+        if (nh == 2) {
+            hv[1] = Half{hv[0].n, b - hv[0].n, rows_from(w, d, hv[0].n), pipe->side, d.h0 + hv[0].n * Hd};
+            HIP_STEP_TRY(hipEventRecord(pipe->fork, static_cast<hipStream_t>(stream)));
+            HIP_STEP_TRY(hipStreamWaitEvent(pipe->side, pipe->fork, 0));
         }
-        const half_t* nxt = li + 1 < NL ? w->blocks[li + 1].in_norm : w->final_norm;
-        const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
-        if (small) {
-            STEP_TRY(produced_matmuls(1, res, d.oo, L.post_norm, d.h2, w->eps, gu, 2, b, Hd, stream));   // add + norm + gate/up
-            const Out dn[1] = {{&L.down, d.dn}};
-            STEP_TRY(produced_matmuls(2, d.go, d.uo, nullptr, nullptr, 0.0f, dn, 1, b, F, stream));        // silu x up + down
-        } else {   // norm / activation launches that also quantize the next matmul's input rows
-            STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, b, Hd, w->eps, stream));
-            STEP_TRY(shared_matmuls(d.xq2, d.xs2, gu, 2, b, Hd, stream));
-            STEP_TRY(cactus_hip_silu_multiply_quant_f16_dev(d.go, d.uo, nullptr, d.aq, d.as, b, F, stream));
-            STEP_TRY(matmul_q(d.aq, d.as, L.down, d.dn, b, stream));
+        struct LaneGuard {     // the second half's calls use the library workspace's second lane
+            int prev;
+            explicit LaneGuard(int lane) : prev(cactus_hip::workspace_lane(lane)) {}
+            ~LaneGuard() { cactus_hip::workspace_lane(prev); }
+        };
+        size_t ai = 0, ci = 0;
+        for (size_t li = 0; li < NL; li++) {
+            const cactus_hip_block_weights& L = w->blocks[li];
+            const half_t* nxt = li + 1 < NL ? w->blocks[li + 1].in_norm : w->final_norm;
             const bool last = li + 1 == NL;     // the lm_head below takes the FP16 row
-            STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h2, d.dn, nxt, d.hid, last ? d.x : nullptr, d.xq, d.xs, b, Hd, w->eps,
-                                                           stream));
-            res = d.hid;
+            if (L.kind == 0) {
+                for (int h = 0; h < nh; h++) {
+                    LaneGuard lg(h);
+                    Half& H = hv[h];
+                    const Out qkv[3] = {{&L.q, H.d.qo}, {&L.k, H.d.ko}, {&L.v, H.d.vo}};
+                    STEP_TRY(shared_matmuls(H.d.xq, H.d.xs, qkv, 3, H.n, Hd, H.stream));   // rows quantized by the launch that produced them
+                }
+                for (int h = 0; h < nh; h++) {
+                    LaneGuard lg(h);
+                    Half& H = hv[h];
+                    int8_t* kc = kv->k_cache + (ai * b + H.r0) * cbs;
+                    int8_t* vc = kv->v_cache + (ai * b + H.r0) * cbs;
+                    float* ks = kv->k_scales + (ai * b + H.r0) * sbs;
+                    float* vs = kv->v_scales + (ai * b + H.r0) * sbs;
+                    const int32_t* lens = kv->cache_lens + H.r0;
+                    const int32_t* pos = kv->positions + H.r0;
+                    hipStream_t hs = static_cast<hipStream_t>(H.stream);
+                    if (nh == 2) {       // A(i) after B(i - 1), B(i) after A(i)
+                        if (h == 0 && ai > 0) HIP_STEP_TRY(hipStreamWaitEvent(hs, pipe->b_done[ai - 1], 0));
+                        if (h == 1) HIP_STEP_TRY(hipStreamWaitEvent(hs, pipe->a_done[ai], 0));
+                    }
+                    // q/k norm + RoPE at each sequence's position.  Without a window the new token's K and V join the
+                    // cache in the same launch as the attention; with a window they are appended after the attention,
+                    // which must still see the token a full window is about to drop.
+                    if (fused_attention) {
+                        if (o_quant)
+                            STEP_TRY(cactus_hip_attention_decode_fused_quant_f16_dev(H.d.qo, H.d.ko, H.d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs,
+                                                                                    H.d.ao, H.d.oq, H.d.os, H.n, lens, pos, kv->max_position, Hq,
+                                                                                    Hkv, D, w->eps, w->theta, 0.0f, 128, cbs, sbs, kv->slots,
+                                                                                    kv->slots, H.stream));
+                        else
+                            STEP_TRY(cactus_hip_attention_decode_fused_f16_dev(H.d.qo, H.d.ko, H.d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs, H.d.ao,
+                                                                              H.n, lens, pos, kv->max_position, Hq, Hkv, D, w->eps, w->theta,
+                                                                              0.0f, 128, cbs, sbs, kv->slots, kv->slots, H.stream));
+                    } else {
+                        const bool app = fused_append;
+                        STEP_TRY(cactus_hip_qk_norm_rope_seq_f16_dev(H.d.qo, H.d.ko, app ? H.d.vo : nullptr, L.q_norm, L.k_norm, H.d.qr, H.d.kr,
+                                                                    app ? kc : nullptr, app ? vc : nullptr, app ? ks : nullptr,
+                                                                    app ? vs : nullptr, pos, kv->max_position, H.n, 1, Hq, Hkv, D, w->eps,
+                                                                    w->theta, 128, app ? cbs : 0, app ? sbs : 0, app ? kv->slots : 0, 0, 0,
+                                                                    H.stream));
+                        STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_batched_dev(H.d.qr, kc, vc, ks, vs, H.d.kr, H.d.vo, H.d.ao, H.n, 1, lens, 1,
+                                                                                  Hq, Hkv, D, 0.0f, pos, 128, cbs, sbs, kv->slots, H.stream));
+                    }
+                    if (nh == 2) HIP_STEP_TRY(hipEventRecord(h == 0 ? pipe->a_done[ai] : pipe->b_done[ai], hs));
+                    if (!fused_append)
+                        STEP_TRY(cactus_hip_kv_append_windowed_dev(H.d.kr, H.d.vo, kc, vc, ks, vs, pos, H.n, 1, Hkv, D, 128, cbs, sbs,
+                                                                  kv->slots, kv->window, kv->sink, H.stream));
+                    if (o_quant) STEP_TRY(matmul_q(H.d.oq, H.d.os, L.o, H.d.oo, H.n, H.stream));
+                    else STEP_TRY(matmul_f16act(H.d.ao, L.o, H.d.oo, H.n, H.stream));
+                }
+                ai++;
+            } else {
+                // LFM2 short convolution: in-projection; B * X, convolution over the carried rows, C gate, state update
+                // and the out-projection's row quantization in one launch; out-projection
+                for (int h = 0; h < nh; h++) {
+                    LaneGuard lg(h);
+                    Half& H = hv[h];
+                    half_t* state = kv->conv_state + (ci * b + H.r0) * w->conv_rows * Hd;
+                    STEP_TRY(matmul_q(H.d.xq, H.d.xs, L.in_proj, H.d.ipj, H.n, H.stream));
+                    STEP_TRY(cactus_hip_lfm2_conv_gate_quant_f16_dev(H.d.ipj, L.conv_weight, state, nullptr, H.d.cq, H.d.cs, H.n, 1, Hd,
+                                                                    w->conv_taps, w->conv_rows, H.stream));
+                    STEP_TRY(matmul_q(H.d.cq, H.d.cs, L.out_proj, H.d.oo, H.n, H.stream));
+                }
+                ci++;
+            }
+            for (int h = 0; h < nh; h++) {   // norm / activation launches that also quantize the next matmul's input rows
+                LaneGuard lg(h);
+                Half& H = hv[h];
+                const Out gu[2] = {{&L.gate, H.d.go}, {&L.up, H.d.uo}};
+                STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(H.res, H.d.oo, L.post_norm, H.d.h2, nullptr, H.d.xq2, H.d.xs2, H.n, Hd, w->eps,
+                                                               H.stream));
+                STEP_TRY(shared_matmuls(H.d.xq2, H.d.xs2, gu, 2, H.n, Hd, H.stream));
+                STEP_TRY(cactus_hip_silu_multiply_quant_f16_dev(H.d.go, H.d.uo, nullptr, H.d.aq, H.d.as, H.n, F, H.stream));
+                STEP_TRY(matmul_q(H.d.aq, H.d.as, L.down, H.d.dn, H.n, H.stream));
+                STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(H.d.h2, H.d.dn, nxt, H.d.hid, last ? H.d.x : nullptr, H.d.xq, H.d.xs, H.n, Hd,
+                                                               w->eps, H.stream));
+                H.res = H.d.hid;
+            }
         }
+        if (nh == 2) {
+            HIP_STEP_TRY(hipEventRecord(pipe->join, pipe->side));
+            HIP_STEP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), pipe->join, 0));
+        }
+    }
+    const half_t* res = d.h0;
+    size_t ai = 0;
+    for (size_t li = 0; small && li < NL; li++) {
+        const cactus_hip_block_weights& L = w->blocks[li];
+        const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
+        // residual add of the previous block + this block's input norm + q/k/v, one launch per precision
+        if (li == 0) STEP_TRY(produced_matmuls(1, d.h0, nullptr, L.in_norm, nullptr, w->eps, qkv, 3, b, Hd, stream));
+        else STEP_TRY(produced_matmuls(1, d.h2, d.dn, L.in_norm, d.hid, w->eps, qkv, 3, b, Hd, stream));
+        if (li) res = d.hid;
+        int8_t* kc = kv->k_cache + ai * b * cbs;
+        int8_t* vc = kv->v_cache + ai * b * cbs;
+        float* ks = kv->k_scales + ai * b * sbs;
+        float* vs = kv->v_scales + ai * b * sbs;
+        ai++;
+        if (fused_attention) {
+            STEP_TRY(cactus_hip_attention_decode_fused_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, kc, vc, ks, vs, d.ao, b,
+                                                              kv->cache_lens, kv->positions, kv->max_position, Hq, Hkv, D,
+                                                              w->eps, w->theta, 0.0f, 128, cbs, sbs, kv->slots, kv->slots,
+                                                              stream));
+        } else {
+            const bool app = fused_append;
+            STEP_TRY(cactus_hip_qk_norm_rope_seq_f16_dev(d.qo, d.ko, app ? d.vo : nullptr, L.q_norm, L.k_norm, d.qr, d.kr,
+                                                        app ? kc : nullptr, app ? vc : nullptr, app ? ks : nullptr,
+                                                        app ? vs : nullptr, kv->positions, kv->max_position, b, 1, Hq, Hkv, D,
+                                                        w->eps, w->theta, 128, app ? cbs : 0, app ? sbs : 0,
+                                                        app ? kv->slots : 0, 0, 0, stream));
+            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_batched_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, b, 1, kv->cache_lens, 1,
+                                                                      Hq, Hkv, D, 0.0f, kv->positions, 128, cbs, sbs, kv->slots,
+                                                                      stream));
+        }
+        if (!fused_append)
+            STEP_TRY(cactus_hip_kv_append_windowed_dev(d.kr, d.vo, kc, vc, ks, vs, kv->positions, b, 1, Hkv, D, 128, cbs, sbs,
+                                                      kv->slots, kv->window, kv->sink, stream));
+        STEP_TRY(matmul_f16act(d.ao, L.o, d.oo, b, stream));
+        const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
+        STEP_TRY(produced_matmuls(1, res, d.oo, L.post_norm, d.h2, w->eps, gu, 2, b, Hd, stream));   // add + norm + gate/up
+        const Out dn[1] = {{&L.down, d.dn}};
+        STEP_TRY(produced_matmuls(2, d.go, d.uo, nullptr, nullptr, 0.0f, dn, 1, b, F, stream));        // silu x up + down
     }
     if (small) {   // last residual add + final norm + lm_head
         const Out hd[1] = {{&head, logits}};

@@ -181,6 +181,8 @@ class _PrefillState(C.Structure):
 
 
 _lib = H.lib
+_lib.cactus_hip_decode_step_split.restype = C.c_size_t
+_lib.cactus_hip_decode_step_split.argtypes = [C.c_size_t]
 _lib.cactus_hip_decode_step_workspace_bytes.restype = C.c_size_t
 _lib.cactus_hip_decode_step_workspace_bytes.argtypes = [C.POINTER(_Weights), C.c_size_t]
 _lib.cactus_hip_decode_step_dev.restype = C.c_int
@@ -220,6 +222,11 @@ def describe_model(weights, cfg):
                  _qm(weights.get("head")), _vp(weights["final_norm"]))
     w._keep = (blocks, weights)
     return w
+
+
+def decode_step_split(min_batch):
+    """Smallest batch a decode step runs as two half-batches on two streams (0: never); returns the previous value."""
+    return int(_lib.cactus_hip_decode_step_split(int(min_batch)))
 
 
 class _DecodeStep:

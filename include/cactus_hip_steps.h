@@ -63,15 +63,28 @@ typedef struct cactus_hip_decode_state {
     cactus_half_t* conv_state;
 } cactus_hip_decode_state;
 
-/* Bytes of `workspace` (256-byte aligned device memory) a decode step of `batch` sequences needs. */
+/* Bytes of `workspace` (256-byte aligned device memory) a decode step of `batch` sequences needs.  Call it once
+ * outside any stream capture before capturing a step of that batch: it also creates the second stream and the events
+ * of the split step below. */
 size_t cactus_hip_decode_step_workspace_bytes(const cactus_hip_decoder_weights* w, size_t batch);
 
 /* One decode step: embedding lookup of state->tokens, every block, final norm, lm_head into logits half[batch, vocab],
  * greedy sampler back into state->tokens; advance != 0 also moves positions / cache_lens on by one token.
  * Batches of at most 4 sequences on an all-attention model run every matmul as a streaming launch that produces its
- * own input rows; larger ones quantize rows in the producing launch and use the tile kernel. */
+ * own input rows; larger ones quantize rows in the producing launch and use the tile kernel.
+ * Optional (off by default, see cactus_hip_decode_step_split): batches of at least that many sequences run the blocks
+ * as two half-batches, the second half on a stream of the library's own that forks from `stream` after the embedding
+ * and joins it before the lm_head (a capture of `stream` takes in both), the halves' attention launches taking turns,
+ * so that one half reads its KV cache while the other runs its matmuls.  Rows are independent: every result is the
+ * single stream's, bit for bit. */
 int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus_hip_decode_state* state,
                                void* workspace, cactus_half_t* logits, int advance, void* stream);
+
+/* Smallest batch that cactus_hip_decode_step_dev splits into two half-batches (0, the default: never split); returns
+ * the previous value.  The environment variable CACTUS_HIP_STEP_SPLIT sets the initial value.  No counterpart in the
+ * reference, which decodes one sequence.  Measured on MI355X (Qwen3-0.6B shape, 512 cached tokens): 256 sequences 3.03 ms
+ * unsplit, 3.22 ms split; LFM2-1.2B shape, 1024 sequences 3.60 / 3.55 ms. */
+size_t cactus_hip_decode_step_split(size_t min_batch);
 
 /* A chunked prefill of ONE sequence through an all-attention model, the way the engine walks a long prompt
  * (Model::prefill, engine_model.cpp:170-219): `chunk` tokens at a time, chunk 0 against nothing (FP16 attention), the

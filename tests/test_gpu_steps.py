@@ -503,3 +503,67 @@ def test_attention_decode_fused_quantized_rows(ST, B, Hq, Hkv, D, slots, lens):
     assert torch.equal(got_q, want_q)
     for a, b_ in ((kc, kc2), (vc, vc2), (ks, ks2), (vs, vs2)):
         assert torch.equal(a, b_)
+
+
+# ------------------------------------------------------------------ two half-batches on two streams
+def _run_free(ST, make, steps, split, graph):
+    """`steps` free-running decode steps of a freshly built step object; returns logits per step, final tokens, caches."""
+    prev = ST.decode_step_split(split)
+    try:
+        dec = make()
+        out = []
+        if graph:
+            dec.step()                       # sizes the library workspaces outside the capture
+            torch.cuda.synchronize()
+            dec = make()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                dec.step()
+            # the capture ran nothing: replay it `steps` times
+            for _ in range(steps):
+                g.replay()
+                torch.cuda.synchronize()
+                out.append(dec.logits.clone())
+                dec.kv.host_max_position += 1
+        else:
+            for _ in range(steps):
+                dec.step()
+                torch.cuda.synchronize()
+                out.append(dec.logits.clone())
+        state = [dec.kv.tok.clone(), dec.kv.kc.clone(), dec.kv.vc.clone(), dec.kv.ksc.clone(), dec.kv.vsc.clone(),
+                 dec.kv.positions.clone(), dec.kv.cache_lens.clone()]
+        if getattr(dec, "_conv", None) is not None:
+            state.append(dec._conv.clone())
+        return out, state
+    finally:
+        ST.decode_step_split(prev)
+
+
+@pytest.mark.parametrize("model,batch,window", [("qwen3", 150, 0), ("qwen3", 64, 0), ("qwen3", 37, 20), ("lfm2", 130, 0)])
+def test_split_decode_step_equals_the_single_stream_step(ST, model, batch, window):
+    """cactus_hip_decode_step_dev run as two half-batches on two streams (attention launches taking turns) gives, bit
+    for bit, the logits, tokens, caches, positions and convolution rows of the single-stream step: eagerly and as a
+    captured HIP graph; 4 free-running steps of cut-down models (every block kind, uneven halves, a ring window)."""
+    steps, slots = 4, 48
+
+    def make():
+        gen = torch.Generator(device="cuda").manual_seed(1234 + batch)
+        if model == "qwen3":
+            cfg = dict(ST.QWEN3_0P6B, layers=3, vocab=4096)
+            dec = ST.Qwen3Decode(ST.qwen3_synthetic_weights(gen, cfg), cfg, batch, slots, window=window, sink=4 if window else 0,
+                                 max_position=slots + 16, cache_gen=gen)
+        else:
+            cfg = dict(ST.LFM2_1P2B, layers=4, vocab=4096, attention_layers=(1, 3))
+            dec = ST.Lfm2Decode(ST.lfm2_synthetic_weights(gen, batch, cfg), cfg, batch, slots, max_position=slots + 16, cache_gen=gen)
+        lens = torch.randint(1, slots - steps - 1, (batch,), generator=torch.Generator().manual_seed(batch)).tolist()
+        dec.kv.set_positions(lens)
+        dec.kv.tok.copy_(torch.randint(0, cfg["vocab"], (batch,), dtype=torch.int32, device="cuda", generator=gen))
+        return dec
+
+    want_lg, want_st = _run_free(ST, make, steps, 0, False)
+    for graph in (False, True):
+        got_lg, got_st = _run_free(ST, make, steps, 2, graph)
+        for i, (a, b) in enumerate(zip(want_lg, got_lg)):
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (graph, i)
+        for i, (a, b) in enumerate(zip(want_st, got_st)):
+            assert torch.equal(a, b), (graph, "state", i)
