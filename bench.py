@@ -460,7 +460,7 @@ def sharded_decode(H, gen, world):
         print(f"sharded_decode: qwen3 step failed on a rank: {e}", file=sys.stderr)
     per_rank = max(1024 // world, 1)
     try:
-        ms[1] = lfm2_decode_step(H, gen, per_rank, 512)["ms_per_step"]
+        ms[1] = lfm2_decode_step(H, gen, per_rank, 512, mixed=True)["ms_per_step"]     # configs[3]: mixed precision
         torch.cuda.empty_cache()
     except Exception as e:
         print(f"sharded_decode: lfm2 step failed on a rank: {e}", file=sys.stderr)
@@ -472,7 +472,7 @@ def sharded_decode(H, gen, world):
         out["qwen3_0p6b_b256_per_gpu_c512"] = {"ms_per_step": round(q_ms, 4), "sequences": 256 * world,
                                                 "tokens_per_s": round(256 * world / (q_ms * 1e-3), 1)}
     if l_ms < 1e29:
-        out["lfm2_1p2b_1024_sequences_c512"] = {"ms_per_step": round(l_ms, 4), "sequences_per_gpu": per_rank,
+        out["lfm2_1p2b_mixed_1024_sequences_c512"] = {"ms_per_step": round(l_ms, 4), "sequences_per_gpu": per_rank,
                                                  "tokens_per_s": round(per_rank * world / (l_ms * 1e-3), 1)}
     return out
 
@@ -682,13 +682,14 @@ def qwen3_decode_via_graph(H, gen, cache_len=512, tokens=24):
     return out
 
 
-def lfm2_decode_step(H, gen, batch, cache_len):
+def lfm2_decode_step(H, gen, batch, cache_len, mixed=False):
     """One decode step of the LFM2-1.2B op sequence for `batch` independent sequences on one GPU
     (cactus_amd/steps.py: Lfm2Decode; 10 blocks with the short convolution, 6 with attention; dimensions from
-    the public model card).  Synthetic INT8 weights, one HIP graph per step."""
+    the public model card).  Synthetic INT8 weights (mixed: the converter's MIXED INT4 / INT8 policy, BASELINE
+    configs[3]), one HIP graph per step."""
     from cactus_amd import steps as ST
     cfg = ST.LFM2_1P2B
-    w = ST.lfm2_synthetic_weights(gen, batch, cfg)
+    w = ST.lfm2_synthetic_weights(gen, batch, cfg, mixed)
     dec = ST.Lfm2Decode(w, cfg, batch, cache_len + 1, cache_gen=gen)
     for st in dec.state.values():
         st.copy_((torch.rand(st.shape, device="cuda", generator=gen) - 0.5).half())
@@ -698,7 +699,8 @@ def lfm2_decode_step(H, gen, batch, cache_len):
     return {"ms_per_step": round(ms, 4), "tokens_per_s": round(batch / (ms * 1e-3), 1), "batch": batch,
             "cache_len": cache_len,
             "note": "a whole LFM2-1.2B-shape decode step (10 conv + 6 attention blocks): embedding lookup to greedy "
-                    "sampler, token ids stay on the device; dimensions from the public model card"}
+                    "sampler, token ids stay on the device; dimensions from the public model card"
+                    + ("; MIXED precision policy (INT4 attn_v / attn_output / MLP in blocks 2..13)" if mixed else "")}
 
 
 def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28):
@@ -921,7 +923,8 @@ def extra_table(H, gen, big):
     # config 4 (1024 independent LFM2-1.2B sequences sharded over the GPUs of a node): what one GPU
     # runs at 8 GPUs (128 sequences) and at 1 GPU (1024)
     ex["lfm2_1p2b_decode_step"] = {"b128_c512": lfm2_decode_step(H, gen, 128, 512),
-                                      "b1024_c512": lfm2_decode_step(H, gen, 1024, 512)}
+                                      "b1024_c512": lfm2_decode_step(H, gen, 1024, 512),
+                                      "b1024_c512_mixed_int4": lfm2_decode_step(H, gen, 1024, 512, mixed=True)}
     return ex
 
 

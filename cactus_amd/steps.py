@@ -321,16 +321,21 @@ class Qwen3Prefill:
                                                    int(last), self.logits.data_ptr(), self.tok.data_ptr(), H._stream()))
 
 
-def lfm2_synthetic_weights(gen, batch, cfg=LFM2_1P2B):
+def lfm2_synthetic_weights(gen, batch, cfg=LFM2_1P2B, mixed=False):
+    """mixed: the converter's MIXED policy (python/src/precision_config.py:52-124): packed INT4 for attn_v, attn_output
+    and the MLP outside the first and last two blocks; the convolution blocks' projections match no tolerant pattern
+    and stay INT8, as do attn_q / attn_k and the embedding."""
     c = cfg
     Hd, Hq, Hkv, D, F, V = c["hidden"], c["q_heads"], c["kv_heads"], c["head_dim"], c["ffn"], c["vocab"]
+    NL = c["layers"]
     layers = []
-    for li in range(c["layers"]):
-        L = dict(gate=synthetic_matrix(gen, F, Hd), up=synthetic_matrix(gen, F, Hd), down=synthetic_matrix(gen, Hd, F),
-                 in_norm=_norm_weight(gen, Hd), post_norm=_norm_weight(gen, Hd))
+    for li in range(NL):
+        i4 = lambda name: mixed and mixed_policy_int4(name, li, NL)
+        L = dict(gate=synthetic_matrix(gen, F, Hd, i4("gate")), up=synthetic_matrix(gen, F, Hd, i4("up")),
+                 down=synthetic_matrix(gen, Hd, F, i4("down")), in_norm=_norm_weight(gen, Hd), post_norm=_norm_weight(gen, Hd))
         if li in c["attention_layers"]:
             L.update(q=synthetic_matrix(gen, Hq * D, Hd), k=synthetic_matrix(gen, Hkv * D, Hd),
-                     v=synthetic_matrix(gen, Hkv * D, Hd), o=synthetic_matrix(gen, Hd, Hq * D),
+                     v=synthetic_matrix(gen, Hkv * D, Hd, i4("v")), o=synthetic_matrix(gen, Hd, Hq * D, i4("o")),
                      q_norm=_norm_weight(gen, D), k_norm=_norm_weight(gen, D))
         else:
             L.update(in_proj=synthetic_matrix(gen, 3 * Hd, Hd), out_proj=synthetic_matrix(gen, Hd, Hd),

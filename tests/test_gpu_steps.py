@@ -258,25 +258,33 @@ def conv_rows(cc):
     return torch.from_numpy(st.view(np.float16)).cuda()
 
 
-def test_lfm2_batched_decode_matches_oracle_per_sequence(ST):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_lfm2_batched_decode_matches_oracle_per_sequence(ST, mixed, monkeypatch):
     """A cut-down LFM2 (conv, conv, attention, conv, attention; hidden 2048, ffn 2048, vocabulary 4096) for 5
-    sequences of different lengths: conv state rows and INT8 caches per sequence on the device."""
+    sequences of different lengths: conv state rows and INT8 caches per sequence on the device.
+    mixed: packed INT4 for attn_v / attn_output / the MLP (the converter's MIXED policy, python/src/precision_config.py:
+    52-124, here in every block so that a cut-down model has some); the convolution projections, attn_q / attn_k and the
+    embedding stay INT8."""
     from tests import test_gpu_greedy_decode as GD
+    monkeypatch.setattr(GD, "omm", omm)       # the oracle matmul that also takes packed INT4
     c = GD.LFM
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + mixed)
     types, vocab, ffn, steps = "ccaca", 4096, 2048, 6
 
-    def mat(n, k, g):
+    def mat(n, k, g, tolerant=False):
+        if mixed and tolerant:
+            B, Bs = rand_weights_int4(rng, n, k)
+            return B, (Bs.astype(np.float32) * g * 16.0).astype(np.float16)
         B, Bs = rand_weights_int8(rng, n, k)
         return B, (Bs.astype(np.float32) * g).astype(np.float16)
     Ls = []
     for t in types:
-        L = {"gate": mat(ffn, c["HID"], 0.01), "up": mat(ffn, c["HID"], 0.01), "down": mat(c["HID"], ffn, 0.003),
+        L = {"gate": mat(ffn, c["HID"], 0.01, True), "up": mat(ffn, c["HID"], 0.01, True), "down": mat(c["HID"], ffn, 0.003, True),
              "in_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16),
              "post_norm": (1.0 + 0.1 * rng.standard_normal(c["HID"])).astype(np.float16)}
         if t == "a":
             L.update(q=mat(c["HQ"] * c["D"], c["HID"], 0.01), k=mat(c["HKV"] * c["D"], c["HID"], 0.01),
-                     v=mat(c["HKV"] * c["D"], c["HID"], 0.003), o=mat(c["HID"], c["HQ"] * c["D"], 0.003),
+                     v=mat(c["HKV"] * c["D"], c["HID"], 0.003, True), o=mat(c["HID"], c["HQ"] * c["D"], 0.003, True),
                      q_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16),
                      k_norm=(1.0 + 0.1 * rng.standard_normal(c["D"])).astype(np.float16))
         else:
