@@ -703,12 +703,12 @@ def lfm2_decode_step(H, gen, batch, cache_len, mixed=False):
                     + ("; MIXED precision policy (INT4 attn_v / attn_output / MLP in blocks 2..13)" if mixed else "")}
 
 
-def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28):
+def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False):
     """A chunked prefill of one sequence through the Qwen3-0.6B op sequence (cactus_amd/steps.py: Qwen3Prefill),
-    one HIP graph per chunk, replayed in order."""
+    one HIP graph per chunk, replayed in order.  mixed: the converter's MIXED INT4 / INT8 policy (BASELINE configs[2])."""
     from cactus_amd import steps as ST
     cfg = dict(ST.QWEN3_0P6B, layers=layers)
-    w = ST.qwen3_synthetic_weights(gen, cfg)
+    w = ST.qwen3_synthetic_weights(gen, cfg, mixed)
     pf = ST.Qwen3Prefill(w, cfg, tokens, chunk)
     pf.toks.copy_(torch.randint(0, cfg["vocab"], pf.toks.shape, dtype=torch.int32, device="cuda", generator=gen))
     graphs = []
@@ -732,7 +732,8 @@ def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return {"ms": round(ms, 2), "tokens_per_s": round(tokens / (ms * 1e-3), 1), "tokens": tokens, "chunk": chunk,
-            "note": "chunked prefill of one sequence, Qwen3-0.6B op sequence, synthetic INT8 weights"}
+            "note": "chunked prefill of one sequence, Qwen3-0.6B op sequence, synthetic "
+                    + ("MIXED INT4 / INT8 weights (INT4 attn_v / attn_output / MLP in blocks 2..25)" if mixed else "INT8 weights")}
 
 
 def extra_table(H, gen, big):
@@ -912,7 +913,9 @@ def extra_table(H, gen, big):
     # engine's default, and chunks sized for this device (one chunk: FP16 attention over the whole prompt)
     ex["qwen3_0p6b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256),
                                 "t4096_chunk1024": qwen3_prefill(H, gen, 4096, 1024),
-                                "t4096_chunk4096": qwen3_prefill(H, gen, 4096, 4096)}
+                                "t4096_chunk4096": qwen3_prefill(H, gen, 4096, 4096),
+                                "t4096_chunk256_mixed_int4": qwen3_prefill(H, gen, 4096, 256, mixed=True),
+                                "t4096_chunk4096_mixed_int4": qwen3_prefill(H, gen, 4096, 4096, mixed=True)}
     torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),
                                        "b256_c512": qwen3_decode_step(H, gen, 256, 512),

@@ -202,12 +202,14 @@ def test_qwen3_batched_decode_matches_oracle_per_sequence(ST, lens, mixed, windo
     assert len(ck.seen) > 1 and ck.near_ties <= 2
 
 
-def test_qwen3_chunked_prefill_matches_oracle(ST):
+@pytest.mark.parametrize("mixed", [False, True])
+def test_qwen3_chunked_prefill_matches_oracle(ST, mixed):
     """Three chunks of 64 tokens: chunk 0 against nothing (FP16 attention), the others against the INT8 cache;
-    the last token's logits and greedy choice, and the quantized K cache the chunks leave behind."""
-    layers, vocab, tokens, chunk = 4, 8192, 192, 64
-    rng = np.random.default_rng(77)
-    m = make_model(rng, layers, vocab, 0.05, False)
+    the last token's logits and greedy choice, and the quantized K cache the chunks leave behind.
+    mixed: 6 blocks under the converter's MIXED policy (INT4 attn_v / attn_output / MLP in blocks 2 and 3)."""
+    layers, vocab, tokens, chunk = (6 if mixed else 4), 8192, 192, 64
+    rng = np.random.default_rng(77 + mixed)
+    m = make_model(rng, layers, vocab, 0.05, mixed)
     cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
     pf = ST.Qwen3Prefill(ST.weights_to_device(m), cfg, tokens, chunk)
     prompt = rng.integers(0, vocab, tokens)
