@@ -703,16 +703,25 @@ def lfm2_decode_step(H, gen, batch, cache_len, mixed=False):
                     + ("; MIXED precision policy (INT4 attn_v / attn_output / MLP in blocks 2..13)" if mixed else "")}
 
 
-def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False):
-    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence (cactus_amd/steps.py: Qwen3Prefill),
-    one HIP graph per chunk, replayed in order.  mixed: the converter's MIXED INT4 / INT8 policy (BASELINE configs[2])."""
+def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False, lanes=1):
+    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence (cactus_amd/steps.py: Qwen3Prefill).
+    lanes = 1: one HIP graph per chunk, replayed in order (a host that calls cactus_hip_prefill_chunk_dev chunk by chunk);
+    lanes > 1: the whole prompt as one graph of cactus_hip_prefill_dev with that many chunks in flight on the library's
+    streams.  mixed: the converter's MIXED INT4 / INT8 policy (BASELINE configs[2])."""
     from cactus_amd import steps as ST
     cfg = dict(ST.QWEN3_0P6B, layers=layers)
     w = ST.qwen3_synthetic_weights(gen, cfg, mixed)
     pf = ST.Qwen3Prefill(w, cfg, tokens, chunk)
     pf.toks.copy_(torch.randint(0, cfg["vocab"], pf.toks.shape, dtype=torch.int32, device="cuda", generator=gen))
     graphs = []
-    for c in range(pf.nchunks):
+    if lanes > 1:
+        pf.run(lanes)                     # sizes workspaces, builds RoPE rows, creates the streams
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            pf.run(lanes)
+        graphs.append(g)
+    for c in range(pf.nchunks if lanes <= 1 else 0):
         pf.run_chunk(c)                   # sizes workspaces, builds RoPE rows
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -732,6 +741,7 @@ def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return {"ms": round(ms, 2), "tokens_per_s": round(tokens / (ms * 1e-3), 1), "tokens": tokens, "chunk": chunk,
+            "chunks_in_flight": lanes,
             "note": "chunked prefill of one sequence, Qwen3-0.6B op sequence, synthetic "
                     + ("MIXED INT4 / INT8 weights (INT4 attn_v / attn_output / MLP in blocks 2..25)" if mixed else "INT8 weights")}
 
@@ -914,7 +924,10 @@ def extra_table(H, gen, big):
     ex["qwen3_0p6b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256),
                                 "t4096_chunk1024": qwen3_prefill(H, gen, 4096, 1024),
                                 "t4096_chunk4096": qwen3_prefill(H, gen, 4096, 4096),
+                                "t4096_chunk256_4_in_flight": qwen3_prefill(H, gen, 4096, 256, lanes=4),
+                                "t4096_chunk1024_4_in_flight": qwen3_prefill(H, gen, 4096, 1024, lanes=4),
                                 "t4096_chunk256_mixed_int4": qwen3_prefill(H, gen, 4096, 256, mixed=True),
+                                "t4096_chunk256_mixed_int4_4_in_flight": qwen3_prefill(H, gen, 4096, 256, mixed=True, lanes=4),
                                 "t4096_chunk4096_mixed_int4": qwen3_prefill(H, gen, 4096, 4096, mixed=True)}
     torch.cuda.empty_cache()
     ex["qwen3_0p6b_decode_step"] = {"b1_c512": qwen3_decode_step(H, gen, 1, 512),

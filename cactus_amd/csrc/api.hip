@@ -63,9 +63,9 @@ struct Workspace {
 std::mutex g_ws_mu;
 std::unordered_map<int, Workspace> g_ws;
 // Calls enqueued on one stream follow one another, so they can share one workspace.  A host that enqueues on two streams
-// at once (the step driver's two half-batches) names a lane per stream while it enqueues for it: every lane has its own
+// at once (the step drivers' half-batches and chunks in flight) names a lane per stream while it enqueues for it: every lane has its own
 // buffer.  The lane is a property of the enqueueing thread.
-constexpr int WS_LANES = 2;
+constexpr int WS_LANES = 8;
 thread_local int g_ws_lane = 0;
 
 int workspace(size_t bytes, void** out) {
@@ -90,7 +90,7 @@ int workspace(size_t bytes, void** out) {
 }  // namespace
 namespace cactus_hip {
 int workspace_for_comm(size_t bytes, void** out) { return workspace(bytes, out); }   // comm.hip's staging slots
-// the workspace lane (0 or 1) of the calls this thread enqueues from now on; returns the previous one
+// the workspace lane (0 .. 7) of the calls this thread enqueues from now on; returns the previous one
 int workspace_lane(int lane) {
     const int prev = g_ws_lane;
     g_ws_lane = lane < 0 ? 0 : (lane >= WS_LANES ? WS_LANES - 1 : lane);
@@ -316,7 +316,7 @@ int cactus_hip_workspace_reserve(size_t bytes) {
     void* ws = nullptr;
     const int lane = cactus_hip::workspace_lane(0);
     int rc = CACTUS_HIP_OK;
-    for (int l = 0; l < WS_LANES && rc == CACTUS_HIP_OK; l++) {   // every lane: a captured step may use both
+    for (int l = 0; l < WS_LANES && rc == CACTUS_HIP_OK; l++) {   // every lane: a captured step may use all of them
         cactus_hip::workspace_lane(l);
         rc = workspace(bytes, &ws);
     }

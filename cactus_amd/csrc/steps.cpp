@@ -166,10 +166,14 @@ DecodeBuffers rows_from(const cactus_hip_decoder_weights* w, const DecodeBuffers
 
 // Two half-batches in step (see cactus_hip_decode_step_dev): the second half's stream and the events that order the
 // halves' attention launches, one set per device, made on first use and kept.
+constexpr int PF_MAX_LANES = 8;       // chunks of a prompt in flight at a time
 struct StepPipeline {
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr;                 // the decode step's second half; lane 1 of a prefill
+    hipStream_t more[PF_MAX_LANES - 2] = {};    // lanes 2.. of a prefill
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t lane_join[PF_MAX_LANES - 2] = {};
     std::vector<hipEvent_t> a_done, b_done;     // per attention layer
+    std::vector<hipEvent_t> appended[PF_MAX_LANES];   // prefill: per lane and layer, "this chunk's K / V rows are in the cache"
 };
 std::mutex g_pipe_mu;
 StepPipeline g_pipe[64];
@@ -197,6 +201,25 @@ StepPipeline* step_pipeline(size_t attention_layers) {
     return &p;
 }
 
+// the prefill's further streams and its per-lane, per-layer events (on top of step_pipeline's)
+StepPipeline* prefill_pipeline(size_t layers, int lanes) {
+    StepPipeline* p = step_pipeline(0);
+    if (!p) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    for (int l = 2; l < lanes; l++)
+        if (!p->more[l - 2]) {
+            if (hipStreamCreateWithFlags(&p->more[l - 2], hipStreamNonBlocking) != hipSuccess) { p->more[l - 2] = nullptr; return nullptr; }
+            if (hipEventCreateWithFlags(&p->lane_join[l - 2], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+    for (int l = 0; l < lanes; l++)
+        while (p->appended[l].size() < layers) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            p->appended[l].push_back(e);
+        }
+    return p;
+}
+
 // Batches from this size on are run as two half-batches (0: never, the default: on the shapes measured a half-batch's
 // attention, 128 workgroups of 8 waves, streams its cache at 3.2 - 3.7 TB/s against 4.5 - 5.4 TB/s for the whole batch,
 // which costs more than hiding the other half's matmuls returns).  CACTUS_HIP_STEP_SPLIT sets the initial value.
@@ -208,11 +231,81 @@ size_t& step_split_value() {
     return t;
 }
 size_t step_split_threshold() { return step_split_value(); }
+// experiment switch: the halves' attention launches take turns (1, the default) or the halves run freely (0)
+bool step_split_alternate() {
+    static const bool a = [] {
+        const char* e = std::getenv("CACTUS_HIP_STEP_ALTERNATE");
+        return e ? std::atoi(e) != 0 : true;
+    }();
+    return a;
+}
 
 #define HIP_STEP_TRY(expr)                                        \
     do {                                                          \
         if ((expr) != hipSuccess) return fail("decode step: stream / event call failed"); \
     } while (0)
+
+// One chunk.  appended / previous: per-layer events of this chunk's lane and of the lane of the chunk before it (null:
+// chunks follow one another on one stream): this chunk's rows are announced once they are in a block's cache, and its
+// attention over the cache waits for the previous chunk's announcement of that block.
+int prefill_chunk(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* st, const int32_t* tokens,
+                  size_t chunk, size_t cache_start, const int32_t* cache_start_dev, void* workspace, int last,
+                  cactus_half_t* logits, int32_t* token_out, void* stream, const hipEvent_t* appended,
+                  const hipEvent_t* previous) {
+    if (const char* bad = check_weights(w, true)) return fail(bad);
+    if (!st || !st->k_cache || !st->v_cache || !st->k_scales || !st->v_scales) return fail("prefill chunk: null cache");
+    if (!tokens || !cache_start_dev || !workspace || chunk == 0) return fail("prefill chunk: null operand");
+    if (cache_start + chunk > st->capacity) return fail("prefill chunk: the cache cannot hold cache_start + chunk tokens");
+    if (last && (!logits || !token_out)) return fail("prefill chunk: the last chunk needs logits and token_out");
+    const size_t M = chunk, Hd = w->hidden, Hq = w->q_heads, Hkv = w->kv_heads, D = w->head_dim, F = w->ffn, V = w->vocab;
+    const size_t G = (D + 127) / 128, NL = w->layers, QD = Hq * D;
+    const size_t cbs = st->capacity * Hkv * D, sbs = st->capacity * Hkv * G;
+    DecodeBuffers d;
+    carve_decode(w, M, workspace, &d);
+    const cactus_hip_qmatrix& head = w->lm_head.B ? w->lm_head : w->embedding;
+    STEP_TRY(cactus_hip_embedding_int8_dev(static_cast<const int8_t*>(w->embedding.B), w->embedding.scales, tokens, d.h0, M, V, Hd,
+                                           128, nullptr, stream));
+    STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h0, nullptr, w->blocks[0].in_norm, nullptr, nullptr, d.xq, d.xs, M, Hd, w->eps,
+                                                   stream));
+    const half_t* res = d.h0;
+    for (size_t li = 0; li < NL; li++) {
+        const cactus_hip_block_weights& L = w->blocks[li];
+        const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
+        STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, M, Hd, stream));
+        int8_t* kc = st->k_cache + li * cbs;
+        int8_t* vc = st->v_cache + li * cbs;
+        float* ks = st->k_scales + li * sbs;
+        float* vs = st->v_scales + li * sbs;
+        STEP_TRY(cactus_hip_qk_norm_rope_kv_append_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, d.qr, d.kr, kc, vc, ks, vs,
+                                                          cache_start_dev, 1, M, Hq, Hkv, D, w->eps, cache_start, w->theta, 128, cbs,
+                                                          sbs, st->capacity, stream));
+        if (appended) HIP_STEP_TRY(hipEventRecord(appended[li], static_cast<hipStream_t>(stream)));
+        if (previous && cache_start != 0) HIP_STEP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), previous[li], 0));
+        if (cache_start == 0) {
+            STEP_TRY(cactus_hip_attention_f16_dev(d.qr, d.kr, d.vo, d.ao, 1, M, M, Hq, Hkv, D, 0.0f, nullptr, 0, 0, 1, stream));
+            STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
+        } else {
+            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_quant_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, d.oq, d.os, 1, M, cache_start,
+                                                                    M, Hq, Hkv, D, 0.0f, cache_start, 1, 128, stream));
+        }
+        STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, M, stream));
+        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, M, Hd, w->eps, stream));
+        const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
+        STEP_TRY(shared_matmuls(d.xq2, d.xs2, gu, 2, M, Hd, stream));
+        STEP_TRY(cactus_hip_silu_multiply_quant_f16_dev(d.go, d.uo, nullptr, d.aq, d.as, M, F, stream));
+        STEP_TRY(matmul_q(d.aq, d.as, L.down, d.dn, M, stream));
+        const half_t* nxt = li + 1 < NL ? w->blocks[li + 1].in_norm : w->final_norm;
+        const bool fin = li + 1 == NL && last;
+        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h2, d.dn, nxt, d.hid, fin ? d.x : nullptr, d.xq, d.xs, M, Hd, w->eps, stream));
+        res = d.hid;
+    }
+    if (last) {
+        STEP_TRY(matmul_f16act(d.x + (M - 1) * Hd, head, logits, 1, stream));
+        STEP_TRY(cactus_hip_sample_greedy_f16_dev(logits, reinterpret_cast<uint32_t*>(token_out), 1, V, stream));
+    }
+    return CACTUS_HIP_OK;
+}
+
 
 }  // namespace
 
@@ -306,7 +399,7 @@ int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus
                     const int32_t* lens = kv->cache_lens + H.r0;
                     const int32_t* pos = kv->positions + H.r0;
                     hipStream_t hs = static_cast<hipStream_t>(H.stream);
-                    if (nh == 2) {       // A(i) after B(i - 1), B(i) after A(i)
+                    if (nh == 2 && step_split_alternate()) {       // A(i) after B(i - 1), B(i) after A(i)
                         if (h == 0 && ai > 0) HIP_STEP_TRY(hipStreamWaitEvent(hs, pipe->b_done[ai - 1], 0));
                         if (h == 1) HIP_STEP_TRY(hipStreamWaitEvent(hs, pipe->a_done[ai], 0));
                     }
@@ -432,56 +525,53 @@ size_t cactus_hip_prefill_chunk_workspace_bytes(const cactus_hip_decoder_weights
 int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* st, const int32_t* tokens,
                                  size_t chunk, size_t cache_start, const int32_t* cache_start_dev, void* workspace, int last,
                                  cactus_half_t* logits, int32_t* token_out, void* stream) {
+    return prefill_chunk(w, st, tokens, chunk, cache_start, cache_start_dev, workspace, last, logits, token_out, stream, nullptr,
+                         nullptr);
+}
+
+size_t cactus_hip_prefill_workspace_bytes(const cactus_hip_decoder_weights* w, size_t chunk, size_t lanes) {
+    if (!w || chunk == 0 || lanes == 0) return 0;
+    if (lanes > (size_t)PF_MAX_LANES) lanes = PF_MAX_LANES;
+    if (lanes > 1 && w->blocks) prefill_pipeline(w->layers, (int)lanes);     // outside any stream capture
+    return lanes * carve_decode(w, chunk, nullptr, nullptr);
+}
+
+int cactus_hip_prefill_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* st, const int32_t* tokens,
+                           size_t n_tokens, size_t chunk, const int32_t* chunk_starts_dev, void* workspace, size_t lanes,
+                           cactus_half_t* logits, int32_t* token_out, void* stream) {
     if (const char* bad = check_weights(w, true)) return fail(bad);
-    if (!st || !st->k_cache || !st->v_cache || !st->k_scales || !st->v_scales) return fail("prefill chunk: null cache");
-    if (!tokens || !cache_start_dev || !workspace || chunk == 0) return fail("prefill chunk: null operand");
-    if (cache_start + chunk > st->capacity) return fail("prefill chunk: the cache cannot hold cache_start + chunk tokens");
-    if (last && (!logits || !token_out)) return fail("prefill chunk: the last chunk needs logits and token_out");
-    const size_t M = chunk, Hd = w->hidden, Hq = w->q_heads, Hkv = w->kv_heads, D = w->head_dim, F = w->ffn, V = w->vocab;
-    const size_t G = (D + 127) / 128, NL = w->layers, QD = Hq * D;
-    const size_t cbs = st->capacity * Hkv * D, sbs = st->capacity * Hkv * G;
-    DecodeBuffers d;
-    carve_decode(w, M, workspace, &d);
-    const cactus_hip_qmatrix& head = w->lm_head.B ? w->lm_head : w->embedding;
-    STEP_TRY(cactus_hip_embedding_int8_dev(static_cast<const int8_t*>(w->embedding.B), w->embedding.scales, tokens, d.h0, M, V, Hd,
-                                           128, nullptr, stream));
-    STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h0, nullptr, w->blocks[0].in_norm, nullptr, nullptr, d.xq, d.xs, M, Hd, w->eps,
-                                                   stream));
-    const half_t* res = d.h0;
-    for (size_t li = 0; li < NL; li++) {
-        const cactus_hip_block_weights& L = w->blocks[li];
-        const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
-        STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, M, Hd, stream));
-        int8_t* kc = st->k_cache + li * cbs;
-        int8_t* vc = st->v_cache + li * cbs;
-        float* ks = st->k_scales + li * sbs;
-        float* vs = st->v_scales + li * sbs;
-        STEP_TRY(cactus_hip_qk_norm_rope_kv_append_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, d.qr, d.kr, kc, vc, ks, vs,
-                                                          cache_start_dev, 1, M, Hq, Hkv, D, w->eps, cache_start, w->theta, 128, cbs,
-                                                          sbs, st->capacity, stream));
-        if (cache_start == 0) {
-            STEP_TRY(cactus_hip_attention_f16_dev(d.qr, d.kr, d.vo, d.ao, 1, M, M, Hq, Hkv, D, 0.0f, nullptr, 0, 0, 1, stream));
-            STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
-        } else {
-            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_quant_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, d.oq, d.os, 1, M, cache_start,
-                                                                    M, Hq, Hkv, D, 0.0f, cache_start, 1, 128, stream));
+    if (!tokens || !chunk_starts_dev || !workspace || chunk == 0 || n_tokens == 0) return fail("prefill: null or empty operand");
+    if (!logits || !token_out) return fail("prefill: null logits / token_out");
+    if (lanes == 0) lanes = 1;
+    if (lanes > (size_t)PF_MAX_LANES) lanes = PF_MAX_LANES;
+    const size_t nchunks = (n_tokens + chunk - 1) / chunk;
+    if (lanes > nchunks) lanes = nchunks;
+    StepPipeline* pipe = lanes > 1 ? prefill_pipeline(w->layers, (int)lanes) : nullptr;
+    if (lanes > 1 && !pipe) lanes = 1;           // no second stream to be had: one chunk after the other
+    const size_t per_lane = carve_decode(w, chunk, nullptr, nullptr);
+    hipStream_t main_stream = static_cast<hipStream_t>(stream);
+    auto lane_stream = [&](size_t l) { return l == 0 ? main_stream : (l == 1 ? pipe->side : pipe->more[l - 2]); };
+    if (lanes > 1) {
+        HIP_STEP_TRY(hipEventRecord(pipe->fork, main_stream));
+        for (size_t l = 1; l < lanes; l++) HIP_STEP_TRY(hipStreamWaitEvent(lane_stream(l), pipe->fork, 0));
+    }
+    int rc = CACTUS_HIP_OK;
+    for (size_t c = 0; c < nchunks && rc == CACTUS_HIP_OK; c++) {
+        const size_t l = c % lanes, start = c * chunk, len = start + chunk <= n_tokens ? chunk : n_tokens - start;
+        const int prev_lane = cactus_hip::workspace_lane((int)l);
+        rc = prefill_chunk(w, st, tokens + start, len, start, chunk_starts_dev + c, static_cast<unsigned char*>(workspace) + l * per_lane,
+                           c + 1 == nchunks, logits, token_out, lane_stream(l), lanes > 1 ? pipe->appended[l].data() : nullptr,
+                           lanes > 1 && c > 0 ? pipe->appended[(c - 1) % lanes].data() : nullptr);
+        cactus_hip::workspace_lane(prev_lane);
+    }
+    if (lanes > 1) {      // joined even after a failure: a capture of `stream` must not be left with open branches
+        for (size_t l = 1; l < lanes; l++) {
+            hipEvent_t j = l == 1 ? pipe->join : pipe->lane_join[l - 2];
+            if (hipEventRecord(j, lane_stream(l)) != hipSuccess || hipStreamWaitEvent(main_stream, j, 0) != hipSuccess)
+                return fail("prefill: stream / event call failed");
         }
-        STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, M, stream));
-        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, M, Hd, w->eps, stream));
-        const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
-        STEP_TRY(shared_matmuls(d.xq2, d.xs2, gu, 2, M, Hd, stream));
-        STEP_TRY(cactus_hip_silu_multiply_quant_f16_dev(d.go, d.uo, nullptr, d.aq, d.as, M, F, stream));
-        STEP_TRY(matmul_q(d.aq, d.as, L.down, d.dn, M, stream));
-        const half_t* nxt = li + 1 < NL ? w->blocks[li + 1].in_norm : w->final_norm;
-        const bool fin = li + 1 == NL && last;
-        STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h2, d.dn, nxt, d.hid, fin ? d.x : nullptr, d.xq, d.xs, M, Hd, w->eps, stream));
-        res = d.hid;
     }
-    if (last) {
-        STEP_TRY(matmul_f16act(d.x + (M - 1) * Hd, head, logits, 1, stream));
-        STEP_TRY(cactus_hip_sample_greedy_f16_dev(logits, reinterpret_cast<uint32_t*>(token_out), 1, V, stream));
-    }
-    return CACTUS_HIP_OK;
+    return rc;
 }
 
 }  // extern "C"

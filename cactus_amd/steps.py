@@ -181,6 +181,11 @@ class _PrefillState(C.Structure):
 
 
 _lib = H.lib
+_lib.cactus_hip_prefill_workspace_bytes.restype = C.c_size_t
+_lib.cactus_hip_prefill_workspace_bytes.argtypes = [C.POINTER(_Weights), C.c_size_t, C.c_size_t]
+_lib.cactus_hip_prefill_dev.restype = C.c_int
+_lib.cactus_hip_prefill_dev.argtypes = [C.POINTER(_Weights), C.POINTER(_PrefillState), C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p,
+                                        C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
 _lib.cactus_hip_decode_step_split.restype = C.c_size_t
 _lib.cactus_hip_decode_step_split.argtypes = [C.c_size_t]
 _lib.cactus_hip_decode_step_workspace_bytes.restype = C.c_size_t
@@ -319,6 +324,18 @@ class Qwen3Prefill:
         H._check(_lib.cactus_hip_prefill_chunk_dev(C.byref(self._desc), C.byref(self._state), self.toks[ci].data_ptr(),
                                                    self.chunk, ci * self.chunk, self.slots[ci].data_ptr(), self._ws.data_ptr(),
                                                    int(last), self.logits.data_ptr(), self.tok.data_ptr(), H._stream()))
+
+    def run(self, lanes=4):
+        """The whole prompt in one call (cactus_hip_prefill_dev): up to `lanes` chunks in flight on streams of the
+        library's own, each chunk's attention in a block waiting for the previous chunk's rows in that block's cache."""
+        if getattr(self, "_lanes", 0) < lanes:
+            nbytes = _lib.cactus_hip_prefill_workspace_bytes(C.byref(self._desc), self.chunk, lanes)
+            self._ws_all = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+            self._starts = torch.arange(self.nchunks, dtype=torch.int32, device="cuda") * self.chunk
+            self._lanes = lanes
+        H._check(_lib.cactus_hip_prefill_dev(C.byref(self._desc), C.byref(self._state), self.toks.data_ptr(), self.tokens,
+                                             self.chunk, self._starts.data_ptr(), self._ws_all.data_ptr(), lanes,
+                                             self.logits.data_ptr(), self.tok.data_ptr(), H._stream()))
 
 
 def lfm2_synthetic_weights(gen, batch, cfg=LFM2_1P2B, mixed=False):

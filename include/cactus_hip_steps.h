@@ -102,6 +102,21 @@ int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cact
                                  const int32_t* tokens, size_t chunk, size_t cache_start, const int32_t* cache_start_dev,
                                  void* workspace, int last, cactus_half_t* logits, int32_t* token_out, void* stream);
 
+/* The whole prompt: every chunk of cactus_hip_prefill_chunk_dev in one call (Model::prefill's loop, engine_model.cpp:
+ * 170-219), up to `lanes` (1 .. 8) chunks in flight at a time.  A chunk's launches are short and leave most of the chip
+ * idle, and chunk c + 1 needs nothing of chunk c but its rows in a block's cache when it reaches that block's attention:
+ * chunk c runs on stream c % lanes (lane 0 = `stream`, the others the library's own, forked from and joined to `stream`,
+ * so a capture of `stream` takes in all of them), records an event per block once its K / V rows are appended, and its
+ * attention in a block waits for the previous chunk's event of that block.  The results are those of the chunks called
+ * one after the other, bit for bit.  tokens: device int32[n_tokens]; the last chunk may be short; chunk_starts_dev:
+ * device int32[chunks] holding c * chunk; workspace: cactus_hip_prefill_workspace_bytes(w, chunk, lanes) bytes (call it
+ * outside any stream capture: it also creates the streams and events); logits half[1, vocab] and *token_out receive the
+ * last token's logits and greedy choice.  No counterpart in the reference, whose chunks are separate graph executions. */
+size_t cactus_hip_prefill_workspace_bytes(const cactus_hip_decoder_weights* w, size_t chunk, size_t lanes);
+int cactus_hip_prefill_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* state, const int32_t* tokens,
+                           size_t n_tokens, size_t chunk, const int32_t* chunk_starts_dev, void* workspace, size_t lanes,
+                           cactus_half_t* logits, int32_t* token_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

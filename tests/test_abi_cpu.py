@@ -36,7 +36,8 @@ def test_steps_library_exports_every_declared_symbol():
     import cactus_amd.hip as H
     names = _declared("cactus_hip_steps.h")
     assert names == ["cactus_hip_decode_step_dev", "cactus_hip_decode_step_split", "cactus_hip_decode_step_workspace_bytes",
-                     "cactus_hip_prefill_chunk_dev", "cactus_hip_prefill_chunk_workspace_bytes"]
+                     "cactus_hip_prefill_chunk_dev", "cactus_hip_prefill_chunk_workspace_bytes", "cactus_hip_prefill_dev",
+                     "cactus_hip_prefill_workspace_bytes"]
     for n in names:
         assert hasattr(H.lib, n), f"{n} declared in include/cactus_hip_steps.h but not exported"
 

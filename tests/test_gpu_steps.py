@@ -577,3 +577,44 @@ def test_split_decode_step_equals_the_single_stream_step(ST, model, batch, windo
             assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (graph, i)
         for i, (a, b) in enumerate(zip(want_st, got_st)):
             assert torch.equal(a, b), (graph, "state", i)
+
+
+@pytest.mark.parametrize("lanes,mixed", [(2, False), (4, False), (3, True)])
+def test_pipelined_prefill_equals_chunk_after_chunk(ST, lanes, mixed):
+    """cactus_hip_prefill_dev (several chunks in flight on the library's own streams, a block's attention waiting for the
+    previous chunk's rows in that block's cache) leaves, bit for bit, the caches, logits and token of the chunks run one
+    after the other with cactus_hip_prefill_chunk_dev: eagerly, and as one captured HIP graph replayed twice."""
+    layers, vocab, tokens, chunk = 5, 4096, 448, 64
+    cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
+
+    def make():
+        gen = torch.Generator(device="cuda").manual_seed(99 + lanes)
+        pf = ST.Qwen3Prefill(ST.qwen3_synthetic_weights(gen, cfg, mixed), cfg, tokens, chunk)
+        pf.toks.copy_(torch.randint(0, vocab, pf.toks.shape, dtype=torch.int32, device="cuda", generator=gen))
+        return pf
+
+    def state(pf):
+        return [pf.logits.clone(), pf.tok.clone(), pf.kc.clone(), pf.vc.clone(), pf.ksc.clone(), pf.vsc.clone()]
+
+    ref = make()
+    for ci in range(ref.nchunks):
+        ref.run_chunk(ci)
+    torch.cuda.synchronize()
+    want = state(ref)
+    pf = make()
+    pf.run(lanes)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(want, state(pf))):
+        assert torch.equal(a, b), ("eager", i)
+    pf = make()
+    pf.run(lanes)                      # sizes the library workspaces outside the capture
+    torch.cuda.synchronize()
+    pf.kc.zero_(); pf.vc.zero_(); pf.logits.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pf.run(lanes)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(want, state(pf))):
+        assert torch.equal(a, b), ("graph", i)
