@@ -703,15 +703,20 @@ def lfm2_decode_step(H, gen, batch, cache_len, mixed=False):
                     + ("; MIXED precision policy (INT4 attn_v / attn_output / MLP in blocks 2..13)" if mixed else "")}
 
 
-def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False, lanes=1):
-    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence (cactus_amd/steps.py: Qwen3Prefill).
+def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False, lanes=1, lfm2=False):
+    """A chunked prefill of one sequence through the Qwen3-0.6B op sequence (cactus_amd/steps.py: Prefill), or with lfm2
+    the LFM2-1.2B one (10 short-convolution blocks carrying their rows from chunk to chunk, 6 attention blocks).
     lanes = 1: one HIP graph per chunk, replayed in order (a host that calls cactus_hip_prefill_chunk_dev chunk by chunk);
     lanes > 1: the whole prompt as one graph of cactus_hip_prefill_dev with that many chunks in flight on the library's
     streams.  mixed: the converter's MIXED INT4 / INT8 policy (BASELINE configs[2])."""
     from cactus_amd import steps as ST
-    cfg = dict(ST.QWEN3_0P6B, layers=layers)
-    w = ST.qwen3_synthetic_weights(gen, cfg, mixed)
-    pf = ST.Qwen3Prefill(w, cfg, tokens, chunk)
+    if lfm2:
+        cfg = ST.LFM2_1P2B
+        w = ST.lfm2_synthetic_weights(gen, 1, cfg, mixed)
+    else:
+        cfg = dict(ST.QWEN3_0P6B, layers=layers)
+        w = ST.qwen3_synthetic_weights(gen, cfg, mixed)
+    pf = ST.Prefill(w, cfg, tokens, chunk)
     pf.toks.copy_(torch.randint(0, cfg["vocab"], pf.toks.shape, dtype=torch.int32, device="cuda", generator=gen))
     graphs = []
     if lanes > 1:
@@ -742,8 +747,9 @@ def qwen3_prefill(H, gen, tokens=4096, chunk=256, layers=28, mixed=False, lanes=
     ms = e0.elapsed_time(e1) / reps
     return {"ms": round(ms, 2), "tokens_per_s": round(tokens / (ms * 1e-3), 1), "tokens": tokens, "chunk": chunk,
             "chunks_in_flight": lanes,
-            "note": "chunked prefill of one sequence, Qwen3-0.6B op sequence, synthetic "
-                    + ("MIXED INT4 / INT8 weights (INT4 attn_v / attn_output / MLP in blocks 2..25)" if mixed else "INT8 weights")}
+            "note": "chunked prefill of one sequence, " + ("LFM2-1.2B" if lfm2 else "Qwen3-0.6B") + " op sequence, synthetic "
+                    + ("MIXED INT4 / INT8 weights (INT4 attn_v / attn_output / MLP outside the first and last two blocks)"
+                       if mixed else "INT8 weights")}
 
 
 def extra_table(H, gen, big):
@@ -938,6 +944,10 @@ def extra_table(H, gen, big):
     torch.cuda.empty_cache()
     # config 4 (1024 independent LFM2-1.2B sequences sharded over the GPUs of a node): what one GPU
     # runs at 8 GPUs (128 sequences) and at 1 GPU (1024)
+    ex["lfm2_1p2b_prefill"] = {"t4096_chunk256": qwen3_prefill(H, gen, 4096, 256, lfm2=True),
+                               "t4096_chunk256_4_in_flight": qwen3_prefill(H, gen, 4096, 256, lfm2=True, lanes=4),
+                               "t4096_chunk256_mixed_int4_4_in_flight": qwen3_prefill(H, gen, 4096, 256, lfm2=True, mixed=True, lanes=4),
+                               "t4096_chunk4096": qwen3_prefill(H, gen, 4096, 4096, lfm2=True)}
     ex["lfm2_1p2b_decode_step"] = {"b128_c512": lfm2_decode_step(H, gen, 128, 512),
                                       "b1024_c512": lfm2_decode_step(H, gen, 1024, 512),
                                       "b1024_c512_mixed_int4": lfm2_decode_step(H, gen, 1024, 512, mixed=True)}

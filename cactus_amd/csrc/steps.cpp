@@ -97,7 +97,7 @@ bool check_matrix(const cactus_hip_qmatrix& m, size_t N, size_t K) {
     return m.B != nullptr && m.scales != nullptr && m.N == N && m.K == K;
 }
 
-const char* check_weights(const cactus_hip_decoder_weights* w, bool attention_only) {
+const char* check_weights(const cactus_hip_decoder_weights* w) {
     if (!w || !w->blocks || w->layers == 0) return "decoder step: null model description";
     if (w->hidden == 0 || w->q_heads == 0 || w->kv_heads == 0 || w->head_dim == 0 || w->ffn == 0 || w->vocab == 0)
         return "decoder step: zero model dimension";
@@ -118,7 +118,6 @@ const char* check_weights(const cactus_hip_decoder_weights* w, bool attention_on
                 return "decoder step: attention matrices must be q [Hq D, hidden], k / v [Hkv D, hidden], o [hidden, Hq D]";
             if (!b.q_norm || !b.k_norm) return "decoder step: null q / k norm";
         } else if (b.kind == 1) {
-            if (attention_only) return "prefill chunk: blocks with the short convolution are not supported";
             if (!check_matrix(b.in_proj, 3 * Hd, Hd) || !check_matrix(b.out_proj, Hd, Hd) || !b.conv_weight)
                 return "decoder step: conv block needs in_proj [3 hidden, hidden], out_proj [hidden, hidden], conv_weight";
             if (b.in_proj.int4 || b.out_proj.int4) return "decoder step: conv block projections must be INT8";
@@ -252,8 +251,11 @@ int prefill_chunk(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_
                   size_t chunk, size_t cache_start, const int32_t* cache_start_dev, void* workspace, int last,
                   cactus_half_t* logits, int32_t* token_out, void* stream, const hipEvent_t* appended,
                   const hipEvent_t* previous) {
-    if (const char* bad = check_weights(w, true)) return fail(bad);
+    if (const char* bad = check_weights(w)) return fail(bad);
     if (!st || !st->k_cache || !st->v_cache || !st->k_scales || !st->v_scales) return fail("prefill chunk: null cache");
+    size_t n_conv = 0;
+    for (size_t i = 0; i < w->layers; i++) n_conv += w->blocks[i].kind == 1;
+    if (n_conv && !st->conv_state) return fail("prefill chunk: null convolution state");
     if (!tokens || !cache_start_dev || !workspace || chunk == 0) return fail("prefill chunk: null operand");
     if (cache_start + chunk > st->capacity) return fail("prefill chunk: the cache cannot hold cache_start + chunk tokens");
     if (last && (!logits || !token_out)) return fail("prefill chunk: the last chunk needs logits and token_out");
@@ -268,27 +270,44 @@ int prefill_chunk(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_
     STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(d.h0, nullptr, w->blocks[0].in_norm, nullptr, nullptr, d.xq, d.xs, M, Hd, w->eps,
                                                    stream));
     const half_t* res = d.h0;
+    size_t ai = 0, ci = 0;
     for (size_t li = 0; li < NL; li++) {
         const cactus_hip_block_weights& L = w->blocks[li];
-        const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
-        STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, M, Hd, stream));
-        int8_t* kc = st->k_cache + li * cbs;
-        int8_t* vc = st->v_cache + li * cbs;
-        float* ks = st->k_scales + li * sbs;
-        float* vs = st->v_scales + li * sbs;
-        STEP_TRY(cactus_hip_qk_norm_rope_kv_append_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, d.qr, d.kr, kc, vc, ks, vs,
-                                                          cache_start_dev, 1, M, Hq, Hkv, D, w->eps, cache_start, w->theta, 128, cbs,
-                                                          sbs, st->capacity, stream));
-        if (appended) HIP_STEP_TRY(hipEventRecord(appended[li], static_cast<hipStream_t>(stream)));
-        if (previous && cache_start != 0) HIP_STEP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), previous[li], 0));
-        if (cache_start == 0) {
-            STEP_TRY(cactus_hip_attention_f16_dev(d.qr, d.kr, d.vo, d.ao, 1, M, M, Hq, Hkv, D, 0.0f, nullptr, 0, 0, 1, stream));
-            STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
+        if (L.kind == 1) {
+            // LFM2 short convolution over the rows the chunk before left in this block's state (the first chunk
+            // starts from none): the in-projection needs nothing of the chunk before, the convolution launch does
+            half_t* state = st->conv_state + ci++ * w->conv_rows * Hd;
+            STEP_TRY(matmul_q(d.xq, d.xs, L.in_proj, d.ipj, M, stream));
+            if (cache_start == 0)
+                HIP_STEP_TRY(hipMemsetAsync(state, 0, w->conv_rows * Hd * sizeof(half_t), static_cast<hipStream_t>(stream)));
+            else if (previous)
+                HIP_STEP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), previous[li], 0));
+            STEP_TRY(cactus_hip_lfm2_conv_gate_quant_f16_dev(d.ipj, L.conv_weight, state, nullptr, d.cq, d.cs, 1, M, Hd, w->conv_taps,
+                                                            w->conv_rows, stream));
+            if (appended) HIP_STEP_TRY(hipEventRecord(appended[li], static_cast<hipStream_t>(stream)));
+            STEP_TRY(matmul_q(d.cq, d.cs, L.out_proj, d.oo, M, stream));
         } else {
-            STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_quant_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, d.oq, d.os, 1, M, cache_start,
-                                                                    M, Hq, Hkv, D, 0.0f, cache_start, 1, 128, stream));
+            const Out qkv[3] = {{&L.q, d.qo}, {&L.k, d.ko}, {&L.v, d.vo}};
+            STEP_TRY(shared_matmuls(d.xq, d.xs, qkv, 3, M, Hd, stream));
+            int8_t* kc = st->k_cache + ai * cbs;
+            int8_t* vc = st->v_cache + ai * cbs;
+            float* ks = st->k_scales + ai * sbs;
+            float* vs = st->v_scales + ai * sbs;
+            ai++;
+            STEP_TRY(cactus_hip_qk_norm_rope_kv_append_f16_dev(d.qo, d.ko, d.vo, L.q_norm, L.k_norm, d.qr, d.kr, kc, vc, ks, vs,
+                                                              cache_start_dev, 1, M, Hq, Hkv, D, w->eps, cache_start, w->theta, 128, cbs,
+                                                              sbs, st->capacity, stream));
+            if (appended) HIP_STEP_TRY(hipEventRecord(appended[li], static_cast<hipStream_t>(stream)));
+            if (previous && cache_start != 0) HIP_STEP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), previous[li], 0));
+            if (cache_start == 0) {
+                STEP_TRY(cactus_hip_attention_f16_dev(d.qr, d.kr, d.vo, d.ao, 1, M, M, Hq, Hkv, D, 0.0f, nullptr, 0, 0, 1, stream));
+                STEP_TRY(cactus_hip_quantize_activations_dev(d.ao, d.oq, d.os, M, QD, stream));
+            } else {
+                STEP_TRY(cactus_hip_attention_hybrid_int8_fp16_quant_dev(d.qr, kc, vc, ks, vs, d.kr, d.vo, d.ao, d.oq, d.os, 1, M, cache_start,
+                                                                        M, Hq, Hkv, D, 0.0f, cache_start, 1, 128, stream));
+            }
+            STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, M, stream));
         }
-        STEP_TRY(matmul_q(d.oq, d.os, L.o, d.oo, M, stream));
         STEP_TRY(cactus_hip_add_rms_norm_quant_f16_dev(res, d.oo, L.post_norm, d.h2, nullptr, d.xq2, d.xs2, M, Hd, w->eps, stream));
         const Out gu[2] = {{&L.gate, d.go}, {&L.up, d.uo}};
         STEP_TRY(shared_matmuls(d.xq2, d.xs2, gu, 2, M, Hd, stream));
@@ -329,7 +348,7 @@ size_t cactus_hip_decode_step_workspace_bytes(const cactus_hip_decoder_weights* 
 
 int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus_hip_decode_state* kv, void* workspace,
                                cactus_half_t* logits, int advance, void* stream) {
-    if (const char* bad = check_weights(w, false)) return fail(bad);
+    if (const char* bad = check_weights(w)) return fail(bad);
     if (!kv || kv->batch == 0) return fail("decode step: null or empty state");
     if (!workspace || !logits) return fail("decode step: null workspace or logits");
     if (!kv->positions || !kv->cache_lens || !kv->tokens) return fail("decode step: null positions / cache_lens / tokens");
@@ -539,7 +558,7 @@ size_t cactus_hip_prefill_workspace_bytes(const cactus_hip_decoder_weights* w, s
 int cactus_hip_prefill_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* st, const int32_t* tokens,
                            size_t n_tokens, size_t chunk, const int32_t* chunk_starts_dev, void* workspace, size_t lanes,
                            cactus_half_t* logits, int32_t* token_out, void* stream) {
-    if (const char* bad = check_weights(w, true)) return fail(bad);
+    if (const char* bad = check_weights(w)) return fail(bad);
     if (!tokens || !chunk_starts_dev || !workspace || chunk == 0 || n_tokens == 0) return fail("prefill: null or empty operand");
     if (!logits || !token_out) return fail("prefill: null logits / token_out");
     if (lanes == 0) lanes = 1;

@@ -177,7 +177,7 @@ class _DecodeState(C.Structure):
 
 class _PrefillState(C.Structure):
     _fields_ = [("capacity", C.c_size_t), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("k_scales", C.c_void_p),
-                ("v_scales", C.c_void_p)]
+                ("v_scales", C.c_void_p), ("conv_state", C.c_void_p)]
 
 
 _lib = H.lib
@@ -293,29 +293,33 @@ class Qwen3Decode(_DecodeStep):
     launches."""
 
 
-class Qwen3Prefill:
-    """A chunked prefill of one sequence through the Qwen3 op sequence, the way the engine walks a long prompt
-    (Model::prefill, engine_model.cpp:170-219: chunks of `chunk` tokens, the first against nothing, the others against
-    the INT8 cache), through cactus_hip_prefill_chunk_dev: per block norm + activation quantization, q/k/v GEMM, q/k
-    norm + RoPE + cache append, attention (FP16 for chunk 0, INT8-cache hybrid after), o GEMM, add + norm, gate/up GEMM,
-    SiLU x up, down GEMM, add; after the last chunk the final norm, the lm_head on the last token and the greedy
-    sampler.  No window: the cache holds the whole prompt."""
+class Prefill:
+    """A chunked prefill of one sequence, the way the engine walks a long prompt (Model::prefill, engine_model.cpp:
+    170-219: chunks of `chunk` tokens, the first against nothing, the others against the INT8 cache), through
+    cactus_hip_prefill_chunk_dev: per block norm + activation quantization, then either q/k/v GEMM, q/k norm + RoPE +
+    cache append, attention (FP16 for chunk 0, INT8-cache hybrid after), o GEMM, or LFM2's in-projection, short
+    convolution over the rows the previous chunk left, out-projection; add + norm, gate/up GEMM, SiLU x up, down GEMM,
+    add; after the last chunk the final norm, the lm_head on the last token and the greedy sampler.  No window: the
+    cache holds the whole prompt.  kc / vc / ksc / vsc: [attention_blocks, 1, tokens, kv_heads, ...]; conv: half
+    [conv_blocks, 1, conv_rows, hidden] or None."""
 
     def __init__(self, weights, cfg, tokens, chunk):
         c = self.cfg = cfg
         assert tokens % chunk == 0
         self.w, self.tokens, self.chunk, self.nchunks = weights, tokens, chunk, tokens // chunk
         Hkv, D, V = c["kv_heads"], c["head_dim"], c["vocab"]
-        NL = len(weights["layers"])
+        NA = sum("q" in L for L in weights["layers"])
+        NC = len(weights["layers"]) - NA
         G = (D + 127) // 128
         H.rope_reserve(D, c["theta"], tokens + 1)
         self.toks = torch.zeros((self.nchunks, chunk), dtype=torch.int32, device="cuda")
-        self.kc, self.vc = _i8(NL, 1, tokens, Hkv, D), _i8(NL, 1, tokens, Hkv, D)
-        self.ksc, self.vsc = _f32(NL, 1, tokens, Hkv, G), _f32(NL, 1, tokens, Hkv, G)
+        self.kc, self.vc = _i8(NA, 1, tokens, Hkv, D), _i8(NA, 1, tokens, Hkv, D)
+        self.ksc, self.vsc = _f32(NA, 1, tokens, Hkv, G), _f32(NA, 1, tokens, Hkv, G)
+        self.conv = torch.zeros((NC, 1, c["conv_rows"], c["hidden"]), dtype=torch.float16, device="cuda") if NC else None
         self.logits, self.tok = _half(1, V), torch.empty((1,), dtype=torch.int32, device="cuda")
         self.slots = [torch.full((1,), ci * chunk, dtype=torch.int32, device="cuda") for ci in range(self.nchunks)]
         self._desc = describe_model(weights, cfg)
-        self._state = _PrefillState(tokens, _vp(self.kc), _vp(self.vc), _vp(self.ksc), _vp(self.vsc))
+        self._state = _PrefillState(tokens, _vp(self.kc), _vp(self.vc), _vp(self.ksc), _vp(self.vsc), _vp(self.conv))
         nbytes = _lib.cactus_hip_prefill_chunk_workspace_bytes(C.byref(self._desc), chunk)
         self._ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
 
@@ -336,6 +340,10 @@ class Qwen3Prefill:
         H._check(_lib.cactus_hip_prefill_dev(C.byref(self._desc), C.byref(self._state), self.toks.data_ptr(), self.tokens,
                                              self.chunk, self._starts.data_ptr(), self._ws_all.data_ptr(), lanes,
                                              self.logits.data_ptr(), self.tok.data_ptr(), H._stream()))
+
+
+Qwen3Prefill = Prefill
+Lfm2Prefill = Prefill
 
 
 def lfm2_synthetic_weights(gen, batch, cfg=LFM2_1P2B, mixed=False):

@@ -86,16 +86,21 @@ int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus
  * unsplit, 3.22 ms split; LFM2-1.2B shape, 1024 sequences 3.60 / 3.55 ms. */
 size_t cactus_hip_decode_step_split(size_t min_batch);
 
-/* A chunked prefill of ONE sequence through an all-attention model, the way the engine walks a long prompt
- * (Model::prefill, engine_model.cpp:170-219): `chunk` tokens at a time, chunk 0 against nothing (FP16 attention), the
- * others against the INT8 cache.  tokens: device int32[chunk] of this chunk; cache_start = tokens before it;
- * cache_start_dev: device int32 holding cache_start (the append kernel reads it); caches int8 [layers][capacity]
- * [kv_heads][head_dim] / float [layers][capacity][kv_heads][1] with capacity >= cache_start + chunk.  last != 0: also
- * the final norm, the lm_head on the last token into logits half[1, vocab] and the greedy token into *token_out. */
+/* A chunked prefill of ONE sequence, the way the engine walks a long prompt (Model::prefill, engine_model.cpp:170-219):
+ * `chunk` tokens at a time, chunk 0 against nothing (FP16 attention), the others against the INT8 cache.  tokens: device
+ * int32[chunk] of this chunk; cache_start = tokens before it; cache_start_dev: device int32 holding cache_start (the
+ * append kernel reads it); caches cover the attention blocks in block order: int8 [attention_blocks][capacity][kv_heads]
+ * [head_dim] / float [attention_blocks][capacity][kv_heads][1] with capacity >= cache_start + chunk.  conv_state: half
+ * [conv_blocks][conv_rows][hidden] in block order, the rows LFM2's short convolutions carry from chunk to chunk
+ * (model_lfm2.cpp:166-191); chunk 0 (cache_start == 0) clears it; NULL for a model without such blocks.  With one
+ * sequence the caches and conv_state have the layout of cactus_hip_decode_state with batch 1 and slots = capacity: a
+ * decode step carries on from them.  last != 0: also the final norm, the lm_head on the last token into logits
+ * half[1, vocab] and the greedy token into *token_out. */
 typedef struct cactus_hip_prefill_state {
     size_t capacity;
     int8_t *k_cache, *v_cache;
     float *k_scales, *v_scales;
+    cactus_half_t* conv_state;
 } cactus_hip_prefill_state;
 size_t cactus_hip_prefill_chunk_workspace_bytes(const cactus_hip_decoder_weights* w, size_t chunk);
 int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* state,
@@ -104,10 +109,11 @@ int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cact
 
 /* The whole prompt: every chunk of cactus_hip_prefill_chunk_dev in one call (Model::prefill's loop, engine_model.cpp:
  * 170-219), up to `lanes` (1 .. 8) chunks in flight at a time.  A chunk's launches are short and leave most of the chip
- * idle, and chunk c + 1 needs nothing of chunk c but its rows in a block's cache when it reaches that block's attention:
- * chunk c runs on stream c % lanes (lane 0 = `stream`, the others the library's own, forked from and joined to `stream`,
- * so a capture of `stream` takes in all of them), records an event per block once its K / V rows are appended, and its
- * attention in a block waits for the previous chunk's event of that block.  The results are those of the chunks called
+ * idle, and chunk c + 1 needs nothing of chunk c but its rows in a block's cache when it reaches that block's attention
+ * (or the rows it left in a convolution block's state when it reaches that convolution): chunk c runs on stream
+ * c % lanes (lane 0 = `stream`, the others the library's own, forked from and joined to `stream`, so a capture of
+ * `stream` takes in all of them), records an event per block once its K / V rows are appended (its convolution has
+ * run), and its attention (convolution) in a block waits for the previous chunk's event of that block.  The results are those of the chunks called
  * one after the other, bit for bit.  tokens: device int32[n_tokens]; the last chunk may be short; chunk_starts_dev:
  * device int32[chunks] holding c * chunk; workspace: cactus_hip_prefill_workspace_bytes(w, chunk, lanes) bytes (call it
  * outside any stream capture: it also creates the streams and events); logits half[1, vocab] and *token_out receive the

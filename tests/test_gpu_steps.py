@@ -260,18 +260,11 @@ def conv_rows(cc):
     return torch.from_numpy(st.view(np.float16)).cuda()
 
 
-@pytest.mark.parametrize("mixed", [False, True])
-def test_lfm2_batched_decode_matches_oracle_per_sequence(ST, mixed, monkeypatch):
-    """A cut-down LFM2 (conv, conv, attention, conv, attention; hidden 2048, ffn 2048, vocabulary 4096) for 5
-    sequences of different lengths: conv state rows and INT8 caches per sequence on the device.
-    mixed: packed INT4 for attn_v / attn_output / the MLP (the converter's MIXED policy, python/src/precision_config.py:
-    52-124, here in every block so that a cut-down model has some); the convolution projections, attn_q / attn_k and the
-    embedding stay INT8."""
+def make_lfm2(ST, rng, types, mixed, vocab=4096, ffn=2048):
+    """A cut-down LFM2 (one block per letter of `types`: c = short convolution, a = attention; hidden 2048): the host
+    model, its device copy and the configuration."""
     from tests import test_gpu_greedy_decode as GD
-    monkeypatch.setattr(GD, "omm", omm)       # the oracle matmul that also takes packed INT4
     c = GD.LFM
-    rng = np.random.default_rng(5 + mixed)
-    types, vocab, ffn, steps = "ccaca", 4096, 2048, 6
 
     def mat(n, k, g, tolerant=False):
         if mixed and tolerant:
@@ -301,6 +294,22 @@ def test_lfm2_batched_decode_matches_oracle_per_sequence(ST, mixed, monkeypatch)
     for L in dm["layers"]:
         if "conv_w" in L:
             L["conv_w"] = L["conv_w"].reshape(c["HID"], c["K"]).contiguous()
+    return m, dm, cfg
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_lfm2_batched_decode_matches_oracle_per_sequence(ST, mixed, monkeypatch):
+    """A cut-down LFM2 (conv, conv, attention, conv, attention; hidden 2048, ffn 2048, vocabulary 4096) for 5
+    sequences of different lengths: conv state rows and INT8 caches per sequence on the device.
+    mixed: packed INT4 for attn_v / attn_output / the MLP (the converter's MIXED policy, python/src/precision_config.py:
+    52-124, here in every block so that a cut-down model has some); the convolution projections, attn_q / attn_k and the
+    embedding stay INT8."""
+    from tests import test_gpu_greedy_decode as GD
+    monkeypatch.setattr(GD, "omm", omm)       # the oracle matmul that also takes packed INT4
+    c = GD.LFM
+    rng = np.random.default_rng(5 + mixed)
+    types, steps = "ccaca", 6
+    m, dm, cfg = make_lfm2(ST, rng, types, mixed)
     lens = (4, 9, 2, 13, 7)
     batch = len(lens)
     dec = ST.Lfm2Decode(dm, cfg, batch, 64, max_position=128)
@@ -308,7 +317,7 @@ def test_lfm2_batched_decode_matches_oracle_per_sequence(ST, mixed, monkeypatch)
     for b, n in enumerate(lens):
         kv = [None] * len(types)
         conv = [O.Lfm2ConvState(c["W"], c["HID"]) for _ in types]
-        prompt = rng.integers(0, vocab, n).tolist()
+        prompt = rng.integers(0, cfg["vocab"], n).tolist()
         lg = GD.lfm2_oracle_forward(m, prompt, 0, kv, conv)
         toks.append(int(O.sample_greedy(lg.view(np.float16)[None])[0]))
         kvs.append(kv); convs.append(conv)
@@ -332,6 +341,48 @@ def test_lfm2_batched_decode_matches_oracle_per_sequence(ST, mixed, monkeypatch)
             for li in dec.state:
                 dec.state[li][b] = conv_rows(convs[b][li])
     assert ck.near_ties <= 2
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_lfm2_chunked_prefill_matches_oracle(ST, mixed, monkeypatch):
+    """Three chunks of 32 tokens through conv, conv, attention, conv, attention blocks: the convolution rows carried
+    from chunk to chunk on the device, chunk 0 with FP16 attention and the others against the INT8 cache; the last
+    token's logits and greedy choice, the rows the first convolution block is left holding (bit-exact: nothing but the
+    embedding, a norm and the in-projection in front of them) and the K cache.  Then the same prompt with three chunks
+    in flight, which must leave the same bits everywhere."""
+    from tests import test_gpu_greedy_decode as GD
+    monkeypatch.setattr(GD, "omm", omm)
+    c = GD.LFM
+    rng = np.random.default_rng(15 + mixed)
+    types, tokens, chunk = "ccaca", 96, 32
+    m, dm, cfg = make_lfm2(ST, rng, types, mixed)
+    pf = ST.Lfm2Prefill(dm, cfg, tokens, chunk)
+    pf.conv.fill_(3.0)                       # chunk 0 must not use what an earlier prompt left
+    prompt = rng.integers(0, cfg["vocab"], tokens)
+    pf.toks.copy_(torch.from_numpy(prompt.reshape(-1, chunk).astype(np.int32)))
+    kv = [None] * len(types)
+    conv = [O.Lfm2ConvState(c["W"], c["HID"]) for _ in types]
+    for ci in range(tokens // chunk):
+        pf.run_chunk(ci)
+        lg_o = GD.lfm2_oracle_forward(m, prompt[ci * chunk:(ci + 1) * chunk].tolist(), ci * chunk, kv, conv)
+    torch.cuda.synchronize()
+    StepChecker().check(pf.logits.cpu().numpy()[0], int(pf.tok.cpu()[0]), lg_o, "lfm2 prefill")
+    assert torch.equal(pf.conv[0, 0], conv_rows(conv[0]))
+    attn_at = cfg["attention_layers"]
+    frac = [(np.abs(pf.kc[ai, 0].cpu().numpy().astype(np.int32) - kv[li][0].astype(np.int32)) <= 1).mean()
+            for ai, li in enumerate(attn_at)]
+    assert min(frac) > 0.9, frac
+    for ai, li in enumerate([i for i, t in enumerate(types) if t == "c"]):
+        want = conv_rows(conv[li]).float()       # blocks behind an attention: fp16 ulps upstream, a few flipped INT8 values
+        close = ((pf.conv[ai, 0].float() - want).abs() <= 0.05 * want.abs().max()).float().mean()
+        assert close > 0.9, (li, float(close))
+    ref = [t.clone() for t in (pf.logits, pf.tok, pf.kc, pf.vc, pf.ksc, pf.vsc, pf.conv)]
+    for t in (pf.logits, pf.kc, pf.vc, pf.conv):
+        t.fill_(1)
+    pf.run(lanes=3)
+    torch.cuda.synchronize()
+    for a, b in zip(ref, (pf.logits, pf.tok, pf.kc, pf.vc, pf.ksc, pf.vsc, pf.conv)):
+        assert torch.equal(a, b)
 
 
 # ------------------------------------------------------------------ per-sequence positions and the ring window
