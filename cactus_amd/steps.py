@@ -267,6 +267,21 @@ class _DecodeStep:
         nbytes = _lib.cactus_hip_decode_step_workspace_bytes(C.byref(self._desc), batch)
         self._ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
 
+    def adopt(self, prefill):
+        """Carry on from a prefill of one sequence: the decode state points at the prefill's caches and convolution rows
+        (same layout at batch 1 with slots = the prefill's capacity), position = the prompt length, token = its choice."""
+        kv = self.kv
+        assert self.batch == 1 and not kv.window and kv.slots == prefill.capacity
+        kv.kc, kv.vc, kv.ksc, kv.vsc = prefill.kc, prefill.vc, prefill.ksc, prefill.vsc
+        if self._conv is not None:
+            self._conv = prefill.conv
+            self.state = {li: self._conv[i] for i, li in enumerate(sorted(self.state))}
+        st = self._state
+        st.k_cache, st.v_cache, st.k_scales, st.v_scales = _vp(kv.kc), _vp(kv.vc), _vp(kv.ksc), _vp(kv.vsc)
+        st.conv_state = _vp(self._conv)
+        kv.set_positions([prefill.tokens])
+        kv.tok.copy_(prefill.tok)
+
     def step(self, advance=True):
         self.kv.check_room()
         H._check(_lib.cactus_hip_decode_step_dev(C.byref(self._desc), C.byref(self._state), self._ws.data_ptr(),
@@ -303,7 +318,7 @@ class Prefill:
     cache holds the whole prompt.  kc / vc / ksc / vsc: [attention_blocks, 1, tokens, kv_heads, ...]; conv: half
     [conv_blocks, 1, conv_rows, hidden] or None."""
 
-    def __init__(self, weights, cfg, tokens, chunk):
+    def __init__(self, weights, cfg, tokens, chunk, capacity=None):
         c = self.cfg = cfg
         assert tokens % chunk == 0
         self.w, self.tokens, self.chunk, self.nchunks = weights, tokens, chunk, tokens // chunk
@@ -311,15 +326,17 @@ class Prefill:
         NA = sum("q" in L for L in weights["layers"])
         NC = len(weights["layers"]) - NA
         G = (D + 127) // 128
-        H.rope_reserve(D, c["theta"], tokens + 1)
+        cap = self.capacity = capacity or tokens        # cache slots: room for the tokens a decode adds afterwards
+        assert cap >= tokens
+        H.rope_reserve(D, c["theta"], cap + 1)
         self.toks = torch.zeros((self.nchunks, chunk), dtype=torch.int32, device="cuda")
-        self.kc, self.vc = _i8(NA, 1, tokens, Hkv, D), _i8(NA, 1, tokens, Hkv, D)
-        self.ksc, self.vsc = _f32(NA, 1, tokens, Hkv, G), _f32(NA, 1, tokens, Hkv, G)
+        self.kc, self.vc = _i8(NA, 1, cap, Hkv, D), _i8(NA, 1, cap, Hkv, D)
+        self.ksc, self.vsc = _f32(NA, 1, cap, Hkv, G), _f32(NA, 1, cap, Hkv, G)
         self.conv = torch.zeros((NC, 1, c["conv_rows"], c["hidden"]), dtype=torch.float16, device="cuda") if NC else None
         self.logits, self.tok = _half(1, V), torch.empty((1,), dtype=torch.int32, device="cuda")
         self.slots = [torch.full((1,), ci * chunk, dtype=torch.int32, device="cuda") for ci in range(self.nchunks)]
         self._desc = describe_model(weights, cfg)
-        self._state = _PrefillState(tokens, _vp(self.kc), _vp(self.vc), _vp(self.ksc), _vp(self.vsc), _vp(self.conv))
+        self._state = _PrefillState(cap, _vp(self.kc), _vp(self.vc), _vp(self.ksc), _vp(self.vsc), _vp(self.conv))
         nbytes = _lib.cactus_hip_prefill_chunk_workspace_bytes(C.byref(self._desc), chunk)
         self._ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
 

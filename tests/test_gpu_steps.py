@@ -356,7 +356,7 @@ def test_lfm2_chunked_prefill_matches_oracle(ST, mixed, monkeypatch):
     rng = np.random.default_rng(15 + mixed)
     types, tokens, chunk = "ccaca", 96, 32
     m, dm, cfg = make_lfm2(ST, rng, types, mixed)
-    pf = ST.Lfm2Prefill(dm, cfg, tokens, chunk)
+    pf = ST.Lfm2Prefill(dm, cfg, tokens, chunk, capacity=tokens + 8)
     pf.conv.fill_(3.0)                       # chunk 0 must not use what an earlier prompt left
     prompt = rng.integers(0, cfg["vocab"], tokens)
     pf.toks.copy_(torch.from_numpy(prompt.reshape(-1, chunk).astype(np.int32)))
@@ -369,7 +369,7 @@ def test_lfm2_chunked_prefill_matches_oracle(ST, mixed, monkeypatch):
     StepChecker().check(pf.logits.cpu().numpy()[0], int(pf.tok.cpu()[0]), lg_o, "lfm2 prefill")
     assert torch.equal(pf.conv[0, 0], conv_rows(conv[0]))
     attn_at = cfg["attention_layers"]
-    frac = [(np.abs(pf.kc[ai, 0].cpu().numpy().astype(np.int32) - kv[li][0].astype(np.int32)) <= 1).mean()
+    frac = [(np.abs(pf.kc[ai, 0, :tokens].cpu().numpy().astype(np.int32) - kv[li][0].astype(np.int32)) <= 1).mean()
             for ai, li in enumerate(attn_at)]
     assert min(frac) > 0.9, frac
     for ai, li in enumerate([i for i, t in enumerate(types) if t == "c"]):
@@ -382,7 +382,19 @@ def test_lfm2_chunked_prefill_matches_oracle(ST, mixed, monkeypatch):
     pf.run(lanes=3)
     torch.cuda.synchronize()
     for a, b in zip(ref, (pf.logits, pf.tok, pf.kc, pf.vc, pf.ksc, pf.vsc, pf.conv)):
-        assert torch.equal(a, b)
+        assert torch.equal(a[..., :tokens, :, :] if a.dim() == 5 else a, b[..., :tokens, :, :] if b.dim() == 5 else b)
+    # a decode step carries on from the prefill's buffers: three tokens against the oracle, which carries on from its own
+    dec = ST.Lfm2Decode(dm, cfg, 1, tokens + 8, max_position=tokens + 8)
+    dec.adopt(pf)
+    ck = StepChecker()
+    tok = int(O.sample_greedy(lg_o.view(np.float16)[None])[0])
+    for step in range(3):
+        dec.kv.tok.copy_(torch.tensor([tok], dtype=torch.int32))
+        dec.step()
+        torch.cuda.synchronize()
+        lg_o = GD.lfm2_oracle_forward(m, [tok], tokens + step, kv, conv)
+        tok, _ = ck.check(dec.logits.cpu().numpy()[0], int(dec.kv.tok.cpu()[0]), lg_o, ("decode after prefill", step))
+    assert dec.kv.positions.cpu().tolist() == [tokens + 3]
 
 
 # ------------------------------------------------------------------ per-sequence positions and the ring window
