@@ -75,6 +75,7 @@ __device__ __forceinline__ float halves_sum(float x) {
 #ifndef PF_TIMING
 #define PF_TIMING 0
 #endif
+
 // head_dim 256: the Q rows and the output accumulators of a lane alone are 192 registers, so that variant runs one
 // wave per SIMD with the whole register file
 template <int D>
@@ -694,66 +695,78 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
             }
         }
     };
-    // softmax of one block from sacc (kernel_attention.cpp:160-204): updates m_run, l_run, rescales O, leaves the
-    // weights as hi + lo binary16 parts.  FULL: all 32 keys visible to all 32 queries of the wave.
-    auto softmax = [&](auto full_tag, int kb, int ke) __attribute__((always_inline)) {
+    // softmax of one block from sacc (kernel_attention.cpp:160-204), leaving the weights as hi + lo binary16 parts.
+    // FULL: all 32 keys visible to all 32 queries of the wave.
+    // The reference rescales (l, O) by exp(m_prev - bm) at every block, bm the block's own maximum; the output O / l does
+    // not depend on the scale the two are held on, so here they stay on the scale of m_run, the maximum of the block at
+    // which they were last rescaled, and a block's weights are multiplied by f = exp(bm - m_run) instead (16 products
+    // in place of head_dim / 2); (l, O) move to a new scale only when f would pass e^8 (binary16 weights, fp32 sums).
+    // The polynomial's argument is still relative to the block's own maximum, as the reference's is.
+    // x = (s - bm) * scale * log2e <= 0 is formed from the difference of the raw scores (exactly 0 for the maximum);
+    // with z = -x: trunc(x) = -floor(z) and x - trunc(x) = -fract(z).
+    // Returns the factor (l, O) still have to be multiplied by (1: none); the caller applies it to O outside the
+    // branches that select this lambda's variants, in place.
+    auto softmax = [&](auto full_tag, int kb, int ke) __attribute__((always_inline)) -> float {
         constexpr bool FULL = decltype(full_tag)::value;
         const int vec = ((ke - kb) / 4) * 4;
         const int lim_blk = ke - kb;
         const int lim = a.is_causal ? (int)max(-1LL, min((long long)lim_blk, qabs - kb + 1)) : lim_blk;
         const int limg = lim - 4 * g;
-        float sc[16], wgt[16];
-        float bm = -INFINITY, bsum = 0.0f;
-        if constexpr (FULL) {
+        float bs = -INFINITY;
+        if constexpr (!FULL) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[r] = sacc[r] * scale;
-                bm = fmaxf(bm, sc[r]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                sc[r] = (8 * (r >> 2) + (r & 3) < limg) ? sacc[r] * scale : -INFINITY;
-                bm = fmaxf(bm, sc[r]);
-            }
+            for (int r = 0; r < 16; r++) sacc[r] = (8 * (r >> 2) + (r & 3) < limg) ? sacc[r] : -INFINITY;
         }
-        bm = halves_max(bm);
-        if (FULL || bm > -INFINITY) {
-            const float corr = __expf(m_run - bm);
+#pragma unroll
+        for (int r = 0; r < 16; r++) bs = fmaxf(bs, sacc[r]);
+        bs = halves_max(bs);
+        if (!FULL && bs == -INFINITY) {       // no key of the block is visible to this query
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) { phi[ks][e] = (_Float16)0.0f; plo[ks][e] = (_Float16)0.0f; }
+            return 1.0f;
+        }
+        const float bm = bs * scale;
+        float dm = bm - m_run;                // +inf at the first block
+        float corr = 1.0f;
+        if (dm > 8.0f) {
+            corr = __expf(m_run - bm);
             l_run *= corr;
-#pragma unroll
-            for (int dt = 0; dt < NDT; dt++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) o[dt][r] *= corr;
             m_run = bm;
+            dm = 0.0f;
         }
+        const float f = __expf(dm);
+        // (written with packed fp32 operations, 63 of 190 instructions instead of 250 single ones, the block takes as long)
+        const float c1 = scale * 1.442695f;
+        const float fk1 = f * -0.6931472f, fk2 = f * 0.2402265f;     // the weights leave the polynomial already times f
         const int vecg = vec - 4 * g;
+        float wsum0 = 0.0f, wsum1 = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float x = (sc[r] - bm) * 1.442695f;
-            const int xi = (int)x;
-            const float xf = x - (float)xi;
-            float y = fmaf(xf, 0.6931472f, 1.0f);
-            y = fmaf(xf * xf, 0.2402265f, y);
-            float wv = y * __uint_as_float(((uint32_t)xi + 127u) << 23);
+            bool vis = true;
+            float raw = sacc[r];
             if constexpr (!FULL) {
-                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(sc[r] - bm);
-                wv = (sc[r] == -INFINITY) ? 0.0f : wv;
+                vis = raw > -INFINITY;
+                raw = vis ? raw : bs;
             }
-            wgt[r] = wv;
-            bsum += wv;
+            const float dz = bs - raw;
+            const float z = dz * c1;
+            const float zf = __builtin_amdgcn_fractf(z);
+            float y = fmaf(zf, fk1, f);
+            y = fmaf(zf * zf, fk2, y);
+            float wv = __builtin_amdgcn_ldexpf(y, (int)(-z));
+            if constexpr (!FULL) {
+                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(-(dz * scale)) * f;
+                wv = vis ? wv : 0.0f;
+            }
+            if (r & 1) wsum1 += wv; else wsum0 += wv;
+            const _Float16 hi = (_Float16)wv;
+            phi[r >> 3][r & 7] = hi;
+            plo[r >> 3][r & 7] = (_Float16)fmaf((float)hi, -1.0f, wv);
         }
-        bsum = halves_sum(bsum);
-        l_run += bsum;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const float wv = wgt[8 * ks + e];
-                const _Float16 hi = (_Float16)wv;
-                phi[ks][e] = hi;
-                plo[ks][e] = (_Float16)(wv - (float)hi);
-            }
+        l_run += halves_sum(wsum0 + wsum1);
+        return corr;
     };
 
     // prologue: K of the group's first block into LDS
@@ -788,12 +801,19 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
         stash_rows(sK, KROW, kst);       // K of block it + 1
         stash_rows(sV, VROW, vst);       // V of block it
         PF_T(t3);
+        float corr = 1.0f;
         if (live) {
             const int ke = min(KV, kb + PF_BLOCK);
             if (ke - kb == PF_BLOCK && (!a.is_causal || off + q_first - kb + 1 >= PF_BLOCK) && q_first + 31 < S)
-                softmax(std::true_type{}, kb, ke);
+                corr = softmax(std::true_type{}, kb, ke);
             else
-                softmax(std::false_type{}, kb, ke);
+                corr = softmax(std::false_type{}, kb, ke);
+        }
+        if (corr != 1.0f) {
+#pragma unroll
+            for (int dt = 0; dt < NDT; dt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) o[dt][r] *= corr;
         }
         pv_pending = live;
 #ifdef PF_TRACE
