@@ -706,6 +706,8 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
     // with z = -x: trunc(x) = -floor(z) and x - trunc(x) = -fract(z).
     // Returns the factor (l, O) still have to be multiplied by (1: none); the caller applies it to O outside the
     // branches that select this lambda's variants, in place.
+    float minus_one = -1.0f;
+    asm volatile("" : "+v"(minus_one));
     auto softmax = [&](auto full_tag, int kb, int ke) __attribute__((always_inline)) -> float {
         constexpr bool FULL = decltype(full_tag)::value;
         const int vec = ((ke - kb) / 4) * 4;
@@ -738,7 +740,9 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
         }
         const float f = __expf(dm);
         // (written with packed fp32 operations, 63 of 190 instructions instead of 250 single ones, the block takes as long)
-        const float c1 = scale * 1.442695f;
+        // z = (bs - s) * c1 as |bs * c1 - s * c1|, one fused operation (the absolute value is an operand modifier of the
+        // instructions that read z): a rounding that leaves the maximum's own z a hair under 0 must not reach fract()
+        const float c1 = scale * 1.442695f, bsc = bs * c1;
         const float fk1 = f * -0.6931472f, fk2 = f * 0.2402265f;     // the weights leave the polynomial already times f
         const int vecg = vec - 4 * g;
         float wsum0 = 0.0f, wsum1 = 0.0f;
@@ -750,20 +754,21 @@ void attn_prefill_pp_kernel(const AttnArgs a) {
                 vis = raw > -INFINITY;
                 raw = vis ? raw : bs;
             }
-            const float dz = bs - raw;
-            const float z = dz * c1;
+            const float z = fabsf(fmaf(raw, -c1, bsc));
             const float zf = __builtin_amdgcn_fractf(z);
             float y = fmaf(zf, fk1, f);
             y = fmaf(zf * zf, fk2, y);
             float wv = __builtin_amdgcn_ldexpf(y, (int)(-z));
             if constexpr (!FULL) {
-                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(-(dz * scale)) * f;
+                if (vec != PF_BLOCK && !(8 * (r >> 2) + (r & 3) < vecg)) wv = __expf(-((bs - raw) * scale)) * f;
                 wv = vis ? wv : 0.0f;
             }
             if (r & 1) wsum1 += wv; else wsum0 += wv;
+            // hi + lo: the low part straight from the binary16 high part in one mixed-precision fma (minus_one is opaque
+            // to the compiler, which would otherwise turn the fma into a conversion and a subtraction)
             const _Float16 hi = (_Float16)wv;
             phi[r >> 3][r & 7] = hi;
-            plo[r >> 3][r & 7] = (_Float16)fmaf((float)hi, -1.0f, wv);
+            plo[r >> 3][r & 7] = (_Float16)fmaf((float)hi, minus_one, wv);
         }
         l_run += halves_sum(wsum0 + wsum1);
         return corr;
