@@ -878,6 +878,13 @@ template <bool INT4, int W, int P, int CT>
 #ifndef SK_BATCH_P
 #define SK_BATCH_P 4
 #endif
+// Ring depth of the batched launches on packed INT4 weights.  A wave walks its units in whole rounds of the ring, and
+// a packed row has half the units: K = 1024 split over two waves is 2 units per wave, which a ring of 4 pads with two
+// empty ones (their loads return zeros, their MFMAs still run).  16-shape INT4 sweep by depth 1 / 2 / 3 / 4 / 8:
+// 25.4 / 25.2 / 29.5 / 27.9 / 39.4 us (INT8 at 2 / 3 / 4: 39.8 / 40.2 / 39.8).
+#ifndef SK_BATCH_P4
+#define SK_BATCH_P4 2
+#endif
 #if SK_WPE
 #define SK_WPE_ATTR __attribute__((amdgpu_waves_per_eu(SK_WPE, SK_WPE)))
 #else
@@ -1233,7 +1240,7 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
             bt.tile_end[i] = (int)blocks;
         }
         if (lds_sub <= 64 * 1024) {
-            if (int4) skinny_batch_sub_kernel<true, SK_BATCH_P><<<dim3((unsigned)blocks), dim3(256), lds_sub, st>>>(bt);
+            if (int4) skinny_batch_sub_kernel<true, SK_BATCH_P4><<<dim3((unsigned)blocks), dim3(256), lds_sub, st>>>(bt);
             else skinny_batch_sub_kernel<false, SK_BATCH_P><<<dim3((unsigned)blocks), dim3(256), lds_sub, st>>>(bt);
             return hipGetLastError();
         }
@@ -1310,7 +1317,7 @@ hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyPr
     const dim3 grid((unsigned)blocks), block(256);
 #define FQP_CASE(KIND)                                                                                        \
     case KIND:                                                                                                \
-        if (int4) skinny_batch_sub_kernel<true, SK_BATCH_P, KIND><<<grid, block, lds_sub, st>>>(bt);          \
+        if (int4) skinny_batch_sub_kernel<true, SK_BATCH_P4, KIND><<<grid, block, lds_sub, st>>>(bt);         \
         else skinny_batch_sub_kernel<false, SK_BATCH_P, KIND><<<grid, block, lds_sub, st>>>(bt);              \
         break;
     switch (kind) { FQP_CASE(1) FQP_CASE(2) FQP_CASE(3) }
