@@ -1027,10 +1027,16 @@ hipError_t launch_cfg(const int8_t* A, const float* A_scales_c, const void* B, c
 
 }  // namespace
 
+#ifndef SK_FQ_UPW4
+#define SK_FQ_UPW4 4
+#endif
+#ifndef SK_FQ_UPW8
+#define SK_FQ_UPW8 8
+#endif
 static int skinny_waves(bool int4, size_t K) {
     const size_t nu = K / (int4 ? 256 : 128);
     int W = 1;
-    while (W < 8 && (size_t)W * 8 <= nu) W *= 2;
+    while (W < 8 && (size_t)W * (int4 ? SK_FQ_UPW4 : SK_FQ_UPW8) <= nu) W *= 2;
     return W;
 }
 
@@ -1083,8 +1089,18 @@ static hipError_t launch_fq(bool int4, int W, int ct, const uint16_t* X, float* 
 #ifdef FQ_TRACE
     pk_arg |= (g_fq_trace_next++ + 1) << 1;
 #endif
+// Ring depth of the single fused-quantization launches (units in flight per wave) and the least units a wave takes
+// before a tile gets another wave.  M = 1, tile-major twins, by (depth, least units): INT4 8192^2 (4, 8) 10.7 us,
+// (2, 8) 9.85, (2, 4) 9.8, (1, 4) 9.8, (3, 6) 11.4; 2048 x 8192 6.5 / 6.2 / 5.5 / 5.2 / 7.2; INT8 8192^2 (4, 8) 13.5,
+// (2, 8) 13.0, (2, 4) 12.95; 2048 x 8192 5.9 / 5.55 / 6.0.
+#ifndef SK_FQ_P4
+#define SK_FQ_P4 2
+#endif
+#ifndef SK_FQ_P8
+#define SK_FQ_P8 2
+#endif
 #define FQ_LAUNCH(I4, WW, CC)                                                                                     \
-    skinny_fq_kernel<I4, WW, 4, CC><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C,       \
+    skinny_fq_kernel<I4, WW, (I4 ? SK_FQ_P4 : SK_FQ_P8), CC><<<grid, block, lds, st>>>(X, scales_out, (const uint8_t*)B, B_scales, C,       \
                                                              (int)M, (int)K, (int)N, pk_arg)
 #define FQ_CASE(WW)                                                        \
     case WW:                                                                \
