@@ -1140,7 +1140,7 @@ hipError_t launch_matmul_skinny_variant(int variant, bool int4, const int8_t* A,
     switch (variant) {
         SK_CASE(4, 2) SK_CASE(4, 4) SK_CASE(4, 8) SK_CASE(8, 2) SK_CASE(8, 4) SK_CASE(8, 8)
         SK_CASE(16, 2) SK_CASE(16, 4) SK_CASE(2, 4) SK_CASE(2, 8) SK_CASE(8, 1) SK_CASE(4, 1) SK_CASE(2, 2)
-        SK_CASE(16, 1) SK_CASE(1, 4) SK_CASE(1, 8)
+        SK_CASE(16, 1) SK_CASE(1, 4) SK_CASE(1, 8) SK_CASE(1, 2) SK_CASE(1, 1) SK_CASE(2, 1)
         default: return hipErrorInvalidValue;
     }
 #undef SK_CASE
@@ -1353,16 +1353,24 @@ bool skinny_fq_pro_ok(bool int4, int kind, size_t M, size_t K) {
 hipError_t launch_matmul_skinny(bool int4, const int8_t* A, const float* A_scales, const void* B,
                                 const uint16_t* B_scales, uint16_t* C, int32_t* gsums, size_t M,
                                 size_t K, size_t N, hipStream_t st, bool packed) {
-    // Measured on MI355X (scripts/gemv_bench): ring depth 4 everywhere; about 4 units per wave,
-    // i.e. short rows get few waves per tile (more, smaller workgroups in flight) and long rows 8.
+    // Measured on MI355X (scripts/m16_probe.py, M = 16, tile-major twins): ring depth 2, a further wave per 4 units of
+    // a row (short rows get few waves per tile: more, smaller workgroups in flight; long rows 8).  Against depth 4 and
+    // 8 units per wave: INT4 8192^2 16.3 -> 13.8 us, 151936 x 1024 41.1 -> 34.9, 1024^2 5.8 -> 4.6; INT8 the same
+    // within 2 % (1024^2 4.2 -> 3.7).
+#ifndef SK_DEF_UPW
+#define SK_DEF_UPW 4
+#endif
+#ifndef SK_DEF_P
+#define SK_DEF_P 2
+#endif
     const size_t nu = K / (int4 ? 256 : 128);
     int W = 1;
-    while (W < 8 && (size_t)W * 8 <= nu) W *= 2;
+    while (W < 8 && (size_t)W * SK_DEF_UPW <= nu) W *= 2;
     // activations through LDS whenever activations + group sums + scales fit 64 KB
     const size_t G = K / 128;
     const size_t lds_alds = (M * 16 * (G + 8 + 4) + 16 * (G + 8)) * sizeof(float) + M * K;
     const bool alds = M <= 4 && lds_alds <= 60 * 1024;
-    return launch_matmul_skinny_variant((alds ? 10000 : 0) + W * 100 + 4 + (packed ? 40000 : 0), int4, A, A_scales, B,
+    return launch_matmul_skinny_variant((alds ? 10000 : 0) + W * 100 + SK_DEF_P + (packed ? 40000 : 0), int4, A, A_scales, B,
                                         B_scales, C, gsums, M, K, N, st);
 }
 

@@ -14,7 +14,7 @@ Ms = [int(v) for v in sys.argv[1:]] or [8, 16, 17, 32]
 for int4 in (False, True):
     for K, N in shapes:
         nb = min(64, max(2, int(600e6 // max(1, (N * K // (2 if int4 else 1)))) + 1))
-        ws = [make_weights(K, N, int4, gen) for _ in range(nb)]
+        ws = [make_weights(K, N, int4, gen, pack=os.environ.get('PACK', '1') == '1') for _ in range(nb)]
         row = []
         for M in Ms:
             x = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).half()
