@@ -320,8 +320,7 @@ class Prefill:
 
     def __init__(self, weights, cfg, tokens, chunk, capacity=None):
         c = self.cfg = cfg
-        assert tokens % chunk == 0
-        self.w, self.tokens, self.chunk, self.nchunks = weights, tokens, chunk, tokens // chunk
+        self.w, self.tokens, self.chunk, self.nchunks = weights, tokens, chunk, (tokens + chunk - 1) // chunk   # the last may be short
         Hkv, D, V = c["kv_heads"], c["head_dim"], c["vocab"]
         NA = sum("q" in L for L in weights["layers"])
         NC = len(weights["layers"]) - NA
@@ -329,7 +328,9 @@ class Prefill:
         cap = self.capacity = capacity or tokens        # cache slots: room for the tokens a decode adds afterwards
         assert cap >= tokens
         H.rope_reserve(D, c["theta"], cap + 1)
-        self.toks = torch.zeros((self.nchunks, chunk), dtype=torch.int32, device="cuda")
+        self._toks_all = torch.zeros((self.nchunks * chunk,), dtype=torch.int32, device="cuda")
+        self.toks = self._toks_all.view(self.nchunks, chunk)       # row ci: chunk ci's ids (a short last chunk: its head)
+        self.prompt = self._toks_all[:tokens]
         self.kc, self.vc = _i8(NA, 1, cap, Hkv, D), _i8(NA, 1, cap, Hkv, D)
         self.ksc, self.vsc = _f32(NA, 1, cap, Hkv, G), _f32(NA, 1, cap, Hkv, G)
         self.conv = torch.zeros((NC, 1, c["conv_rows"], c["hidden"]), dtype=torch.float16, device="cuda") if NC else None
@@ -343,7 +344,7 @@ class Prefill:
     def run_chunk(self, ci):
         last = ci + 1 == self.nchunks
         H._check(_lib.cactus_hip_prefill_chunk_dev(C.byref(self._desc), C.byref(self._state), self.toks[ci].data_ptr(),
-                                                   self.chunk, ci * self.chunk, self.slots[ci].data_ptr(), self._ws.data_ptr(),
+                                                   min(self.chunk, self.tokens - ci * self.chunk), ci * self.chunk, self.slots[ci].data_ptr(), self._ws.data_ptr(),
                                                    int(last), self.logits.data_ptr(), self.tok.data_ptr(), H._stream()))
 
     def run(self, lanes=4):

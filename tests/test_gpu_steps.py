@@ -250,6 +250,35 @@ def test_qwen3_single_chunk_prefill_matches_oracle(ST):
     assert np.array_equal(pf.ksc[0, 0].cpu().numpy(), caches[0][1])
 
 
+def test_qwen3_prefill_with_a_short_last_chunk(ST):
+    """200 tokens in chunks of 64: the last chunk holds 8 (its matmuls run on the streaming kernels, its attention with
+    fewer than 32 queries on the vector-ALU kernel); chunk by chunk against the oracle, then the whole prompt in one call
+    with three chunks in flight against the chunk loop, bit for bit."""
+    layers, vocab, tokens, chunk = 4, 8192, 200, 64
+    rng = np.random.default_rng(81)
+    m = make_model(rng, layers, vocab, 0.05, False)
+    cfg = dict(ST.QWEN3_0P6B, layers=layers, vocab=vocab)
+    pf = ST.Qwen3Prefill(ST.weights_to_device(m), cfg, tokens, chunk)
+    assert pf.nchunks == 4
+    prompt = rng.integers(0, vocab, tokens)
+    pf.prompt.copy_(torch.from_numpy(prompt.astype(np.int32)))
+    caches = [None] * layers
+    for ci in range(pf.nchunks):
+        pf.run_chunk(ci)
+        lg_o = oracle_forward(m, prompt[ci * chunk:(ci + 1) * chunk].tolist(), ci * chunk, caches)
+    torch.cuda.synchronize()
+    StepChecker().check(pf.logits.cpu().numpy()[0], int(pf.tok.cpu()[0]), lg_o, "prefill")
+    assert np.array_equal(pf.kc[0, 0].cpu().numpy(), caches[0][0])
+    assert np.array_equal(pf.ksc[0, 0].cpu().numpy(), caches[0][1])
+    ref = [t.clone() for t in (pf.logits, pf.tok, pf.kc, pf.vc, pf.ksc, pf.vsc)]
+    for t in (pf.logits, pf.kc, pf.vc):
+        t.fill_(1)
+    pf.run(lanes=3)
+    torch.cuda.synchronize()
+    for a, b in zip(ref, (pf.logits, pf.tok, pf.kc, pf.vc, pf.ksc, pf.vsc)):
+        assert torch.equal(a, b)
+
+
 def conv_rows(cc):
     """The oracle's circular ConvCache rows of one block in temporal order, zeros for rows not held yet."""
     W, Cc = cc.W, cc.rows.shape[1]
