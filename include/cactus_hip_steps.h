@@ -76,7 +76,8 @@ size_t cactus_hip_decode_step_workspace_bytes(const cactus_hip_decoder_weights* 
  * as two half-batches, the second half on a stream of the library's own that forks from `stream` after the embedding
  * and joins it before the lm_head (a capture of `stream` takes in both), the halves' attention launches taking turns,
  * so that one half reads its KV cache while the other runs its matmuls.  Rows are independent: every result is the
- * single stream's, bit for bit. */
+ * single stream's, bit for bit.  (That stream and its events exist once per device: split steps that overlap on one
+ * device must be serialized by the caller.) */
 int cactus_hip_decode_step_dev(const cactus_hip_decoder_weights* w, const cactus_hip_decode_state* state,
                                void* workspace, cactus_half_t* logits, int advance, void* stream);
 
@@ -117,7 +118,10 @@ int cactus_hip_prefill_chunk_dev(const cactus_hip_decoder_weights* w, const cact
  * one after the other, bit for bit.  tokens: device int32[n_tokens]; the last chunk may be short; chunk_starts_dev:
  * device int32[chunks] holding c * chunk; workspace: cactus_hip_prefill_workspace_bytes(w, chunk, lanes) bytes (call it
  * outside any stream capture: it also creates the streams and events); logits half[1, vocab] and *token_out receive the
- * last token's logits and greedy choice.  No counterpart in the reference, whose chunks are separate graph executions. */
+ * last token's logits and greedy choice.  The library owns one set of these streams and events per device: calls that
+ * overlap on one device (from several host threads, or on several caller streams at once) would share them and must be
+ * serialized by the caller; calls on different devices are independent.  No counterpart in the reference, whose chunks
+ * are separate graph executions. */
 size_t cactus_hip_prefill_workspace_bytes(const cactus_hip_decoder_weights* w, size_t chunk, size_t lanes);
 int cactus_hip_prefill_dev(const cactus_hip_decoder_weights* w, const cactus_hip_prefill_state* state, const int32_t* tokens,
                            size_t n_tokens, size_t chunk, const int32_t* chunk_starts_dev, void* workspace, size_t lanes,
