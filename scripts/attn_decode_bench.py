@@ -16,17 +16,25 @@ shapes = [("qwen3_c512_b1", 16, 8, 128, 512, 1), ("qwen3_c4096_b1", 16, 8, 128, 
           ("gemma270m_c4096_b1", 4, 1, 256, 4096, 1), ("gemma4b_c4096_b64", 8, 4, 256, 4096, 64)]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0] in sys.argv[1:]]
+# ROTATE=n: n cache sets used in turn (more than the 256 MB Infinity Cache between two uses of a set), as the layers of
+# a decode step do; default 1 = the same cache every launch
+rot = int(os.environ.get("ROTATE", "1"))
 for name, Hq, Hkv, D, cache, Bn in shapes:
-    kq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
-    vq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
     ng = (D + 127) // 128      # scale groups per row
-    ks = torch.rand((Bn, cache, Hkv, ng), device="cuda", generator=gen) * 0.02
-    vs = torch.rand((Bn, cache, Hkv, ng), device="cuda", generator=gen) * 0.02
+    sets = []
+    for _ in range(rot):
+        kq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+        vq = torch.randint(-127, 128, (Bn, cache, Hkv, D), dtype=torch.int8, device="cuda", generator=gen)
+        ks = torch.rand((Bn, cache, Hkv, ng), device="cuda", generator=gen) * 0.02
+        vs = torch.rand((Bn, cache, Hkv, ng), device="cuda", generator=gen) * 0.02
+        sets.append((kq, vq, ks, vs))
     qh = (torch.rand((Bn, 1, Hq, D), device="cuda", generator=gen) * 2 - 1).half()
     kn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
     vn = (torch.rand((Bn, 1, Hkv, D), device="cuda", generator=gen) * 2 - 1).half()
     lens = torch.full((Bn,), cache, dtype=torch.int32, device="cuda")
     out = torch.empty_like(qh)
-    ms = time_graph(lambda i: H.attention_hybrid_batched(qh, kq, vq, ks, vs, kn, vn, 0.0, lens, lens, out=out), 8)
+    ms = time_graph(lambda i: H.attention_hybrid_batched(qh, *sets[i % rot], kn, vn, 0.0, lens, lens, out=out), max(8, 2 * rot))
     byts = Bn * (2 * cache * Hkv * (D + 4 * ng) + 2 * Hkv * D * 2 + 2 * Hq * D * 2)
     print(f"{name:20s} {ms * 1e3:9.2f} us  {byts / (ms * 1e-3) / 1e9:8.1f} GB/s  {byts / (ms * 1e-3) / 8e12:.3f} of 8 TB/s")
+    del sets
+    torch.cuda.empty_cache()
