@@ -12,7 +12,7 @@ for each of the 16 (K, N) shapes the FP16-activation matmul of compute_matmul_no
 FP16 in / FP16 out, on weights already resident in HBM.  The 16 matmuls of a step are
 independent, and the library takes them as one batch (cactus_hip_matmul_int8_f16act_batch_dev):
 one launch whose workgroups each quantize their activation row and stream a 16-row weight tile
-of one of the shapes.  Two complete weight sets (450 MB) alternate
+of one of the shapes.  Four complete weight sets (--weight-sets; 229 MiB each) take turns
 between steps so that no weight is served from the 256 MiB Infinity Cache.  `value` is
 algorithmic bytes of a step (weights + scales + activations + outputs) times ranks, divided by
 the slowest rank's time per step.
@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--weight-sets", type=int, default=4, help="complete weight sets the timed steps use in turn (240 MB each)")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-shape / M=16 / M=512 / attention table")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic)")
@@ -254,7 +255,8 @@ def main():
 
     # ---- workload: two complete weight sets, FP16 activation rows per K
     sets = []
-    for _ in range(2):
+    NS = max(2, args.weight_sets)
+    for _ in range(NS):
         sets.append({(K, N): make_weights(K, N, False, gen) for K in SIZES for N in SIZES})
     acts = {K: (torch.rand((1, K), device="cuda", generator=gen) * 2 - 1).half() for K in SIZES}
     outs = {(K, N): torch.empty((1, N), dtype=torch.float16, device="cuda") for K in SIZES for N in SIZES}
@@ -266,9 +268,9 @@ def main():
 
     def step(i, batched=True):
         if batched:
-            batches[i & 1].run()
+            batches[i % NS].run()
         else:
-            ws = sets[i & 1]
+            ws = sets[i % NS]
             for K, N in order:
                 H.matmul_f16act(acts[K], ws[(K, N)][0], ws[(K, N)][1], 128, out=outs[(K, N)])
 
@@ -280,8 +282,9 @@ def main():
     # Steps are captured into HIP graphs (the kernels allocate nothing and run on the capturing
     # stream): CHUNK consecutive steps per graph, as a decode loop captures a whole token's
     # launches, plus single-step graphs for the remainder.  Weight sets alternate step by step.
-    CHUNK = 10
-    step(0); step(1)
+    CHUNK = 12 if NS in (2, 3, 4, 6) else 2 * NS      # a multiple of NS: every chunk starts on set 0
+    for i in range(NS):
+        step(i)
     torch.cuda.synchronize()
 
     def capture(batched, nsteps=1, first=0):
@@ -296,13 +299,14 @@ def main():
     for ws in sets:
         for B, _ in ws.values():
             H.pack_weights(B)
-    step(0); step(1)
+    for i in range(NS):
+        step(i)
     torch.cuda.synchronize()
-    graphs = [capture(True, 1, 0), capture(True, 1, 1)]
-    chunk_graph = capture(True, CHUNK, 0)        # CHUNK is even: every chunk starts on set 0
+    graphs = [capture(True, 1, i) for i in range(NS)]
+    chunk_graph = capture(True, CHUNK, 0)
 
     def run_step(i):
-        graphs[i & 1].replay()
+        graphs[i % NS].replay()
 
     def run_steps(n):
         for _ in range(n // CHUNK):
@@ -375,7 +379,7 @@ def main():
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": "INT8-weight x FP16-activation matmul sweep, M=1, K,N in {1024,2048,4096,8192} "
                                    "(16 shapes/step: fused row quant + grouped INT8 GEMV, group 128); "
-                                   "two alternating weight sets (450 MB); one step = one batched launch, "
+                                   f"{NS} weight sets used in turn ({NS * 229} MiB); one step = one batched launch, "
                                    f"{CHUNK} steps per HIP graph; weights resident row-major [N,K] with the "
                                    "library's tile-major twins (cactus_hip_weights_pack_dev, made once at load)",
                        "bytes_per_step": step_bytes,
@@ -757,12 +761,12 @@ def extra_table(H, gen, big):
     buffers (> 256 MiB in total) so that weights come from HBM."""
     ex = {}
     # the headline step on weights WITHOUT tile-major twins (the reference's row-major [N, K] layout read as it lies)
-    sets = [{(K, N): make_weights(K, N, False, gen) for K in SIZES for N in SIZES} for _ in range(2)]
+    sets = [{(K, N): make_weights(K, N, False, gen) for K in SIZES for N in SIZES} for _ in range(4)]
     acts = {K: (torch.rand((1, K), device="cuda", generator=gen) * 2 - 1).half() for K in SIZES}
     outs = {(K, N): torch.empty((1, N), dtype=torch.float16, device="cuda") for K in SIZES for N in SIZES}
     order = sorted(((K, N) for K in SIZES for N in SIZES), key=lambda kn: -kn[0] * kn[1])
     batches = [H.MatmulBatch([(acts[K], ws[(K, N)][0], ws[(K, N)][1], outs[(K, N)]) for K, N in order], 128) for ws in sets]
-    ms = time_graph(lambda i: batches[i & 1].run(), 10)
+    ms = time_graph(lambda i: batches[i & 3].run(), 12)
     sb = sum(gemv_bytes(1, K, N) for K in SIZES for N in SIZES)
     ex["gemv_sweep_row_major_layout"] = {"us_per_step": round(ms * 1e3, 2), "GBps": round(sb / (ms * 1e-3) / 1e9, 1),
                                          "frac_hbm": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
