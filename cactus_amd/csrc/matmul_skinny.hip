@@ -1168,6 +1168,30 @@ hipError_t launch_matmul_skinny_fq(bool int4, const uint16_t* X, float* scales_o
 
 // Batched fused launch: every problem must satisfy skinny_fused_quant_ok and the alignment the
 // single launch needs; count <= SK_MAXB (the caller splits longer lists).
+// Waves per tile of the wave-group launches, by the bytes of a weight row: a short row cannot feed 4 waves, and with
+// fewer waves per tile more independent tiles are in flight per CU.  Measured on the 16-shape sweeps from HBM (four /
+// six weight sets in turn): INT8 rows of 1024 bytes on one wave and of 2048 on two 39.3 us against 40.4 with two and
+// four; packed INT4 the other way (26.6 us against 27.2 - 27.7).
+#ifndef SK_SUB_K1
+#define SK_SUB_K1 1024   // INT8 weight rows up to this many bytes take one wave per tile
+#endif
+#ifndef SK_SUB_K2
+#define SK_SUB_K2 2048   // ... up to this, two waves per tile
+#endif
+#ifndef SK_SUB_K1_4
+#define SK_SUB_K1_4 0    // the same for packed INT4 rows
+#endif
+#ifndef SK_SUB_K2_4
+#define SK_SUB_K2_4 1024
+#endif
+// total_tiles: 16-row tiles of the whole launch; one wave per tile only pays when there are thousands (the launches of a
+// batch-1 decode step, a few hundred tiles each, take 1.13 ms per step with it against 1.04)
+static int sub_waves(bool int4, size_t K, size_t total_tiles) {
+    const size_t kb = int4 ? K / 2 : K;
+    const size_t k1 = int4 ? SK_SUB_K1_4 : SK_SUB_K1, k2 = int4 ? SK_SUB_K2_4 : SK_SUB_K2;
+    return (kb <= k1 && total_tiles >= 2048) ? 1 : (kb <= k2 ? 2 : 4);
+}
+
 hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, size_t count, hipStream_t st) {
     if (count == 0) return hipSuccess;
     if (count > (size_t)SK_MAXB) return hipErrorInvalidValue;
@@ -1235,18 +1259,11 @@ hipError_t launch_matmul_skinny_fq_batch(bool int4, const SkinnyProblem* pr, siz
     }
     // Four waves per tile: the workgroup of 4 waves is cut into wave groups per problem, so that
     // short rows (few units) get fewer waves per tile and more tiles in flight.
-#ifndef SK_SUB_K1
-#define SK_SUB_K1 0      // weight rows up to this many bytes take one wave per tile
-#endif
-#ifndef SK_SUB_K2
-#define SK_SUB_K2 1024   // ... up to this, two waves per tile
-#endif
-    if (W == 4 && ct == 1 && SK_SUB_K2 > 0) {
+    if (W == 4 && ct == 1) {
         size_t blocks = 0, lds_sub = 0;
         for (size_t i = 0; i < count; i++) {
             const SkinnyProblem& q = pr[order[i]];
-            const size_t kb = int4 ? q.K / 2 : q.K;
-            const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
+            const int wt = sub_waves(int4, q.K, total_tiles);
             const size_t l = (fq_lds_bytes(int4, wt, 1, q.M, q.K) + 15) & ~(size_t)15;
             bt.wt[i] = wt;
             bt.lds_floats[i] = (int)(l / sizeof(float));
@@ -1313,8 +1330,7 @@ hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyPr
         if (!skinny_fused_quant_ok(int4, q.M, q.K)) return hipErrorInvalidValue;
         if (((q.N + 15) & ~size_t(15)) * (int4 ? q.K / 2 : q.K) > (size_t(1) << 31)) return hipErrorInvalidValue;
         if (q.packed) bt.pk_mask |= 1u << i;
-        const size_t kb = int4 ? q.K / 2 : q.K;
-        const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
+        const int wt = sub_waves(int4, q.K, 0);
         size_t l = fq_lds_bytes(int4, wt, 1, q.M, q.K) + 16;            // + the rows' 1 / rms
         if (kind == 1) l += 2 * q.M * q.K;                              // + the summed rows (binary16)
         l = (l + 15) & ~(size_t)15;
@@ -1343,8 +1359,7 @@ hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyPr
 
 bool skinny_fq_pro_ok(bool int4, int kind, size_t M, size_t K) {
     if (!skinny_fused_quant_ok(int4, M, K)) return false;
-    const size_t kb = int4 ? K / 2 : K;
-    const int wt = kb <= (size_t)SK_SUB_K1 ? 1 : (kb <= (size_t)SK_SUB_K2 ? 2 : 4);
+    const int wt = sub_waves(int4, K, 0);
     size_t l = fq_lds_bytes(int4, wt, 1, M, K) + 16 + (kind == 1 ? 2 * M * K : 0);
     l = (l + 15) & ~(size_t)15;
     return l * (4 / wt) <= 64 * 1024;
