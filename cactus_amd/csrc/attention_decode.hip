@@ -49,7 +49,13 @@ constexpr int DC_BLOCK = 32;     // keys per block
 #ifndef DC_STAGES_N
 #define DC_STAGES_N 2
 #endif
-constexpr int DC_STAGES = DC_STAGES_N;     // LDS stages and K register sets per wave: DC_STAGES - 1 blocks in flight
+// LDS stages per wave (V rows and both scales of a block) for head_dim 64 / 128; K rows go to two register sets whatever
+// this is (235 registers rule out a third set).  With 3, a wave computing block j has V(j+1), K(j+1) and V(j+2) in
+// flight (12 KB at head_dim 128 instead of 8); measured from HBM (cache sets in turn): 256 sequences x 512 tokens 56.2 us
+// against 55.4 with 2, 64 x 4096 104.6 / 103.1, LFM2 heads 1024 x 512 121.1 / 119.5 - bytes in flight are not what
+// bounds the stream, so 2 it stays.  head_dim 256 always has 2 (its stages are 8.7 KB).
+constexpr int DC_VSTAGES = DC_STAGES_N;
+constexpr int DC_KSETS = 2;
 constexpr int DC_MAX_NEW = 8;    // FP16 tokens of the step itself (decode: 1)
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     constexpr int NC = D / 32;                      // 32-dim column blocks
     constexpr int NG = D == 256 ? 2 : 1;            // scale groups per row (head_dim 256: two groups of 128 dims)
     constexpr int CG = NC / NG;                     // column blocks per scale group
+    constexpr int DC_STAGES = D == 256 ? 2 : DC_VSTAGES;
     constexpr int RING = NW * DC_STAGES * STAGE;
     constexpr int ROWS_OWN = FUSED && D == 256 ? 18 * D * 2 : 0;   // per wave: the fused rows when a ring stage cannot hold them
     static_assert(ROWS_OWN || !FUSED || 18 * D * 2 <= STAGE, "a stage holds the fused rows");
@@ -240,20 +247,20 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         __builtin_amdgcn_raw_ptr_buffer_load_lds(vsrsrc, (lptr_t)(st + VBYTES + 256), 4, (int)(sbase + s_lane_off), 0, 0, 0);
     };
 
-    KRegs kr[DC_STAGES];
+    KRegs kr[DC_KSETS];
     // FUSED: the first block of the wave's range is requested before the wave turns to its rows (whose loads, tables
     // and arithmetic would otherwise all precede the first byte of the cache stream); the rows then sit in the ring's
     // last stage, which later requests overwrite once the q rows are in registers
     // (head_dim 256: up to 18 rows of 512 bytes do not fit a stage and have an area of their own).  The requests are
     // unconditional like all others: a wave without blocks reads nothing.
     constexpr bool early = FUSED;
-    if constexpr (early) {
+    // request order: K(first), V(first), V(first + 1) .. V(first + DC_STAGES - 2); then per block j: K(j + 1), V(j + DC_STAGES - 1)
+    auto issue_first = [&]() __attribute__((always_inline)) {
+        issue_k(blk_first, kr[0]);
 #pragma unroll
-        for (int u = 0; u < DC_STAGES - 1; u++) {
-            issue_k(blk_first + u, kr[u]);
-            issue_v(blk_first + u, u);
-        }
-    }
+        for (int u = 0; u < DC_STAGES - 1; u++) issue_v(blk_first + u, u);
+    };
+    if constexpr (early) issue_first();
     if constexpr (FUSED) {
         // rows of this wave, 16 lanes each, four at a time: its query heads, its key, and (key range 0) its value;
         // they sit in the still idle ring: [gq] normalized + rotated q rows, the k row, the raw v row
@@ -523,9 +530,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         }
     };
 
-    // this wave's blocks, the next one requested before the current one is consumed (two K register sets
-    // and two LDS stages that swap roles); the counted waits leave exactly the next block's requests in
-    // flight.  Requests are unconditional (past the wave's share they read nothing); only the arithmetic of
+    // this wave's blocks, requested ahead of their use: K one block ahead into the other of two register sets, V
+    // DC_STAGES - 1 blocks ahead into the LDS stage whose block was consumed last; the counted waits leave exactly the
+    // requests issued after K(j) in flight when block j is computed.  Requests are unconditional (past the wave's share they read nothing); only the arithmetic of
     // a block that does not exist is skipped.  Every lane runs every iteration: the transposed reads need
     // all lanes.  A stage is rewritten by the requests issued after its consumer, whose LDS reads have
     // completed by then (the consumer waited for them).
@@ -536,24 +543,22 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             if (bk * DC_BLOCK + DC_BLOCK <= c_cnt) compute_block(std::true_type{}, bk, stage, k);
             else compute_block(std::false_type{}, bk, stage, k);
         };
-        constexpr int OPS_PER_BLOCK = 2 * KL + NDMA + 2;   // vector-memory operations of one block's requests
-        if constexpr (!early) {
+        constexpr int K_OPS = 2 * KL, V_OPS = NDMA + 2;    // vector-memory operations of a block's K and V requests
+        // what may still be in flight when K(j) and V(j) must have landed: the requests issued after K(j)
+        constexpr int LEAVE = DC_STAGES == 2 ? K_OPS + V_OPS : K_OPS + 2 * V_OPS;
+        if constexpr (!early) issue_first();
+        int vs = 0;                                        // LDS stage of block blk
+        for (int it = 0; it < mine; it += DC_KSETS) {
 #pragma unroll
-            for (int u = 0; u < DC_STAGES - 1; u++) {
-                issue_k(blk + u, kr[u]);
-                issue_v(blk + u, u);
-            }
-        }
-        for (int it = 0; it < mine; it += DC_STAGES) {
-#pragma unroll
-            for (int u = 0; u < DC_STAGES; u++) {
-                constexpr int AHEAD = DC_STAGES - 1;
-                const int un = (u + AHEAD) % DC_STAGES;
-                issue_k(blk + AHEAD, kr[un]);
-                issue_v(blk + AHEAD, un);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * OPS_PER_BLOCK) : "memory");
-                if (it + u < mine) compute(blk, u, kr[u]);
+            for (int u = 0; u < DC_KSETS; u++) {
+                int vn = vs + DC_STAGES - 1;
+                if (vn >= DC_STAGES) vn -= DC_STAGES;
+                issue_k(blk + 1, kr[u ^ 1]);
+                issue_v(blk + DC_STAGES - 1, vn);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
+                if (it + u < mine) compute(blk, vs, kr[u]);
                 blk++;
+                vs = vs + 1 == DC_STAGES ? 0 : vs + 1;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last, empty requests still write this wave's LDS
