@@ -117,3 +117,50 @@ def test_cpp_host_batched_decode_equals_the_python_driver(tmp_path, batch):
         tok = int(O.sample_greedy(ref[None])[0])
         assert got[0][s] == tok, (s, got[0])
         pos += 1
+
+
+PROMPT_EXE = os.path.join(os.path.dirname(EXE), "qwen_prompt_decode")
+
+
+@pytest.mark.parametrize("chunk,lanes", [(16, 3), (64, 1)])
+def test_cpp_host_prompt_then_decode(tmp_path, chunk, lanes):
+    """examples/qwen_prompt_decode.cpp: a C++ host that prefills a 40-token prompt with cactus_hip_prefill_dev (chunks of 16,
+    three in flight, the last one short; or one chunk) and decodes on the same cache buffers with
+    cactus_hip_decode_step_dev.  The same weights through cactus_amd.steps (Prefill, adopt, Qwen3Decode): identical tokens;
+    and the first choices against the oracle run on the whole prompt."""
+    import cactus_amd.hip as H
+    H.init(0)
+    from cactus_amd import cact, steps as ST
+    from tests import test_gpu_steps as SD
+    assert os.path.exists(PROMPT_EXE), "cactus_amd/lib/qwen_prompt_decode is not built"
+    LAYERS, VOCAB, steps, n = 4, 8192, 6, 40
+    rng = np.random.default_rng(60 + chunk)
+    m = GD.make_model(rng, LAYERS, VOCAB, 0.05)
+    prompt = rng.integers(0, VOCAB, n).tolist()
+    cfg = dict(ST.QWEN3_0P6B, layers=LAYERS, vocab=VOCAB)
+    cact.write_qwen_folder(tmp_path, m, cfg)
+    r = subprocess.run([PROMPT_EXE, str(tmp_path), str(steps), str(chunk), str(lanes)] + [str(t) for t in prompt],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])["tokens"]
+    assert len(got) == steps + 1
+    dm = ST.weights_to_device(m)
+    pf = ST.Prefill(dm, cfg, n, chunk, capacity=n + steps + 1)
+    pf.prompt.copy_(torch.tensor(prompt, dtype=torch.int32))
+    pf.run(lanes)
+    dec = ST.Qwen3Decode(dm, cfg, 1, n + steps + 1, max_position=n + steps + 1)
+    dec.adopt(pf)
+    want = [int(pf.tok.cpu()[0])]
+    for _ in range(steps):
+        dec.step()
+        want.append(int(dec.kv.tok.cpu()[0]))
+    assert got == want
+    caches = [None] * LAYERS
+    ref = SD.oracle_forward(m, prompt, 0, caches).view(np.float16)
+    tok, pos = int(O.sample_greedy(ref[None])[0]), n
+    assert got[0] == tok
+    for s in range(2):
+        ref = SD.oracle_forward(m, [tok], pos, caches).view(np.float16)
+        tok = int(O.sample_greedy(ref[None])[0])
+        assert got[1 + s] == tok, (s, got)
+        pos += 1
