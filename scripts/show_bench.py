@@ -11,6 +11,7 @@ for k in ("gemv_int8_M1", "gemv_int8_M16", "gemv_int4_M1", "gemv_int4_M16"):
 for k in ("qwen3_0p6b_decode_step", "lfm2_1p2b_decode_step"):
     print(k, {s: v["ms_per_step"] for s, v in e.get(k, {}).items()})
 print("prefill", {s: v["ms"] for s, v in e.get("qwen3_0p6b_prefill", {}).items()})
+print("lfm2 prefill", {s: v["ms"] for s, v in e.get("lfm2_1p2b_prefill", {}).items()})
 print("attn_decode", {s: (v["us"], v["frac_hbm"]) for s, v in e.get("attn_decode_int8kv", {}).items()})
 print("attn_prefill", {s: (v["us"], v.get("TFLOPs")) for s, v in e.get("attn_prefill_f16_causal", {}).items()})
 print("single_launch_8192", e.get("single_launch_8192", {}).get("us_per_launch"))
