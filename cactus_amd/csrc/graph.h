@@ -218,14 +218,16 @@ public:
         void trim();             // frees idle buffers, largest first, until at most max_idle_bytes() stay idle
         size_t device_allocations() const { return allocations_; }
         size_t idle_bytes() const { return idle_bytes_; }
-        size_t max_idle_bytes() const { return max_idle_bytes_; }
-        void set_max_idle_bytes(size_t b) { max_idle_bytes_ = b; }
+        size_t max_idle_bytes();
+        void trim_to(size_t cap);
+        void set_max_idle_bytes(size_t b) { max_idle_bytes_ = b; cap_set_ = true; }
     private:
         std::unordered_map<size_t, std::vector<void*>> free_;   // rounded size -> idle buffers
         std::unordered_map<void*, size_t> size_of_;             // every buffer handed out -> rounded size
         size_t allocations_ = 0;
         size_t idle_bytes_ = 0;
-        size_t max_idle_bytes_ = size_t(1) << 30;   // idle buffers kept across soft resets (1 GiB unless set)
+        size_t max_idle_bytes_ = size_t(1) << 30;   // idle buffers kept across soft resets; unless set: an eighth of the
+        bool cap_set_ = false;                      // device's memory (at least 1 GiB), found at the first trim
     };
 
 private:

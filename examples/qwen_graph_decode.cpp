@@ -145,7 +145,7 @@ int main(int argc, char** argv) {
 
     std::vector<size_t> ks, vs;
     std::vector<uint32_t> out;
-    double t_build = 0, t_exec = 0, t_update = 0, t_reset = 0, t_all = 0, prefill_ms = 0;
+    double t_build = 0, t_exec = 0, t_update = 0, t_reset = 0, t_all = 0, prefill_ms = 0, prefill_parts[4] = {0, 0, 0, 0};
     int timed = 0;
     std::vector<uint32_t> feed = prompt;
     // step -1: the prompt once untimed (first use of every kernel, buffers, RoPE rows), then the cache is emptied
@@ -163,7 +163,13 @@ int main(int argc, char** argv) {
         const auto t3 = std::chrono::steady_clock::now();
         ok(cactus_hip_graph_soft_reset(m.g), "soft_reset");
         const auto t4 = std::chrono::steady_clock::now();
-        if (step == 0) prefill_ms = std::chrono::duration<double, std::milli>(t4 - t0).count();
+        if (step == 0) {
+            prefill_ms = std::chrono::duration<double, std::milli>(t4 - t0).count();
+            prefill_parts[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            prefill_parts[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+            prefill_parts[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
+            prefill_parts[3] = std::chrono::duration<double, std::milli>(t4 - t3).count();
+        }
         if (timing) {
             t_build += std::chrono::duration<double, std::milli>(t1 - t0).count();
             t_exec += std::chrono::duration<double, std::milli>(t2 - t1).count();
@@ -184,9 +190,10 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < out.size(); i++) std::printf("%s%u", i ? ", " : "", out[i]);
     const double n = timed ? (double)timed : 1.0;
     std::printf("], \"prompt_tokens\": %zu, \"prefill_ms\": %.3f, \"timed_steps\": %d, \"ms_per_token\": %.4f, \"build_ms\": %.4f, \"execute_ms\": %.4f, \"cache_update_ms\": %.4f, "
-                "\"soft_reset_ms\": %.4f, \"fused_launches\": %zu, \"pool_allocations\": %zu}\n",
+                "\"soft_reset_ms\": %.4f, \"fused_launches\": %zu, \"pool_allocations\": %zu, "
+                "\"prefill_build_execute_update_reset_ms\": [%.3f, %.3f, %.3f, %.3f]}\n",
                 prompt.size(), prefill_ms, timed, t_all / n, t_build / n, t_exec / n, t_update / n, t_reset / n, cactus_hip_graph_fused_launches(m.g),
-                cactus_hip_graph_pool_allocations(m.g));
+                cactus_hip_graph_pool_allocations(m.g), prefill_parts[0], prefill_parts[1], prefill_parts[2], prefill_parts[3]);
     cactus_hip_kvcache_destroy(m.cache);
     cactus_hip_graph_destroy(m.g);
     return 0;

@@ -114,8 +114,8 @@ size_t cactus_hip_graph_node_count(void* graph);
 size_t cactus_hip_graph_pool_allocations(void* graph);
 /* The pool hands out buffers in power-of-two sizes from 1 KiB (as the reference's BufferPool buckets them,
  * graph_core.cpp:5-19), so passes of different sequence lengths share buffers.  soft_reset() keeps at most
- * max_idle_bytes of idle buffers (default 1 GiB) and frees the rest, largest first; a device allocation that
- * fails frees every idle buffer and is tried once more. */
+ * max_idle_bytes of idle buffers (default: an eighth of the device's memory, at least 1 GiB) and frees the rest, largest
+ * first; a device allocation that fails frees every idle buffer and is tried once more. */
 size_t cactus_hip_graph_pool_idle_bytes(void* graph);
 void   cactus_hip_graph_set_pool_max_idle_bytes(void* graph, size_t bytes);
 /* Grouped weights bound from now on (set_external_input / set_packed_int4 + set_grouped_scales, mmap_weights)
