@@ -681,6 +681,13 @@ def qwen3_decode_via_graph(H, gen, cache_len=512, tokens=24):
                 d = _json.loads(r.stdout.strip().splitlines()[-1])
                 out["cpp_host_prefill_4096"] = {"ms": round(d["prefill_ms"], 2),
                                                 "tokens_per_s": round(4096 / (d["prefill_ms"] * 1e-3), 1)}
+            # ... and in the engine's default chunks of 256 tokens, a graph per chunk (engine_model.cpp:170-219, 637-642)
+            r = subprocess.run([exe, folder, "4", "1"] + long_prompt, capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, CACTUS_PREFILL_CHUNK="256"))
+            if r.returncode == 0:
+                d = _json.loads(r.stdout.strip().splitlines()[-1])
+                out["cpp_host_prefill_4096_chunk256"] = {"ms": round(d["prefill_ms"], 2),
+                                                         "tokens_per_s": round(4096 / (d["prefill_ms"] * 1e-3), 1)}
         finally:
             shutil.rmtree(folder, ignore_errors=True)
     return out

@@ -148,10 +148,32 @@ int main(int argc, char** argv) {
     double t_build = 0, t_exec = 0, t_update = 0, t_reset = 0, t_all = 0, prefill_ms = 0, prefill_parts[4] = {0, 0, 0, 0};
     int timed = 0;
     std::vector<uint32_t> feed = prompt;
+    // CACTUS_PREFILL_CHUNK=n: the prompt in chunks of n tokens, a graph each, as Model::prefill walks it
+    // (engine_model.cpp:170-219; get_prefill_chunk_size() is 256 there); default: the prompt as one graph
+    const char* chunk_env = std::getenv("CACTUS_PREFILL_CHUNK");
+    const size_t chunk = chunk_env ? (size_t)std::atol(chunk_env) : 0;
+    auto run_chunks = [&](bool timed_run) {     // all chunks but the last; returns the milliseconds they took
+        const auto c0 = std::chrono::steady_clock::now();
+        size_t done = 0;
+        while (chunk && prompt.size() - done > chunk) {
+            std::vector<uint32_t> part(prompt.begin() + (long)done, prompt.begin() + (long)(done + chunk));
+            (void)m.build(part, ks, vs);
+            ok(cactus_hip_graph_execute(m.g), "execute");
+            ok(cactus_hip_kvcache_update(m.cache, m.g, ks.data(), vs.data(), part.size()), "kvcache_update");
+            ok(cactus_hip_graph_soft_reset(m.g), "soft_reset");
+            m.pos += part.size();
+            done += chunk;
+        }
+        feed.assign(prompt.begin() + (long)done, prompt.end());
+        (void)timed_run;
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+    };
+    double chunks_ms = 0;
     // step -1: the prompt once untimed (first use of every kernel, buffers, RoPE rows), then the cache is emptied
     // and the run proper starts; step 0: the prompt
     for (int step = prompt.size() > 1 ? -1 : 0; step <= steps; step++) {
         const bool timing = step > 2;
+        if (step <= 0 && prompt.size() > 1) chunks_ms = run_chunks(step == 0);
         const auto t0 = std::chrono::steady_clock::now();
         const size_t tok_node = m.build(feed, ks, vs);
         const auto t1 = std::chrono::steady_clock::now();
@@ -164,7 +186,7 @@ int main(int argc, char** argv) {
         ok(cactus_hip_graph_soft_reset(m.g), "soft_reset");
         const auto t4 = std::chrono::steady_clock::now();
         if (step == 0) {
-            prefill_ms = std::chrono::duration<double, std::milli>(t4 - t0).count();
+            prefill_ms = chunks_ms + std::chrono::duration<double, std::milli>(t4 - t0).count();
             prefill_parts[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
             prefill_parts[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
             prefill_parts[2] = std::chrono::duration<double, std::milli>(t3 - t2).count();
@@ -180,6 +202,7 @@ int main(int argc, char** argv) {
         }
         if (step < 0) {
             cactus_hip_kvcache_reset(m.cache);
+            m.pos = 0;
             continue;
         }
         m.pos += feed.size();

@@ -19,7 +19,8 @@ try:
     cact.write_qwen_folder(folder, host, cfg)
     for n in [int(a) for a in sys.argv[1:]] or [512, 4096]:
         prompt = [str(t) for t in np.random.default_rng(3).integers(0, cfg["vocab"], n).tolist()]
-        r = subprocess.run([exe, folder, "6", "1"] + prompt, capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, folder, "6", "1"] + prompt, capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ))      # CACTUS_PREFILL_CHUNK=256: the prompt in chunks, a graph each
         print(n, r.stderr[-300:] if r.returncode else {k: v for k, v in json.loads(r.stdout.strip().splitlines()[-1]).items() if k != "tokens"}, flush=True)
 finally:
     shutil.rmtree(folder, ignore_errors=True)
