@@ -1119,25 +1119,26 @@ void CactusGraph::make_view(GraphNode& n) {
     out.device_valid = true;
 }
 
-// nodes_[attn_idx] is an ATTENTION_INT8_HYBRID over one new token of one sequence whose q and k inputs are each
-// rope(reshape(rms_norm(reshape(projection)))) - per-head norm and RoPE of the projections' rows, as every
+// nodes_[attn_idx] is an ATTENTION or ATTENTION_INT8_HYBRID over the new tokens of one sequence whose q and k inputs
+// are each rope(reshape(rms_norm(reshape(projection)))) - per-head norm and RoPE of the projections' rows, as every
 // decoder of the reference builds them (model_qwen.cpp:63-84) - read by nothing else in the graph, with equal
-// epsilon, theta and position on both sides, on a shape the fused decode kernel takes.
-bool CactusGraph::match_decode_attention(size_t attn_idx, AttnChain* out) const {
+// epsilon, theta and position on both sides.  *seq: the new tokens.
+bool CactusGraph::match_attention_chain(size_t attn_idx, AttnChain* out, size_t* seq) const {
     const GraphNode& a = *nodes_[attn_idx];
-    if (a.op_type != OpType::ATTENTION_INT8_HYBRID || a.input_ids.size() < 3) return false;
+    if ((a.op_type != OpType::ATTENTION_INT8_HYBRID && a.op_type != OpType::ATTENTION) || a.input_ids.size() < 3) return false;
     const OpParams& p = a.params;
-    const size_t D = p.head_dim, Hkv = p.num_kv_heads;
-    if (p.cache_seq_len == 0 || !p.cached_keys_int8 || !p.cached_values_int8 || !p.cached_k_scales || !p.cached_v_scales)
-        return false;
-    if (D != 64 && D != 128 && D != 256) return false;
+    const BufferDesc& q = node(a.input_ids[0]).output_buffer;
+    const BufferDesc& kb = node(a.input_ids[1]).output_buffer;
+    if (q.shape.size() != 4 || kb.shape.size() != 4 || q.shape[0] != 1 || q.shape[1] == 0 || kb.shape[1] != q.shape[1]) return false;
+    const size_t S = q.shape[1], D = q.shape[3], Hkv = kb.shape[2];
+    if (Hkv == 0 || q.shape[2] % Hkv != 0 || kb.shape[3] != D) return false;
     auto chain = [&](size_t rope_id, size_t heads, size_t* norm_i, size_t* view_i, size_t* rope_i, size_t* src_id) {
         auto it = node_index_map_.find(rope_id);
         if (it == node_index_map_.end()) return false;
         const GraphNode& rope = *nodes_[it->second];
         if (rope.op_type != OpType::ROPE || rope.params.backend == ComputeBackend::NPU) return false;
         const std::vector<size_t>& rs = rope.output_buffer.shape;
-        if (rs.size() != 4 || rs[0] != 1 || rs[1] != 1 || rs[2] != heads || rs[3] != D) return false;
+        if (rs.size() != 4 || rs[0] != 1 || rs[1] != S || rs[2] != heads || rs[3] != D) return false;
         if (rope.output_buffer.precision != Precision::FP16 || consumers_[it->second].size() != 1) return false;
         const size_t vi = node_index_map_.at(rope.input_ids[0]);
         const GraphNode& view = *nodes_[vi];
@@ -1147,13 +1148,11 @@ bool CactusGraph::match_decode_attention(size_t attn_idx, AttnChain* out) const 
         if (norm.op_type != OpType::RMS_NORM || consumers_[ni].size() != 1) return false;
         const BufferDesc& in = node(norm.input_ids[0]).output_buffer;
         const BufferDesc& w = node(norm.input_ids[1]).output_buffer;
-        if (in.shape.size() != 2 || in.shape[0] != heads || in.shape[1] != D || in.precision != Precision::FP16) return false;
+        if (in.shape.size() != 2 || in.shape[0] != S * heads || in.shape[1] != D || in.precision != Precision::FP16) return false;
         if (w.precision != Precision::FP16 || w.total_size < D || !w.device_valid) return false;
         *norm_i = ni; *view_i = vi; *rope_i = it->second; *src_id = norm.input_ids[0];
         return true;
     };
-    const BufferDesc& q = node(a.input_ids[0]).output_buffer;
-    if (q.shape.size() != 4 || Hkv == 0 || q.shape[2] % Hkv != 0 || q.shape[2] / Hkv > 16) return false;
     AttnChain c;
     if (!chain(a.input_ids[0], q.shape[2], &c.q_norm, &c.q_view, &c.q_rope, &c.q_src)) return false;
     if (!chain(a.input_ids[1], Hkv, &c.k_norm, &c.k_view, &c.k_rope, &c.k_src)) return false;
@@ -1161,6 +1160,27 @@ bool CactusGraph::match_decode_attention(size_t attn_idx, AttnChain* out) const 
     const OpParams& kr = nodes_[c.k_rope]->params;
     if (qr.theta != kr.theta || qr.position_offset != kr.position_offset || qr.position_offset != p.position_offset) return false;
     if (nodes_[c.q_norm]->params.epsilon != nodes_[c.k_norm]->params.epsilon) return false;
+    if (out) *out = c;
+    if (seq) *seq = S;
+    return true;
+}
+
+// ... an ATTENTION_INT8_HYBRID over ONE new token, on a shape the fused decode kernel takes
+bool CactusGraph::match_decode_attention(size_t attn_idx, AttnChain* out) const {
+    const GraphNode& a = *nodes_[attn_idx];
+    if (a.op_type != OpType::ATTENTION_INT8_HYBRID || a.input_ids.size() < 3) return false;
+    const OpParams& p = a.params;
+    const size_t D = p.head_dim, Hkv = p.num_kv_heads;
+    if (p.cache_seq_len == 0 || !p.cached_keys_int8 || !p.cached_values_int8 || !p.cached_k_scales || !p.cached_v_scales)
+        return false;
+    if (D != 64 && D != 128 && D != 256) return false;
+    const BufferDesc& q = node(a.input_ids[0]).output_buffer;
+    const BufferDesc& kb = node(a.input_ids[1]).output_buffer;
+    if (q.shape.size() != 4 || Hkv == 0 || q.shape[2] % Hkv != 0 || q.shape[2] / Hkv > 16 || q.shape[3] != D) return false;
+    if (kb.shape.size() != 4 || kb.shape[2] != Hkv) return false;
+    size_t S = 0;
+    AttnChain c;
+    if (!match_attention_chain(attn_idx, &c, &S) || S != 1) return false;
     const BufferDesc& v = node(a.input_ids[2]).output_buffer;
     if (v.precision != Precision::FP16 || v.total_size != Hkv * D) return false;
     if (out) *out = c;
@@ -1170,13 +1190,14 @@ bool CactusGraph::match_decode_attention(size_t attn_idx, AttnChain* out) const 
 // RMS_NORM / RESHAPE / ROPE node idx sits in such a run: it is left for the attention node to take
 bool CactusGraph::deferred_to_attention(size_t idx) const {
     size_t i = idx;
+    auto is_attn = [&](size_t j) { return nodes_[j]->op_type == OpType::ATTENTION_INT8_HYBRID || nodes_[j]->op_type == OpType::ATTENTION; };
     for (int hop = 0; hop < 3; hop++) {       // norm -> view -> rope -> attention
         if (consumers_[i].size() != 1) return false;
         i = consumers_[i][0];
-        if (nodes_[i]->op_type == OpType::ATTENTION_INT8_HYBRID) break;
+        if (is_attn(i)) break;
     }
     AttnChain c;
-    if (nodes_[i]->op_type != OpType::ATTENTION_INT8_HYBRID || !match_decode_attention(i, &c)) return false;
+    if (!is_attn(i) || !match_attention_chain(i, &c, nullptr)) return false;
     return idx == c.q_norm || idx == c.q_view || idx == c.q_rope || idx == c.k_norm || idx == c.k_view || idx == c.k_rope;
 }
 
@@ -1212,6 +1233,40 @@ bool CactusGraph::try_fuse_decode_attention(size_t attn_idx, std::vector<char>& 
     done[c.k_rope] = 1;
     a.output_buffer.device_valid = true;
     done[attn_idx] = 1;
+    return true;
+}
+
+// The same run in front of an attention over several new tokens (a prompt or a chunk of one): the two per-head norms
+// and the two RoPEs in one launch (cactus_hip_qk_norm_rope_f16_dev: the arithmetic of the four separate calls); the two
+// rotated nodes are written, the norms and views stay unmaterialized until somebody asks for them; the attention
+// node then runs as it is.
+bool CactusGraph::try_fuse_norm_rope(size_t attn_idx, std::vector<char>& done) {
+    AttnChain c;
+    size_t S = 0;
+    if (!match_attention_chain(attn_idx, &c, &S)) return false;
+    for (size_t i : {c.q_norm, c.q_view, c.q_rope, c.k_norm, c.k_view, c.k_rope})
+        if (done[i]) return false;
+    const GraphNode& a = *nodes_[attn_idx];
+    const BufferDesc& qs = node(c.q_src).output_buffer;
+    const BufferDesc& ks = node(c.k_src).output_buffer;
+    if (!qs.device_valid || !ks.device_valid) return false;
+    GraphNode& qrope = *nodes_[c.q_rope];
+    GraphNode& krope = *nodes_[c.k_rope];
+    ensure_device(qrope.output_buffer);
+    ensure_device(krope.output_buffer);
+    const std::vector<size_t>& qsh = qrope.output_buffer.shape;
+    const int rc = cactus_hip_qk_norm_rope_f16_dev(
+        static_cast<const cactus_half_t*>(qs.device_data), static_cast<const cactus_half_t*>(ks.device_data),
+        static_cast<const cactus_half_t*>(node(nodes_[c.q_norm]->input_ids[1]).output_buffer.device_data),
+        static_cast<const cactus_half_t*>(node(nodes_[c.k_norm]->input_ids[1]).output_buffer.device_data),
+        static_cast<cactus_half_t*>(qrope.output_buffer.device_data), static_cast<cactus_half_t*>(krope.output_buffer.device_data),
+        1, S, qsh[2], krope.output_buffer.shape[2], qsh[3], nodes_[c.q_norm]->params.epsilon, a.params.position_offset,
+        qrope.params.theta, nullptr);
+    if (rc != CACTUS_HIP_OK) return false;      // a shape the launch does not take: the plain path
+    fused_launches_++;
+    for (size_t i : {c.q_norm, c.q_view, c.k_norm, c.k_view}) done[i] = 1;     // not valid: computed on demand
+    qrope.output_buffer.device_valid = krope.output_buffer.device_valid = true;
+    done[c.q_rope] = done[c.k_rope] = 1;
     return true;
 }
 
@@ -1272,10 +1327,11 @@ void CactusGraph::execute() {
             if ((n.op_type == OpType::RMS_NORM || n.op_type == OpType::RESHAPE || n.op_type == OpType::ROPE) &&
                 deferred_to_attention(idx))
                 continue;               // not done: the attention node decides
-            if (n.op_type == OpType::ATTENTION_INT8_HYBRID) {
+            if (n.op_type == OpType::ATTENTION_INT8_HYBRID || n.op_type == OpType::ATTENTION) {
                 const size_t q_idx = node_index_map_.at(n.input_ids[0]);
                 if (!done[q_idx]) {     // the run deferred above
-                    if (try_fuse_decode_attention(idx, done)) continue;
+                    if (n.op_type == OpType::ATTENTION_INT8_HYBRID && try_fuse_decode_attention(idx, done)) continue;
+                    if (!try_fuse_norm_rope(idx, done))
                     for (int s = 0; s < 2; s++) {           // the plain path: compute what was left for this node
                         const size_t r = node_index_map_.at(n.input_ids[s]);
                         const size_t v = node_index_map_.at(nodes_[r]->input_ids[0]);

@@ -249,9 +249,11 @@ private:
         size_t q_norm, q_view, q_rope, k_norm, k_view, k_rope;   // node indices
         size_t q_src, k_src;                                     // the projections' rows (node ids)
     };
+    bool match_attention_chain(size_t attn_idx, AttnChain* out, size_t* seq) const;
     bool match_decode_attention(size_t attn_idx, AttnChain* out) const;
     bool deferred_to_attention(size_t idx) const;
     bool try_fuse_decode_attention(size_t attn_idx, std::vector<char>& done);
+    bool try_fuse_norm_rope(size_t attn_idx, std::vector<char>& done);
     void make_view(GraphNode& n);
     void compute_matmul_node(GraphNode& n);
     void compute_attention_node(GraphNode& n);

@@ -870,6 +870,57 @@ def test_fused_decode_attention_equals_node_by_node_execution(G, Hq, Hkv, D, cac
         assert np.array_equal(outs[True][k], outs[False][k]), k
 
 
+def _prompt_attention_run(G, g, rng, S, Hq, Hkv, D, pos, dev_cache, cache_len):
+    """The same run for S new tokens; dev_cache None: plain attention (a prompt against nothing), else the INT8 hybrid."""
+    def inp(shape, data):
+        n = g.input(shape, G.FP16)
+        g.set_input(n, data)
+        return n
+    half = lambda *sh: (rng.standard_normal(sh) * 2).astype(np.float16)
+    qp, kp, vp = inp((S, Hq * D), half(S, Hq * D)), inp((S, Hkv * D), half(S, Hkv * D)), inp((S, Hkv * D), half(S, Hkv * D))
+    qw, kw = inp((D,), (1 + 0.1 * rng.standard_normal(D)).astype(np.float16)), inp((D,), (1 + 0.1 * rng.standard_normal(D)).astype(np.float16))
+    qp, kp, vp = g.scalar_multiply(qp, 1.0), g.scalar_multiply(kp, 1.0), g.scalar_multiply(vp, 1.0)
+    qn = g.rms_norm(g.reshape(qp, (S * Hq, D)), qw, 1e-6)
+    kn = g.rms_norm(g.reshape(kp, (S * Hkv, D)), kw, 1e-6)
+    qr = g.rope(g.reshape(qn, (1, S, Hq, D)), 1e4, pos)
+    kr = g.rope(g.reshape(kn, (1, S, Hkv, D)), 1e4, pos)
+    v4 = g.reshape(vp, (1, S, Hkv, D))
+    if dev_cache is None:
+        att = g.attention(qr, kr, v4, 1.0 / np.sqrt(D), pos)
+    else:
+        kc, vc, ks, vs = dev_cache
+        att = g.attention_int8_hybrid(qr, kr, v4, 1.0 / np.sqrt(D), pos, kc.data_ptr(), vc.data_ptr(), ks.data_ptr(), vs.data_ptr(),
+                                      cache_len, Hkv, D)
+    return dict(att=att, kr=kr, qr=qr, qn=qn, kn=kn)
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,D,cache_len", [(40, 16, 8, 128, 0), (256, 16, 8, 128, 300), (7, 32, 8, 64, 0), (33, 4, 1, 256, 50)])
+def test_fused_prompt_norm_rope_equals_node_by_node_execution(G, S, Hq, Hkv, D, cache_len):
+    """rms_norm -> rope on q and k in front of an attention over several new tokens (a prompt, or a chunk against the
+    INT8 cache) as ONE launch: the attention rows, both rotated nodes and the norms it skipped (computed on request) are
+    identical to node-by-node execution."""
+    gen = torch.Generator(device="cuda").manual_seed(D + S)
+    NG = (D + 127) // 128
+    cache = None
+    if cache_len:
+        cache = (torch.randint(-127, 128, (cache_len, Hkv, D), dtype=torch.int8, device="cuda", generator=gen),
+                 torch.randint(-127, 128, (cache_len, Hkv, D), dtype=torch.int8, device="cuda", generator=gen),
+                 torch.rand((cache_len, Hkv, NG), device="cuda", generator=gen) * 0.02 + 1e-3,
+                 torch.rand((cache_len, Hkv, NG), device="cuda", generator=gen) * 0.02 + 1e-3)
+    outs = {}
+    for fusion in (False, True):
+        rng = np.random.default_rng(S + D)
+        g = G.CactusGraph()
+        g.set_fusion(fusion)
+        nodes = _prompt_attention_run(G, g, rng, S, Hq, Hkv, D, cache_len, cache, cache_len)
+        g.execute()
+        assert g.fused_launches() == (1 if fusion else 0)
+        outs[fusion] = {k: u16(g.get_output(v)).copy() for k, v in nodes.items()}
+        g.close()
+    for k in outs[True]:
+        assert np.array_equal(outs[True][k], outs[False][k]), k
+
+
 def test_decode_attention_run_with_a_second_reader_is_left_alone(G):
     gen = torch.Generator(device="cuda").manual_seed(1)
     Hq, Hkv, D, cache_len = 16, 8, 128, 100
