@@ -152,20 +152,29 @@ int main(int argc, char** argv) {
     // (engine_model.cpp:170-219; get_prefill_chunk_size() is 256 there); default: the prompt as one graph
     const char* chunk_env = std::getenv("CACTUS_PREFILL_CHUNK");
     const size_t chunk = chunk_env ? (size_t)std::atol(chunk_env) : 0;
+    double chunk_parts[3] = {0, 0, 0};          // build, execute + cache update, soft reset of the timed run's chunks
     auto run_chunks = [&](bool timed_run) {     // all chunks but the last; returns the milliseconds they took
         const auto c0 = std::chrono::steady_clock::now();
         size_t done = 0;
         while (chunk && prompt.size() - done > chunk) {
             std::vector<uint32_t> part(prompt.begin() + (long)done, prompt.begin() + (long)(done + chunk));
+            const auto b0 = std::chrono::steady_clock::now();
             (void)m.build(part, ks, vs);
+            const auto b1 = std::chrono::steady_clock::now();
             ok(cactus_hip_graph_execute(m.g), "execute");
             ok(cactus_hip_kvcache_update(m.cache, m.g, ks.data(), vs.data(), part.size()), "kvcache_update");
+            const auto b2 = std::chrono::steady_clock::now();
             ok(cactus_hip_graph_soft_reset(m.g), "soft_reset");
+            const auto b3 = std::chrono::steady_clock::now();
+            if (timed_run) {
+                chunk_parts[0] += std::chrono::duration<double, std::milli>(b1 - b0).count();
+                chunk_parts[1] += std::chrono::duration<double, std::milli>(b2 - b1).count();
+                chunk_parts[2] += std::chrono::duration<double, std::milli>(b3 - b2).count();
+            }
             m.pos += part.size();
             done += chunk;
         }
         feed.assign(prompt.begin() + (long)done, prompt.end());
-        (void)timed_run;
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
     };
     double chunks_ms = 0;
@@ -214,9 +223,10 @@ int main(int argc, char** argv) {
     const double n = timed ? (double)timed : 1.0;
     std::printf("], \"prompt_tokens\": %zu, \"prefill_ms\": %.3f, \"timed_steps\": %d, \"ms_per_token\": %.4f, \"build_ms\": %.4f, \"execute_ms\": %.4f, \"cache_update_ms\": %.4f, "
                 "\"soft_reset_ms\": %.4f, \"fused_launches\": %zu, \"pool_allocations\": %zu, "
-                "\"prefill_build_execute_update_reset_ms\": [%.3f, %.3f, %.3f, %.3f]}\n",
+                "\"prefill_build_execute_update_reset_ms\": [%.3f, %.3f, %.3f, %.3f], \"earlier_chunks_build_execute_reset_ms\": [%.3f, %.3f, %.3f]}\n",
                 prompt.size(), prefill_ms, timed, t_all / n, t_build / n, t_exec / n, t_update / n, t_reset / n, cactus_hip_graph_fused_launches(m.g),
-                cactus_hip_graph_pool_allocations(m.g), prefill_parts[0], prefill_parts[1], prefill_parts[2], prefill_parts[3]);
+                cactus_hip_graph_pool_allocations(m.g), prefill_parts[0], prefill_parts[1], prefill_parts[2], prefill_parts[3], chunk_parts[0],
+                chunk_parts[1], chunk_parts[2]);
     cactus_hip_kvcache_destroy(m.cache);
     cactus_hip_graph_destroy(m.g);
     return 0;
