@@ -46,16 +46,17 @@ namespace cactus_hip {
 namespace {
 
 constexpr int DC_BLOCK = 32;     // keys per block
-#ifndef DC_STAGES_N
-#define DC_STAGES_N 2
+#ifndef DC_AHEAD_N
+#define DC_AHEAD_N 1
 #endif
-// LDS stages per wave (V rows and both scales of a block) for head_dim 64 / 128; K rows go to two register sets whatever
-// this is (235 registers rule out a third set).  With 3, a wave computing block j has V(j+1), K(j+1) and V(j+2) in
-// flight (12 KB at head_dim 128 instead of 8); measured from HBM (cache sets in turn): 256 sequences x 512 tokens 56.2 us
-// against 55.4 with 2, 64 x 4096 104.6 / 103.1, LFM2 heads 1024 x 512 121.1 / 119.5 - bytes in flight are not what
-// bounds the stream, so 2 it stays.  head_dim 256 always has 2 (its stages are 8.7 KB).
-constexpr int DC_VSTAGES = DC_STAGES_N;
-constexpr int DC_KSETS = 2;
+// Blocks a wave requests ahead of the one it computes, head_dim 64 / 128: K rows into DC_AHEAD + 1 register sets, V rows
+// and both scales into as many LDS stages per wave.  head_dim 256 always has 1 (its stages are 8.7 KB).  Measured from
+// HBM (cache sets in turn) with the block arithmetic compiled out (-DDC_ABLATE_STREAM: requests, waits and launch shape
+// only): 256 sequences x 512 tokens 54.4 / 54.1 / 54.4 us with 1 / 2 / 3 blocks ahead, 64 x 4096 102.1 / 100.6 / 100.6,
+// LFM2 heads 1024 x 512 116.4 / 118.3 / 117.4 - the depth of the ring is not what bounds the stream, and the arithmetic
+// adds 1 to 2 us to it.  With the arithmetic, 2 ahead needs 252 registers + 36 at head_dim 128 (one wave per SIMD,
+// 60.9 us) and is slower at head_dim 64 too (127.0 against 120.5), so 1 it stays.
+constexpr int DC_AHEAD = DC_AHEAD_N;
 constexpr int DC_MAX_NEW = 8;    // FP16 tokens of the step itself (decode: 1)
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -153,7 +154,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     constexpr int NC = D / 32;                      // 32-dim column blocks
     constexpr int NG = D == 256 ? 2 : 1;            // scale groups per row (head_dim 256: two groups of 128 dims)
     constexpr int CG = NC / NG;                     // column blocks per scale group
-    constexpr int DC_STAGES = D == 256 ? 2 : DC_VSTAGES;
+    constexpr int AHEAD = D == 256 ? 1 : DC_AHEAD;
+    constexpr int DC_STAGES = AHEAD + 1, DC_KSETS = AHEAD + 1;
     constexpr int RING = NW * DC_STAGES * STAGE;
     constexpr int ROWS_OWN = FUSED && D == 256 ? 18 * D * 2 : 0;   // per wave: the fused rows when a ring stage cannot hold them
     static_assert(ROWS_OWN || !FUSED || 18 * D * 2 <= STAGE, "a stage holds the fused rows");
@@ -189,7 +191,15 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     const int8_t* Vc = a.v_cached + (size_t)b * a.cache_batch_stride;
     const float* Ks = a.k_scales + (size_t)b * a.scale_batch_stride;
     const float* Vs = a.v_scales + (size_t)b * a.scale_batch_stride;
+#ifdef DC_ABLATE_LINEAR
+    // measurement build (with DC_ABLATE_STREAM): the same bytes read as if the cache were [kv head][slot][D]
+    const size_t row_stride = (size_t)D;
+    const unsigned head_off = (unsigned)kvh * (unsigned)c_cnt * D;
+    const unsigned valid_bytes = (unsigned)c_cnt * (unsigned)Hkv * D;
+#else
     const size_t row_stride = (size_t)Hkv * D;
+    const unsigned head_off = (unsigned)kvh * D;
+#endif
 
     uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
     uint16_t* kn_lds = reinterpret_cast<uint16_t*>(lds + RING) + (FUSED ? w * D : 0);
@@ -207,7 +217,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     // pushed out of range) read as zeros and cost no memory traffic.  Requests are therefore made
     // unconditionally and the block loop has no branch around a memory operation (a branch there turns
     // every counted wait into a wait for everything).
+#ifndef DC_ABLATE_LINEAR
     const unsigned valid_bytes = (unsigned)c_cnt * (unsigned)row_stride;
+#endif
     const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Kc), 0, (int)valid_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(Vc), 0, (int)valid_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ksrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ks), 0, c_cnt * Hkv * NG * 4, 0x00020000);
@@ -215,11 +227,11 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     constexpr unsigned OOB = 0x80000000u;
     unsigned k_lane_off[2], v_lane_off[NDMA];
 #pragma unroll
-    for (int g = 0; g < 2; g++) k_lane_off[g] = (unsigned)(16 * g + hd) * (unsigned)row_stride + kvh * D + 16 * q;
+    for (int g = 0; g < 2; g++) k_lane_off[g] = (unsigned)(16 * g + hd) * (unsigned)row_stride + head_off + 16 * q;
 #pragma unroll
     for (int i = 0; i < NDMA; i++) {
         const int row = i * DMA_ROWS + dma_row;
-        v_lane_off[i] = (unsigned)row * (unsigned)row_stride + kvh * D + ((dma_chunk ^ v_swz<D>(row)) << 4);
+        v_lane_off[i] = (unsigned)row * (unsigned)row_stride + head_off + ((dma_chunk ^ v_swz<D>(row)) << 4);
     }
     // one scale per lane and request: lanes 0..32 NG - 1 the block's 32 keys (NG = 2: key lane / 2, group lane % 2),
     // the other lanes nothing
@@ -248,17 +260,25 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     };
 
     KRegs kr[DC_KSETS];
-    // FUSED: the first block of the wave's range is requested before the wave turns to its rows (whose loads, tables
-    // and arithmetic would otherwise all precede the first byte of the cache stream); the rows then sit in the ring's
+    // The first block of the wave's range is requested before the wave turns to its rows (FUSED: their loads, tables
+    // and arithmetic; otherwise the q loads), which would otherwise all precede the first byte of the cache stream
+    // (the plain launch: 256 sequences x 512 tokens 58.8 -> 55.2 us, LFM2 heads 1024 x 512 120.2 -> 117.4;
+    // -DDC_LATE_FIRST is the old order); FUSED rows then sit in the ring's
     // last stage, which later requests overwrite once the q rows are in registers
     // (head_dim 256: up to 18 rows of 512 bytes do not fit a stage and have an area of their own).  The requests are
     // unconditional like all others: a wave without blocks reads nothing.
+#ifdef DC_LATE_FIRST
     constexpr bool early = FUSED;
-    // request order: K(first), V(first), V(first + 1) .. V(first + DC_STAGES - 2); then per block j: K(j + 1), V(j + DC_STAGES - 1)
+#else
+    constexpr bool early = true;
+#endif
+    // request order: K(first), V(first) .. K(first + AHEAD - 1), V(first + AHEAD - 1); then per block j: K(j + AHEAD), V(j + AHEAD)
     auto issue_first = [&]() __attribute__((always_inline)) {
-        issue_k(blk_first, kr[0]);
 #pragma unroll
-        for (int u = 0; u < DC_STAGES - 1; u++) issue_v(blk_first + u, u);
+        for (int u = 0; u < AHEAD; u++) {
+            issue_k(blk_first + u, kr[u]);
+            issue_v(blk_first + u, u);
+        }
     };
     if constexpr (early) issue_first();
     if constexpr (FUSED) {
@@ -388,6 +408,21 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     auto compute_block = [&](auto full_tag, int blk, int stage, KRegs& kr) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         const uint8_t* st = my_lds + stage * STAGE;
+#ifdef DC_ABLATE_STREAM
+        // measurement build: the block's requests and waits as they are, none of its arithmetic (what the loads,
+        // the ring and the launch shape alone allow)
+        {
+            int x = 0;
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int ld = 0; ld < KL; ld++) x ^= kr.k[g][ld][0] ^ kr.k[g][ld][1] ^ kr.k[g][ld][2] ^ kr.k[g][ld][3];
+            v4f t = lds_read_b128(lds_addr(st) + lane * 16);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t));
+            oacc[0][0][0] += __int_as_float(x & 0xFF) + t[0];
+            return;
+        }
+#endif
         const int kb = blk * DC_BLOCK;
         const int nv = min(DC_BLOCK, c_cnt - kb);            // valid keys of the block (wave-uniform)
         // Every LDS read of the loop is issued here, by hand: the compiler orders an LDS read it can see behind
@@ -530,9 +565,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         }
     };
 
-    // this wave's blocks, requested ahead of their use: K one block ahead into the other of two register sets, V
-    // DC_STAGES - 1 blocks ahead into the LDS stage whose block was consumed last; the counted waits leave exactly the
-    // requests issued after K(j) in flight when block j is computed.  Requests are unconditional (past the wave's share they read nothing); only the arithmetic of
+    // this wave's blocks, requested AHEAD blocks before their use: K into the register set, V into the LDS stage whose
+    // block was consumed last; the counted waits leave exactly the requests issued after V(j) in flight when block j is
+    // computed.  Requests are unconditional (past the wave's share they read nothing); only the arithmetic of
     // a block that does not exist is skipped.  Every lane runs every iteration: the transposed reads need
     // all lanes.  A stage is rewritten by the requests issued after its consumer, whose LDS reads have
     // completed by then (the consumer waited for them).
@@ -544,21 +579,17 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
             else compute_block(std::false_type{}, bk, stage, k);
         };
         constexpr int K_OPS = 2 * KL, V_OPS = NDMA + 2;    // vector-memory operations of a block's K and V requests
-        // what may still be in flight when K(j) and V(j) must have landed: the requests issued after K(j)
-        constexpr int LEAVE = DC_STAGES == 2 ? K_OPS + V_OPS : K_OPS + 2 * V_OPS;
+        // what may still be in flight when K(j) and V(j) must have landed: the requests issued after V(j)
+        constexpr int LEAVE = AHEAD * (K_OPS + V_OPS);
         if constexpr (!early) issue_first();
-        int vs = 0;                                        // LDS stage of block blk
         for (int it = 0; it < mine; it += DC_KSETS) {
 #pragma unroll
-            for (int u = 0; u < DC_KSETS; u++) {
-                int vn = vs + DC_STAGES - 1;
-                if (vn >= DC_STAGES) vn -= DC_STAGES;
-                issue_k(blk + 1, kr[u ^ 1]);
-                issue_v(blk + DC_STAGES - 1, vn);
+            for (int u = 0; u < DC_KSETS; u++) {           // block blk sits in register set u and LDS stage u
+                issue_k(blk + AHEAD, kr[(u + AHEAD) % DC_KSETS]);
+                issue_v(blk + AHEAD, (u + AHEAD) % DC_STAGES);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
-                if (it + u < mine) compute(blk, vs, kr[u]);
+                if (it + u < mine) compute(blk, u, kr[u]);
                 blk++;
-                vs = vs + 1 == DC_STAGES ? 0 : vs + 1;
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last, empty requests still write this wave's LDS
