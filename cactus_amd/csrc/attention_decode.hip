@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
     constexpr int RING = NW * DC_STAGES * STAGE;
     constexpr int ROWS_OWN = FUSED && D == 256 ? 18 * D * 2 : 0;   // per wave: the fused rows when a ring stage cannot hold them
     static_assert(ROWS_OWN || !FUSED || 18 * D * 2 <= STAGE, "a stage holds the fused rows");
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0) + NW * ROWS_OWN];   // + each wave's rotated key row (+ its absmax) (+ rows)
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RING + (FUSED ? NW * D * 4 : 0) + (QOUT ? NW * 4 : 0) + NW * ROWS_OWN];   // + each wave's rotated key row and value row (+ its absmax) (+ rows)
 
     const AttnArgs& a = p.a;
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,8 +202,9 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
 #endif
 
     uint8_t* my_lds = lds + w * (DC_STAGES * STAGE);
-    uint16_t* kn_lds = reinterpret_cast<uint16_t*>(lds + RING) + (FUSED ? w * D : 0);
-    uint8_t* rows_lds = ROWS_OWN ? lds + RING + (FUSED ? NW * D * 2 : 0) + (QOUT ? NW * 4 : 0) + w * ROWS_OWN : my_lds + (DC_STAGES - 1) * STAGE;
+    uint16_t* kn_lds = reinterpret_cast<uint16_t*>(lds + RING) + (FUSED ? w * 2 * D : 0);
+    uint16_t* vn_lds = kn_lds + D;       // FUSED: the step's own value row, kept for the last softmax step (no load at the tail)
+    uint8_t* rows_lds = ROWS_OWN ? lds + RING + (FUSED ? NW * D * 4 : 0) + (QOUT ? NW * 4 : 0) + w * ROWS_OWN : my_lds + (DC_STAGES - 1) * STAGE;
     struct KRegs { v4i k[2][KL]; };
     // per-lane pieces of the addresses
     constexpr int ROW_CHUNKS = D / 16;                               // 16-byte chunks of a row
@@ -344,6 +345,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
                     for (int c = l; c < D / 8; c += 16)
                         *reinterpret_cast<v4i*>(f.k_out + ((size_t)b * Hkv + kvh) * D + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
             }
+            if (act && is_v)
+                for (int c = l; c < D / 8; c += 16) *reinterpret_cast<v4i*>(vn_lds + c * 8) = *reinterpret_cast<const v4i*>(nrm + c * 8);
             if (act && place && !is_q)
                 quant_row_groups(nrm, D, (int)a.qgs, (is_k ? f.kc : f.vc) + doff, (is_k ? f.ks : f.vs) + soff, l);
         }
@@ -629,7 +632,8 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
         l_part = l_part * corr + pt;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const v8h vv = *reinterpret_cast<const v8h*>(vn + 32 * c + 8 * q);
+            const v8h vv = FUSED ? *reinterpret_cast<const v8h*>(vn_lds + 32 * c + 8 * q)
+                                 : *reinterpret_cast<const v8h*>(vn + 32 * c + 8 * q);
 #pragma unroll
             for (int e = 0; e < 2; e++)
 #pragma unroll
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_mfma_kernel(const DecodeP
                     m = fmaxf(m, fabsf(h2f(v)));
                 }
         m = wave_max(m);
-        float* smax = reinterpret_cast<float*>(lds + RING + (FUSED ? NW * D * 2 : 0));
+        float* smax = reinterpret_cast<float*>(lds + RING + (FUSED ? NW * D * 4 : 0));
         if (lane == 0) smax[w] = m;
         __syncthreads();
         float rm = smax[0];
