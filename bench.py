@@ -796,6 +796,12 @@ def extra_table(H, gen, big):
                 gb = gemv_bytes(M, K, N, int4) / (ms * 1e-3) / 1e9
                 rows[f"K{K}_N{N}"] = {"us": round(ms * 1e3, 2), "GBps": round(gb, 1),
                                       "frac_hbm": round(gb / HBM_PEAK_GBPS, 3)}
+                if M > 4:     # rows the launch does not quantize itself: also on INT8 rows, the reference kernel's own signature
+                    q, sc = H.quantize_activations(x)
+                    fn = H.matmul_int4 if int4 else H.matmul_int8
+                    ms = time_graph(lambda i: fn(q, sc, ws[i % nb][0], ws[i % nb][1], 128, out=o), max(nb, 16))
+                    gb = gemv_bytes(M, K, N, int4) / (ms * 1e-3) / 1e9
+                    rows[f"K{K}_N{N}"].update({"us_int8_rows_in": round(ms * 1e3, 2), "frac_hbm_int8_rows_in": round(gb / HBM_PEAK_GBPS, 3)})
                 del ws            # (a packed tensor's twin goes with it)
             ex[f"gemv_{tag}_M{M}"] = rows
     # M = 512 GEMM: MFMA rate
