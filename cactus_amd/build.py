@@ -70,7 +70,7 @@ def build_examples(force=False, verbose=False):
     inc = os.path.join(root, "include")
     hdrs = [os.path.join(inc, h) for h in ("cactus_hip.h", "cactus_hip_graph.h", "cactus_hip_steps.h")]
     built = []
-    for name in ("qwen_graph_decode", "qwen_batched_decode", "qwen_prompt_decode"):
+    for name in ("qwen_graph_decode", "qwen_batched_decode", "qwen_prompt_decode", "host_pointer_calls"):
         src = os.path.join(root, "examples", name + ".cpp")
         exe = os.path.join(LIBDIR, name)
         if not os.path.exists(src):

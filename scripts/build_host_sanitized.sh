@@ -1,7 +1,7 @@
 #!/bin/bash
 # Host-side AddressSanitizer + UBSan build of the library and the C++ host examples (device code is untouched:
 # -Xarch_host puts the sanitizers on the host compilation only).  Output: scripts/variants/san/{libcactus_hip.so,
-# qwen_graph_decode, qwen_batched_decode, qwen_prompt_decode}.  Run the examples on the GPU box as usual.
+# qwen_graph_decode, qwen_batched_decode, qwen_prompt_decode, host_pointer_calls}.  Run the examples on the GPU box as usual.
 set -e
 cd "$(dirname "$0")/.."
 out=scripts/variants/san; mkdir -p $out
@@ -18,7 +18,7 @@ for s in quant_kernels.hip matmul_skinny.hip matmul_gemm.hip matmul_generic.hip 
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -fsanitize=undefined -o $out/libcactus_hip.so $objs -ldl
-for e in qwen_graph_decode qwen_batched_decode qwen_prompt_decode; do
+for e in qwen_graph_decode qwen_batched_decode qwen_prompt_decode host_pointer_calls; do
   hipcc -O1 -g -std=c++17 -DEXIT_WITHOUT_TEARDOWN -fsanitize=address -fsanitize=undefined -I include examples/$e.cpp -L $out -lcactus_hip '-Wl,-rpath,$ORIGIN' -o $out/$e
 done
 ls -la $out | grep -v "\.o$"

@@ -164,3 +164,21 @@ def test_cpp_host_prompt_then_decode(tmp_path, chunk, lanes):
         tok = int(O.sample_greedy(ref[None])[0])
         assert got[1 + s] == tok, (s, got)
         pos += 1
+
+
+HOSTPTR_EXE = os.path.join(os.path.dirname(EXE), "host_pointer_calls")
+
+
+def test_cpp_host_pointer_family_links_and_is_deterministic():
+    """examples/host_pointer_calls.cpp: every host-pointer entry (the reference's argument lists, kernel.h:20-24, 41-104)
+    called from a plain C++ host on host buffers, the weight matmuls repeatedly over resident, rewritten and released
+    weights.  Two runs give the same checksum of all outputs (what each entry computes is compared with the oracle in
+    tests/test_gpu_parity.py; this is the C++ linkage and the residency bookkeeping)."""
+    assert os.path.exists(HOSTPTR_EXE), "cactus_amd/lib/host_pointer_calls is not built"
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([HOSTPTR_EXE, "3"], capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["host_pointer_calls"] == "ok"
+    assert outs[0]["checksum"] == outs[1]["checksum"]
