@@ -20,8 +20,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # costs more than the two v_fma_f32 it replaces: keep the SLP vectorizer from packing them.
 # The decode attention rescales its MFMA accumulators with VALU code: keep them in VGPRs (the default puts
 # them in AGPRs and copies them back and forth around every use).
+# The streaming matmuls read every MFMA result with VALU code right away (conversion, fp32 chain or LDS store): in
+# VGPR form the batched INT8 kernel needs 80 registers instead of 92 + 4 (6 waves per SIMD instead of 5), the
+# one-wave-per-tile kernel 126 instead of 168 + 32, and the copies out of the AGPRs go.
 EXTRA_FLAGS = {"matmul_gemm.hip": ["-fno-slp-vectorize"],
-               "attention_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+               "attention_decode.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               "matmul_skinny.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale(target, deps):

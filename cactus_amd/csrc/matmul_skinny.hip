@@ -427,6 +427,9 @@ __device__ __forceinline__ v4i act_mul8_bits(v4i g, v4i u) {
 // vocabulary projection: 9496 tiles of 1024 bytes per row): each wave then has its whole tile in flight at
 // once.  Rows of several ring rounds stream faster split over the waves (the default), whose reads of one
 // row are adjacent.  Needs K % 1024 == 0 (a round is 8 groups = one 16-byte chunk of scales).
+#ifndef SK_A_PRESPLIT
+#define SK_A_PRESPLIT 1
+#endif
 template <bool INT4, int W, int P, int CT, int PRO = 0, bool WT = false>
 __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* __restrict__ scales_out,
                                         const uint8_t* __restrict__ B, const uint16_t* __restrict__ B_scales,
@@ -479,7 +482,6 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         const_cast<uint16_t*>(B_scales), 0, (int)min((size_t)N * G * 2, (size_t)0x7FFFFFFF), 0x00020000);
     const int arow = min(r, M - 1);
     const int8_t* aptr_lds = lds_a + (size_t)arow * K + (INT4 ? q * 32 : q * 16);
-    const bool a_live = r < M;
     const v4i zero4 = {0, 0, 0, 0};
     const int nunits = G / GPU_;
     const bool sc_fast_shape = ((G & 7) == 0) && (TR * G / 8 <= CT * W * 64) &&
@@ -535,10 +537,14 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             for (int i = 0; i < 4; i++) run[i] = fmaf((float)acc[i], sv, run[i]);
             return;
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int m = q * 4 + i;
-            if (m < M && gl < G) gbuf[((ct * M + m) * 16 + r) * SCP + gl] = (float)acc[i];
+        // M <= 4: the rows m = 4 q + i that exist sit in the lanes of q = 0; one lane test per group, then tests on M
+        // that the whole wave shares (no conversion or store is issued for a row that does not exist)
+        if (q == 0 && gl < G) {
+            float* dst = gbuf + ((size_t)(ct * M) * 16 + r) * SCP + gl;
+            dst[0] = (float)acc[0];
+            if (M > 1) dst[16 * SCP] = (float)acc[1];
+            if (M > 2) dst[32 * SCP] = (float)acc[2];
+            if (M > 3) dst[48 * SCP] = (float)acc[3];
         }
     };
     auto compute_unit = [&](int u, const Unit& R, int pslot) {
@@ -548,12 +554,18 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 v4i ae, ao;
+                // (MFMA rows m >= M hold whatever row M - 1 gives: no one reads them, so nothing is zeroed)
+                if constexpr (SK_A_PRESPLIT) {      // the spans in LDS are [even | odd] already
+                    ae = a[2 * h];
+                    ao = a[2 * h + 1];
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t lo = (uint32_t)a[2 * h + (i >> 1)][(2 * i) & 3];
-                    const uint32_t hi = (uint32_t)a[2 * h + (i >> 1)][((2 * i) & 3) + 1];
-                    ae[i] = a_live ? (int)__builtin_amdgcn_perm(hi, lo, 0x06040200u) : 0;
-                    ao[i] = a_live ? (int)__builtin_amdgcn_perm(hi, lo, 0x07050301u) : 0;
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t lo = (uint32_t)a[2 * h + (i >> 1)][(2 * i) & 3];
+                        const uint32_t hi = (uint32_t)a[2 * h + (i >> 1)][((2 * i) & 3) + 1];
+                        ae[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x06040200u);
+                        ao[i] = (int)__builtin_amdgcn_perm(hi, lo, 0x07050301u);
+                    }
                 }
 #pragma unroll
                 for (int ct = 0; ct < CT; ct++) {
@@ -572,9 +584,7 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             }
         } else {
             const int8_t* ap = aptr_lds + (size_t)min(u, nunits - 1) * 128;
-            v4i a0 = ldg(ap), a1 = ldg(ap + 64);
-            a0 = a_live ? a0 : zero4;
-            a1 = a_live ? a1 : zero4;
+            const v4i a0 = ldg(ap), a1 = ldg(ap + 64);
 #pragma unroll
             for (int ct = 0; ct < CT; ct++) {
                 v4i acc = zero4;
@@ -715,7 +725,18 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         auto quant_piece = [&](int i16, v4i x) {
             const int row = row_of(i16);
             const float iv = row == 0 ? inv[0] : (row == 1 ? inv[1] : (row == 2 ? inv[2] : inv[3]));
-            *reinterpret_cast<uint2*>(lds_a + (size_t)i16 * 8) = quant8_bits(x, iv);
+            const uint2 qv = quant8_bits(x, iv);
+            if constexpr (INT4 && SK_A_PRESPLIT) {
+                // a packed weight byte holds elements 2j (low nibble) and 2j + 1 of its row, so the MFMAs take the even
+                // and the odd elements of 32 activations separately: every 32-byte span is stored as [16 even | 16 odd]
+                // once here instead of being split by every wave at every unit (K % 32 == 0: a piece stays in its row)
+                int8_t* span = lds_a + (((size_t)i16 * 8) & ~(size_t)31);
+                const int p0 = (i16 * 8) & 31;
+                *reinterpret_cast<uint32_t*>(span + (p0 >> 1)) = __builtin_amdgcn_perm(qv.y, qv.x, 0x06040200u);
+                *reinterpret_cast<uint32_t*>(span + 16 + (p0 >> 1)) = __builtin_amdgcn_perm(qv.y, qv.x, 0x07050301u);
+            } else {
+                *reinterpret_cast<uint2*>(lds_a + (size_t)i16 * 8) = qv;
+            }
         };
 #pragma unroll
         for (int j = 0; j < AST; j++) {

@@ -10,7 +10,7 @@ objs=""
 for s in quant_kernels.hip matmul_skinny.hip matmul_gemm.hip matmul_generic.hip matmul_f16.hip attention.hip attention_decode.hip attention_prefill.hip block_ops.hip conv_ops.hip sampler.hip comm.hip api.hip graph.cpp steps.cpp; do
   extra=""; lang=""
   [ $s = matmul_gemm.hip ] && extra="-fno-slp-vectorize"
-  [ $s = attention_decode.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+  [ $s = attention_decode.hip -o $s = matmul_skinny.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
   case $s in *.cpp) lang="-x hip";; esac
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $SAN $extra $lang -c cactus_amd/csrc/$s -o $out/$s.o &
   objs="$objs $out/$s.o"
