@@ -533,8 +533,12 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             const uint32_t x = (uint32_t)sc_cur[j8 >> 1];
             float sv = h2f((uint16_t)((j8 & 1) ? (x >> 16) : (x & 0xFFFFu)));
             if (INT4) sv *= 0.0625f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) run[i] = fmaf((float)acc[i], sv, run[i]);
+            run[0] = fmaf((float)acc[0], sv, run[0]);
+            if (M > 1) {            // tests the whole wave shares: one row is the common case
+                run[1] = fmaf((float)acc[1], sv, run[1]);
+                if (M > 2) run[2] = fmaf((float)acc[2], sv, run[2]);
+                if (M > 3) run[3] = fmaf((float)acc[3], sv, run[3]);
+            }
             return;
         }
         // M <= 4: the rows m = 4 q + i that exist sit in the lanes of q = 0; one lane test per group, then tests on M
