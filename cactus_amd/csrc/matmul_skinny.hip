@@ -387,6 +387,7 @@ struct FqPro {
     const uint16_t* w = nullptr;
     uint16_t* sum_out = nullptr;
     float eps = 0.0f;
+    int chains = 0;     // PRO 1: the LDS region holds a second copy of the summed rows, chain by chain (see fq_body)
 };
 
 __device__ __forceinline__ v4i add8_bits(v4i a, v4i b) {
@@ -451,6 +452,10 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
     float* wmax = reinterpret_cast<float*>(lds_a + (((size_t)M * K + 15) & ~(size_t)15));   // [W][4]
     float* s_inv = wmax + W * 4;                                                            // [4]      (PRO 1)
     uint16_t* lds_x = reinterpret_cast<uint16_t*>(s_inv + 4);                               // [M][K]   (PRO 1)
+    // [M][16][K / 16 + 8] (PRO 1, pro.chains): the same rows, the 16 accumulation chains of the norm's sum of squares
+    // each contiguous (elements c, c + 16, c + 32 ...), so that a chain's lane reads 8 elements per LDS instruction; the
+    // 16 bytes between chains put the 16 lanes' reads on different banks
+    uint16_t* lds_t = lds_x + (size_t)M * K;
 
 #ifdef FQ_TRACE
     int fqt_slot = -1;
@@ -639,6 +644,17 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
             const v4i sv = pro.x2 ? add8_bits(x, d) : x;
             *reinterpret_cast<v4i*>(lds_x + (size_t)i16 * 8) = sv;
             if (pro.sum_out != nullptr && tl == 0) *reinterpret_cast<v4i*>(pro.sum_out + (size_t)i16 * 8) = sv;
+            if (pro.chains) {       // elements k0 .. k0 + 7 of a row: position k0 / 16 of the chains k0 % 16 .. + 7
+                const int e0 = i16 * 8;
+                const int row = (M > 1 && e0 >= K) + (M > 2 && e0 >= 2 * K) + (M > 3 && e0 >= 3 * K);
+                const int k0 = e0 - row * K, cl = (K >> 4) + 8;
+                uint16_t* dst = lds_t + (size_t)(row * 16 + (k0 & 15)) * cl + (k0 >> 4);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t wd = (uint32_t)sv[j >> 1];
+                    dst[j * cl] = (uint16_t)((j & 1) ? (wd >> 16) : (wd & 0xFFFFu));
+                }
+            }
         };
 #pragma unroll
         for (int j = 0; j < AST; j++) {
@@ -653,7 +669,9 @@ __device__ __forceinline__ void fq_body(const uint16_t* __restrict__ X, float* _
         asm volatile("" ::: "memory");
         if (w == 0 && (lane >> 4) < M) {      // one 16-lane group per row
             const uint16_t* xr = lds_x + (size_t)(lane >> 4) * K;
-            const float inv = row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, K, pro.eps, lane & 15, lane & ~15);
+            const float inv = pro.chains
+                ? row_inv_rms_chain(lds_t + (size_t)((lane >> 4) * 16 + (lane & 15)) * ((K >> 4) + 8), K, pro.eps, lane & 15, lane & ~15)
+                : row_inv_rms([&](int i) -> uint16_t { return xr[i]; }, K, pro.eps, lane & 15, lane & ~15);
             if ((lane & 15) == 0) s_inv[lane >> 4] = inv;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1357,7 +1375,12 @@ hipError_t launch_matmul_skinny_fq_batch_pro(bool int4, int kind, const SkinnyPr
         if (q.packed) bt.pk_mask |= 1u << i;
         const int wt = sub_waves(int4, q.K, 0);
         size_t l = fq_lds_bytes(int4, wt, 1, q.M, q.K) + 16;            // + the rows' 1 / rms
-        if (kind == 1) l += 2 * q.M * q.K;                              // + the summed rows (binary16)
+        if (kind == 1) {
+            l += 2 * q.M * q.K;                                         // + the summed rows (binary16)
+            const size_t with_chains = (l + 2 * q.M * q.K + 256 * q.M + 15) & ~(size_t)15;
+            if (i == 0) bt.pro.chains = with_chains * (4 / wt) <= 64 * 1024;    // + the same rows chain by chain, if they fit
+            if (bt.pro.chains) l = with_chains;
+        }
         l = (l + 15) & ~(size_t)15;
         bt.wt[i] = wt;
         bt.lds_floats[i] = (int)(l / sizeof(float));
