@@ -253,7 +253,7 @@ def main():
 
     gen = torch.Generator(device="cuda").manual_seed(42 + rank)
 
-    # ---- workload: two complete weight sets, FP16 activation rows per K
+    # ---- workload: NS complete weight sets used in turn (more than the 256 MB Infinity Cache holds), FP16 activation rows per K
     sets = []
     NS = max(2, args.weight_sets)
     for _ in range(NS):
