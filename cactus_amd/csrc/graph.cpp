@@ -145,17 +145,26 @@ const BufferDesc& CactusGraph::get_output_buffer(size_t node_id) const { return 
 // leaves that builder unusable: no model calls it).
 size_t CactusGraph::add_node(OpType op_type, const std::vector<size_t>& inputs,
                              const std::vector<size_t>& output_shape, const OpParams& params) {
-    auto n = std::make_unique<GraphNode>();
+    std::unique_ptr<GraphNode> n;
+    if (!spare_nodes_.empty()) {            // a node of an earlier pass: everything reset, the vectors' storage kept
+        n = std::move(spare_nodes_.back());
+        spare_nodes_.pop_back();
+        std::vector<size_t> ids = std::move(n->input_ids), shp = std::move(n->output_buffer.shape);
+        *n = GraphNode();
+        n->input_ids = std::move(ids);
+        n->output_buffer.shape = std::move(shp);
+    } else {
+        n = std::make_unique<GraphNode>();
+    }
     n->id = next_node_id_;
     n->op_type = op_type;
     n->input_ids = inputs;
     n->params = params;
-    std::vector<size_t> shape = output_shape;
-    if (shape.empty() && !inputs.empty()) shape = node(inputs[0]).output_buffer.shape;
+    const std::vector<size_t>& shape = output_shape.empty() && !inputs.empty() ? node(inputs[0]).output_buffer.shape : output_shape;
     Precision prec = params.output_precision;
     if (op_type != OpType::QUANTIZE_ACTIVATIONS && prec == Precision::INT8 && !inputs.empty())
         prec = node(inputs[0]).output_buffer.precision;
-    n->output_buffer.shape = shape;
+    n->output_buffer.shape.assign(shape.begin(), shape.end());
     n->output_buffer.precision = prec;
     n->output_buffer.total_size = product(shape);
     n->output_buffer.byte_size = n->output_buffer.total_size * precision_size(prec);
@@ -1452,8 +1461,12 @@ static void free_node(GraphNode& n, CactusGraph::DevicePool& pool) {
 void CactusGraph::soft_reset() {   // graph_execute.cpp:640-675: weights survive, everything else goes
     std::vector<std::unique_ptr<GraphNode>> keep;
     for (auto& up : nodes_) {
-        if (is_weight_.count(up->id)) keep.push_back(std::move(up));
-        else free_node(*up, pool_);
+        if (is_weight_.count(up->id)) {
+            keep.push_back(std::move(up));
+        } else {
+            free_node(*up, pool_);
+            if (spare_nodes_.size() < 4096) spare_nodes_.push_back(std::move(up));
+        }
     }
     nodes_ = std::move(keep);
     node_index_map_.clear();
@@ -1469,6 +1482,7 @@ void CactusGraph::hard_reset() {
     twins_.clear();
     for (auto& up : nodes_) free_node(*up, pool_);
     nodes_.clear();
+    spare_nodes_.clear();
     node_index_map_.clear();
     is_weight_.clear();
     weight_cache_.clear();

@@ -281,6 +281,9 @@ private:
     std::vector<std::vector<size_t>> consumers_;   // per node index: indices of the nodes that read it (this execute())
 
     std::vector<std::unique_ptr<GraphNode>> nodes_;
+    // nodes a soft reset took out of the graph, kept for the next pass's add_node: a decode loop builds and drops
+    // the same ~700 nodes per token, and their allocations were a third of what a token costs the host
+    std::vector<std::unique_ptr<GraphNode>> spare_nodes_;
     std::unordered_map<size_t, size_t> node_index_map_;
     size_t next_node_id_ = 0;
     std::unordered_map<size_t, bool> is_weight_;   // node id -> bound with set_external_input
