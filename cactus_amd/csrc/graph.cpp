@@ -1289,7 +1289,8 @@ void CactusGraph::execute() {
     for (auto& up : nodes_)
         if (up->op_type != OpType::INPUT) up->output_buffer.device_valid = false;
     std::vector<char> done(nodes_.size(), 0);
-    consumers_.assign(nodes_.size(), {});
+    if (consumers_.size() < nodes_.size()) consumers_.resize(nodes_.size());     // the lists keep their storage from pass to pass
+    for (size_t i = 0; i < nodes_.size(); i++) consumers_[i].clear();
     for (size_t idx = 0; idx < nodes_.size(); idx++)
         for (size_t in : nodes_[idx]->input_ids) {
             auto it = node_index_map_.find(in);
