@@ -136,8 +136,28 @@ void CactusGraph::DevicePool::clear() {
 CactusGraph::CactusGraph() = default;
 CactusGraph::~CactusGraph() { hard_reset(); }
 
-GraphNode& CactusGraph::node(size_t id) { return *nodes_[node_index_map_.at(id)]; }
-const GraphNode& CactusGraph::node(size_t id) const { return *nodes_[node_index_map_.at(id)]; }
+// Nodes added since the last reset sit behind the kept ones in id order, so their index is arithmetic; only the kept
+// nodes (weights, whose ids are older) go through the map - a decode loop's ~700 nodes per token no longer cost a hash
+// insertion each.
+bool CactusGraph::find_index(size_t id, size_t* idx) const {
+    if (id >= pass_base_id_) {
+        const size_t i = pass_base_idx_ + (id - pass_base_id_);
+        if (i >= nodes_.size()) return false;
+        *idx = i;
+        return true;
+    }
+    auto it = node_index_map_.find(id);
+    if (it == node_index_map_.end()) return false;
+    *idx = it->second;
+    return true;
+}
+size_t CactusGraph::index_of(size_t id) const {
+    size_t i = 0;
+    if (!find_index(id, &i)) throw std::out_of_range("CactusGraph: no node with id " + std::to_string(id));
+    return i;
+}
+GraphNode& CactusGraph::node(size_t id) { return *nodes_[index_of(id)]; }
+const GraphNode& CactusGraph::node(size_t id) const { return *nodes_[index_of(id)]; }
 const BufferDesc& CactusGraph::get_output_buffer(size_t node_id) const { return node(node_id).output_buffer; }
 
 // graph_builder.cpp:572-596.  One deliberate difference: a QUANTIZE_ACTIVATIONS node keeps the
@@ -169,7 +189,6 @@ size_t CactusGraph::add_node(OpType op_type, const std::vector<size_t>& inputs,
     n->output_buffer.total_size = product(shape);
     n->output_buffer.byte_size = n->output_buffer.total_size * precision_size(prec);
     const size_t id = next_node_id_++;
-    node_index_map_[id] = nodes_.size();
     nodes_.push_back(std::move(n));
     return id;
 }
@@ -1029,7 +1048,7 @@ void CactusGraph::launch_produced(int kind, bool int4, const std::vector<size_t>
 bool CactusGraph::try_fuse_norm(size_t norm_idx, std::vector<char>& done) {
     GraphNode& r = *nodes_[norm_idx];
     if (r.op_type != OpType::RMS_NORM) return false;
-    const size_t src_idx = node_index_map_.at(r.input_ids[0]);
+    const size_t src_idx = index_of(r.input_ids[0]);
     GraphNode& src = *nodes_[src_idx];
     const BufferDesc& w = node(r.input_ids[1]).output_buffer;
     const BufferDesc& shape_of = src.output_buffer;
@@ -1071,7 +1090,7 @@ bool CactusGraph::try_fuse_norm(size_t norm_idx, std::vector<char>& done) {
 bool CactusGraph::try_fuse_activation(size_t mul_idx, std::vector<char>& done) {
     GraphNode& m = *nodes_[mul_idx];
     if (m.op_type != OpType::MULTIPLY || m.input_ids.size() != 2) return false;
-    const size_t act_idx = node_index_map_.at(m.input_ids[0]);
+    const size_t act_idx = index_of(m.input_ids[0]);
     GraphNode& act = *nodes_[act_idx];
     if (act.op_type != OpType::SILU && act.op_type != OpType::GELU) return false;
     if (done[act_idx] || consumers_[act_idx].size() != 1) return false;
@@ -1103,7 +1122,7 @@ void CactusGraph::materialize(size_t idx) {
         n.op_type != OpType::MULTIPLY && n.op_type != OpType::RESHAPE && n.op_type != OpType::ROPE)
         return;
     for (size_t in : n.input_ids) {
-        materialize(node_index_map_.at(in));
+        materialize(index_of(in));
         if (!node(in).output_buffer.device_valid) return;
     }
     if (n.op_type == OpType::RESHAPE) {
@@ -1142,24 +1161,24 @@ bool CactusGraph::match_attention_chain(size_t attn_idx, AttnChain* out, size_t*
     const size_t S = q.shape[1], D = q.shape[3], Hkv = kb.shape[2];
     if (Hkv == 0 || q.shape[2] % Hkv != 0 || kb.shape[3] != D) return false;
     auto chain = [&](size_t rope_id, size_t heads, size_t* norm_i, size_t* view_i, size_t* rope_i, size_t* src_id) {
-        auto it = node_index_map_.find(rope_id);
-        if (it == node_index_map_.end()) return false;
-        const GraphNode& rope = *nodes_[it->second];
+        size_t rope_idx = 0;
+        if (!find_index(rope_id, &rope_idx)) return false;
+        const GraphNode& rope = *nodes_[rope_idx];
         if (rope.op_type != OpType::ROPE || rope.params.backend == ComputeBackend::NPU) return false;
         const std::vector<size_t>& rs = rope.output_buffer.shape;
         if (rs.size() != 4 || rs[0] != 1 || rs[1] != S || rs[2] != heads || rs[3] != D) return false;
-        if (rope.output_buffer.precision != Precision::FP16 || consumers_[it->second].size() != 1) return false;
-        const size_t vi = node_index_map_.at(rope.input_ids[0]);
+        if (rope.output_buffer.precision != Precision::FP16 || consumers_[rope_idx].size() != 1) return false;
+        const size_t vi = index_of(rope.input_ids[0]);
         const GraphNode& view = *nodes_[vi];
         if (view.op_type != OpType::RESHAPE || consumers_[vi].size() != 1) return false;
-        const size_t ni = node_index_map_.at(view.input_ids[0]);
+        const size_t ni = index_of(view.input_ids[0]);
         const GraphNode& norm = *nodes_[ni];
         if (norm.op_type != OpType::RMS_NORM || consumers_[ni].size() != 1) return false;
         const BufferDesc& in = node(norm.input_ids[0]).output_buffer;
         const BufferDesc& w = node(norm.input_ids[1]).output_buffer;
         if (in.shape.size() != 2 || in.shape[0] != S * heads || in.shape[1] != D || in.precision != Precision::FP16) return false;
         if (w.precision != Precision::FP16 || w.total_size < D || !w.device_valid) return false;
-        *norm_i = ni; *view_i = vi; *rope_i = it->second; *src_id = norm.input_ids[0];
+        *norm_i = ni; *view_i = vi; *rope_i = rope_idx; *src_id = norm.input_ids[0];
         return true;
     };
     AttnChain c;
@@ -1293,8 +1312,8 @@ void CactusGraph::execute() {
     for (size_t i = 0; i < nodes_.size(); i++) consumers_[i].clear();
     for (size_t idx = 0; idx < nodes_.size(); idx++)
         for (size_t in : nodes_[idx]->input_ids) {
-            auto it = node_index_map_.find(in);
-            if (it != node_index_map_.end()) consumers_[it->second].push_back(idx);
+            size_t pi = 0;
+            if (find_index(in, &pi)) consumers_[pi].push_back(idx);
         }
     for (size_t idx = 0; idx < nodes_.size(); idx++) {
         GraphNode& n = *nodes_[idx];
@@ -1325,7 +1344,7 @@ void CactusGraph::execute() {
                 node(n.input_ids[0]).output_buffer.device_valid)
                 continue;               // not done: the multiply decides
             if (n.op_type == OpType::MULTIPLY) {
-                const size_t a_idx = node_index_map_.at(n.input_ids[0]);
+                const size_t a_idx = index_of(n.input_ids[0]);
                 if (!done[a_idx]) {     // the activation deferred above
                     if (node(n.input_ids[1]).output_buffer.device_valid && try_fuse_activation(idx, done)) continue;
                     materialize(a_idx);
@@ -1338,14 +1357,14 @@ void CactusGraph::execute() {
                 deferred_to_attention(idx))
                 continue;               // not done: the attention node decides
             if (n.op_type == OpType::ATTENTION_INT8_HYBRID || n.op_type == OpType::ATTENTION) {
-                const size_t q_idx = node_index_map_.at(n.input_ids[0]);
+                const size_t q_idx = index_of(n.input_ids[0]);
                 if (!done[q_idx]) {     // the run deferred above
                     if (n.op_type == OpType::ATTENTION_INT8_HYBRID && try_fuse_decode_attention(idx, done)) continue;
                     if (!try_fuse_norm_rope(idx, done))
                     for (int s = 0; s < 2; s++) {           // the plain path: compute what was left for this node
-                        const size_t r = node_index_map_.at(n.input_ids[s]);
-                        const size_t v = node_index_map_.at(nodes_[r]->input_ids[0]);
-                        const size_t m = node_index_map_.at(nodes_[v]->input_ids[0]);
+                        const size_t r = index_of(n.input_ids[s]);
+                        const size_t v = index_of(nodes_[r]->input_ids[0]);
+                        const size_t m = index_of(nodes_[v]->input_ids[0]);
                         materialize(r);
                         done[m] = done[v] = done[r] = 1;
                     }
@@ -1432,13 +1451,13 @@ void CactusGraph::execute() {
 
 void* CactusGraph::get_device_output(size_t node_id) {
     BufferDesc& b = node(node_id).output_buffer;
-    if (!b.device_valid) materialize(node_index_map_.at(node_id));   // a node a fused launch skipped
+    if (!b.device_valid) materialize(index_of(node_id));   // a node a fused launch skipped
     return b.device_data;
 }
 
 void* CactusGraph::get_output(size_t node_id) {   // graph_execute.cpp:223-229; synchronises
     BufferDesc& b = node(node_id).output_buffer;
-    if (!b.device_valid) materialize(node_index_map_.at(node_id));   // a node a fused launch skipped
+    if (!b.device_valid) materialize(index_of(node_id));   // a node a fused launch skipped
     if (!b.device_valid || b.device_data == nullptr) return nullptr;
     b.host_copy.resize(b.byte_size);
     hip_check(hipMemcpy(b.host_copy.data(), b.device_data, b.byte_size, hipMemcpyDeviceToHost), "hipMemcpy D2H");
@@ -1470,8 +1489,20 @@ void CactusGraph::soft_reset() {   // graph_execute.cpp:640-675: weights survive
         }
     }
     nodes_ = std::move(keep);
-    node_index_map_.clear();
-    for (size_t i = 0; i < nodes_.size(); i++) node_index_map_[nodes_[i]->id] = i;
+    // the kept nodes' places (normally the same as after the last reset: nothing to insert); what this pass adds is
+    // found by arithmetic
+    if (node_index_map_.size() > nodes_.size()) node_index_map_.clear();      // (a kept node went: start over)
+    for (size_t i = 0; i < nodes_.size(); i++) {
+        auto it = node_index_map_.find(nodes_[i]->id);
+        if (it == node_index_map_.end()) node_index_map_[nodes_[i]->id] = i;
+        else it->second = i;
+    }
+    if (node_index_map_.size() != nodes_.size()) {                            // stale entries: rebuild
+        node_index_map_.clear();
+        for (size_t i = 0; i < nodes_.size(); i++) node_index_map_[nodes_[i]->id] = i;
+    }
+    pass_base_id_ = next_node_id_;
+    pass_base_idx_ = nodes_.size();
     for (auto& kv : quant_cache_)
         if (kv.second.q) { pool_.release(kv.second.q); pool_.release(kv.second.scales); }
     quant_cache_.clear();
@@ -1485,6 +1516,8 @@ void CactusGraph::hard_reset() {
     nodes_.clear();
     spare_nodes_.clear();
     node_index_map_.clear();
+    pass_base_id_ = 0;
+    pass_base_idx_ = 0;
     is_weight_.clear();
     weight_cache_.clear();
     for (auto& kv : resident_) (void)hipFree(kv.second.dev);

@@ -284,8 +284,11 @@ private:
     // nodes a soft reset took out of the graph, kept for the next pass's add_node: a decode loop builds and drops
     // the same ~700 nodes per token, and their allocations were a third of what a token costs the host
     std::vector<std::unique_ptr<GraphNode>> spare_nodes_;
-    std::unordered_map<size_t, size_t> node_index_map_;
+    std::unordered_map<size_t, size_t> node_index_map_;   // the nodes a reset kept (ids below pass_base_id_)
     size_t next_node_id_ = 0;
+    size_t pass_base_id_ = 0, pass_base_idx_ = 0;          // nodes with id >= pass_base_id_ sit at pass_base_idx_ + (id - pass_base_id_)
+    bool find_index(size_t id, size_t* idx) const;
+    size_t index_of(size_t id) const;
     std::unordered_map<size_t, bool> is_weight_;   // node id -> bound with set_external_input
     // host pointer -> resident device copy (weights, scales)
     struct Resident { void* dev; size_t bytes; };
