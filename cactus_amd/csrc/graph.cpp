@@ -946,8 +946,13 @@ void CactusGraph::compute_embedding_node(GraphNode& n) {
         index_scratch_ = static_cast<int32_t*>(dev_alloc((count + 1) * sizeof(int32_t)));
         index_scratch_count_ = count + 1;
     }
-    int* flag = reinterpret_cast<int*>(index_scratch_ + count);
-    hip_check(hipMemsetAsync(flag, 0, sizeof(int), nullptr), "hipMemsetAsync");
+    // The flag is read back once, when the pass's launches are all enqueued (check_index_flag): a read here would hold
+    // the host until the lookup has run while the GPU waits for the launches behind it.
+    if (!index_flag_) {
+        index_flag_ = static_cast<int*>(dev_alloc(sizeof(int)));
+        hip_check(hipMemsetAsync(index_flag_, 0, sizeof(int), nullptr), "hipMemsetAsync");
+    }
+    int* flag = index_flag_;
     abi_check(cactus_hip_indices_to_int32_dev(idx.device_data, idx.precision == Precision::FP32 ? 2 : 0,
                                               index_scratch_, count, nullptr));
     cactus_half_t* out = static_cast<cactus_half_t*>(n.output_buffer.device_data);
@@ -963,9 +968,19 @@ void CactusGraph::compute_embedding_node(GraphNode& n) {
     } else {
         throw std::runtime_error("Embedding table must be INT8 or FP16");
     }
+    index_flag_pending_ = true;
+    index_flag_vocab_ = vocab;
+}
+
+void CactusGraph::check_index_flag() {
+    if (!index_flag_pending_) return;
+    index_flag_pending_ = false;
     int bad = 0;
-    hip_check(hipMemcpy(&bad, flag, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy D2H (index flag)");
-    if (bad) throw std::runtime_error("Embedding index out of bounds: >= " + std::to_string(vocab));
+    hip_check(hipMemcpy(&bad, index_flag_, sizeof(int), hipMemcpyDeviceToHost), "hipMemcpy D2H (index flag)");
+    if (bad) {
+        hip_check(hipMemsetAsync(index_flag_, 0, sizeof(int), nullptr), "hipMemsetAsync");
+        throw std::runtime_error("Embedding index out of bounds: >= " + std::to_string(index_flag_vocab_));
+    }
 }
 
 // A matmul node the batched decode launch can take: grouped INT8 or packed INT4 weights,
@@ -1447,17 +1462,24 @@ void CactusGraph::execute() {
         n.output_buffer.device_valid = true;
         done[idx] = 1;
     }
+    check_index_flag();
 }
 
 void* CactusGraph::get_device_output(size_t node_id) {
     BufferDesc& b = node(node_id).output_buffer;
-    if (!b.device_valid) materialize(index_of(node_id));   // a node a fused launch skipped
+    if (!b.device_valid) {      // a node a fused launch skipped
+        materialize(index_of(node_id));
+        check_index_flag();
+    }
     return b.device_data;
 }
 
 void* CactusGraph::get_output(size_t node_id) {   // graph_execute.cpp:223-229; synchronises
     BufferDesc& b = node(node_id).output_buffer;
-    if (!b.device_valid) materialize(index_of(node_id));   // a node a fused launch skipped
+    if (!b.device_valid) {      // a node a fused launch skipped
+        materialize(index_of(node_id));
+        check_index_flag();
+    }
     if (!b.device_valid || b.device_data == nullptr) return nullptr;
     b.host_copy.resize(b.byte_size);
     hip_check(hipMemcpy(b.host_copy.data(), b.device_data, b.byte_size, hipMemcpyDeviceToHost), "hipMemcpy D2H");
@@ -1532,6 +1554,9 @@ void CactusGraph::hard_reset() {
     if (index_scratch_) (void)hipFree(index_scratch_);
     index_scratch_ = nullptr;
     index_scratch_count_ = 0;
+    if (index_flag_) (void)hipFree(index_flag_);
+    index_flag_ = nullptr;
+    index_flag_pending_ = false;
     if (sample_state_) (void)hipFree(sample_state_);
     if (sample_work_) (void)hipFree(sample_work_);
     sample_state_ = nullptr;

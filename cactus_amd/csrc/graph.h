@@ -299,6 +299,10 @@ private:
     std::unordered_map<std::string, size_t> weight_cache_;   // file name -> node id
     int32_t* index_scratch_ = nullptr;   // int32 copy of an EMBEDDING node's indices + one flag word
     size_t index_scratch_count_ = 0;
+    int* index_flag_ = nullptr;          // set by an EMBEDDING launch that met an index >= its vocabulary
+    bool index_flag_pending_ = false;    // read back once, behind the pass's last launch (check_index_flag)
+    size_t index_flag_vocab_ = 0;
+    void check_index_flag();
     // SAMPLE: device history uint32[128], its count, the draw, the status word; workspace half[vocab]
     uint32_t* sample_state_ = nullptr;
     void* sample_work_ = nullptr;
