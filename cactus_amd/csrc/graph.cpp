@@ -1507,7 +1507,10 @@ void CactusGraph::soft_reset() {   // graph_execute.cpp:640-675: weights survive
             keep.push_back(std::move(up));
         } else {
             free_node(*up, pool_);
-            if (spare_nodes_.size() < 4096) spare_nodes_.push_back(std::move(up));
+            if (spare_nodes_.size() < 4096) {
+                if (!up->output_buffer.host_copy.empty()) std::vector<char>().swap(up->output_buffer.host_copy);   // no output copy outlives its pass
+                spare_nodes_.push_back(std::move(up));
+            }
         }
     }
     nodes_ = std::move(keep);
